@@ -1,0 +1,377 @@
+"""Generate golden vectors by RUNNING the reference (this container only).
+
+Usage:  python tests/golden/gen/gen_golden.py [name ...]
+
+Writes ``tests/golden/*.npz``.  Every array is produced by code under
+``/root/reference`` imported through ``refshim`` (third-party stand-ins only).
+The fixtures are data: inputs (initial states, actions, recorded reset draws)
+and expected outputs (every hot-path tensor after each step).
+
+Trajectory fixture layout (``traj_*.npz``), T steps, B envs, N agents:
+  meta_json                      parameters used
+  init_*                         state after the initial reset (+ derived tensors)
+  act[T,B,N,2]                   raw actions fed to the env
+  post_*[T,...]                  tensors after reward/observation/info, BEFORE done()
+  done[T,B]
+  next_*[T,...]                  tensors after done() and the resets of step t
+  ev_*                           flat list of reset events (step, kind, env, agent)
+                                 with the post-reset state of every agent of that env
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import refshim  # noqa: E402
+
+refshim.install()
+
+from sigmarl.helper_common import Parameters  # noqa: E402
+
+OUT = os.path.abspath(os.path.join(HERE, ".."))
+
+REWARD_FIELDS = [
+    "rew_progress", "rew_reach_goal", "rew_speed", "rew_centerline", "rew_near_other_agents",
+    "rew_near_left_lane", "rew_near_right_lane", "rew_collide_other_agents", "rew_collide_lane",
+    "rew_energy_acceleration", "rew_energy_steering", "rew_total",
+]
+
+
+def np_(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def snapshot(env, prefix, with_obs=None, rew=None):
+    sc = env.scenario
+    ws = sc.world_state
+    ag = env.world.agents
+    d = {}
+    d[prefix + "pos"] = np_(torch.stack([a.state.pos for a in ag], dim=1))
+    d[prefix + "rot"] = np_(torch.stack([a.state.rot for a in ag], dim=1).squeeze(-1))
+    d[prefix + "vel"] = np_(torch.stack([a.state.vel for a in ag], dim=1))
+    d[prefix + "speed"] = np_(torch.stack([a.state.speed for a in ag], dim=1).squeeze(-1))
+    d[prefix + "steering"] = np_(torch.stack([a.state.steering for a in ag], dim=1).squeeze(-1))
+    d[prefix + "sideslip"] = np_(torch.stack([a.state.sideslip_angle for a in ag], dim=1).squeeze(-1))
+    d[prefix + "vertices"] = np_(ws.vertices)
+    d[prefix + "dist_agents"] = np_(ws.distances.agents)
+    d[prefix + "dist_ref"] = np_(ws.distances.ref_paths)
+    d[prefix + "dist_left"] = np_(ws.distances.left_boundaries)
+    d[prefix + "dist_right"] = np_(ws.distances.right_boundaries)
+    d[prefix + "dist_bound"] = np_(ws.distances.boundaries)
+    d[prefix + "cp_ref"] = np_(ws.distances.closest_point_on_ref_path)
+    d[prefix + "cp_left"] = np_(ws.distances.closest_point_on_left_b)
+    d[prefix + "cp_right"] = np_(ws.distances.closest_point_on_right_b)
+    d[prefix + "short_term"] = np_(ws.ref_paths_agent_related.short_term)
+    d[prefix + "col_agents"] = np_(ws.collisions.with_agents)
+    d[prefix + "col_lane"] = np_(ws.collisions.with_lanelets)
+    d[prefix + "col_entry"] = np_(ws.collisions.with_entry_segments)
+    d[prefix + "col_exit"] = np_(ws.collisions.with_exit_segments)
+    d[prefix + "scenario_id"] = np_(ws.ref_paths_agent_related.scenario_id)
+    d[prefix + "path_id"] = np_(ws.ref_paths_agent_related.path_id)
+    d[prefix + "point_id"] = np_(ws.ref_paths_agent_related.point_id)
+    d[prefix + "timer_step"] = np_(sc.timer.step)
+    d[prefix + "prev_pos"] = np_(sc.state_buffer.get_latest(n=1)[:, :, 0:2])
+    if with_obs is not None:
+        d[prefix + "obs"] = np_(torch.stack(with_obs, dim=1))
+        d[prefix + "nearing_idx"] = np_(sc.observation_provider.observations.nearing_agents_indices)
+    if rew is not None:
+        d[prefix + "reward"] = np_(torch.stack(rew, dim=1))
+        for f in REWARD_FIELDS:
+            d[prefix + f] = np_(getattr(sc.reward_info, f))
+        d[prefix + "num_task_tries"] = np_(sc.num_task_tries)
+        d[prefix + "task_success_times"] = np_(sc.task_success_times)
+    return d
+
+
+def follow_policy(obs, gen, B, N, mode):
+    """obs: list of N tensors [B,32] (default obs layout, ego view).  mode[b]: 0 random, 1 follow."""
+    o = torch.stack(obs, dim=1)  # [B,N,32]
+    pt = o[:, :, 3:5]  # 2nd short-term point (ego frame, normalised)
+    ang = torch.atan2(pt[..., 1], pt[..., 0])
+    steer_f = (1.6 * ang).clamp(-0.5, 0.5) + (torch.rand(B, N, generator=gen) - 0.5) * 0.06
+    v_f = 0.55 + 0.45 * torch.rand(B, N, generator=gen)
+    v_r = torch.rand(B, N, generator=gen) * 1.3 - 0.1  # exercises the action clamp
+    steer_r = torch.rand(B, N, generator=gen) * 1.3 - 0.65  # exercises the steering clamp
+    m = mode.view(B, 1).expand(B, N)
+    v = torch.where(m == 1, v_f, v_r)
+    s = torch.where(m == 1, steer_f, steer_r)
+    return torch.stack([v, s], dim=-1).to(torch.float32)
+
+
+def run_traj(name, T, B, seed, mode_pattern, no_reset=False, **pkw):
+    torch.manual_seed(seed)
+    gen = torch.Generator().manual_seed(seed + 1000)
+    kw = dict(
+        is_obs_noise=False, is_apply_mask=False, max_steps=128, num_vmas_envs=B,
+        is_challenging_initial_state_buffer=False, is_testing_mode=False,
+    )
+    kw.update(pkw)
+    p = Parameters(**kw)
+    env = refshim.RefEnv(p, B)
+    sc = env.scenario
+    N = env.n_agents
+    mode = torch.tensor([mode_pattern[b % len(mode_pattern)] for b in range(B)])
+
+    events = []  # (step, kind, env, agent) + per-env state arrays
+    cur_step = [-1]
+    orig_reset = sc.reset_world_at
+
+    def logged_reset(env_index=None, agent_index=None):
+        orig_reset(env_index=env_index, agent_index=agent_index)
+        if env_index is None:
+            return
+        e = int(env_index)
+        ag = env.world.agents
+        rp = sc.world_state.ref_paths_agent_related
+        events.append(dict(
+            step=cur_step[0], kind=0 if agent_index is not None else 1, env=e,
+            agent=int(agent_index) if agent_index is not None else -1,
+            pos=np_(torch.stack([a.state.pos[e] for a in ag])),
+            rot=np_(torch.stack([a.state.rot[e] for a in ag]).squeeze(-1)),
+            vel=np_(torch.stack([a.state.vel[e] for a in ag])),
+            speed=np_(torch.stack([a.state.speed[e] for a in ag]).squeeze(-1)),
+            steering=np_(torch.stack([a.state.steering[e] for a in ag]).squeeze(-1)),
+            sideslip=np_(torch.stack([a.state.sideslip_angle[e] for a in ag]).squeeze(-1)),
+            scenario_id=np_(rp.scenario_id[e]), path_id=np_(rp.path_id[e]), point_id=np_(rp.point_id[e]),
+        ))
+
+    sc.reset_world_at = logged_reset
+
+    obs = env.observe()
+    out = {}
+    out.update(snapshot(env, "init_", with_obs=obs))
+    steps = []
+    for t in range(T):
+        cur_step[0] = t
+        act = follow_policy(obs, gen, B, N, mode)
+        env.set_actions(act)
+        env.world.step()
+        rew = [sc.reward(a).clone() for a in env.world.agents]
+        obs = [sc.observation(a).clone() for a in env.world.agents]
+        info = [refshim.TorchUtils.recursive_clone(sc.info(a)) for a in env.world.agents]
+        rec = {"act": np_(act)}
+        rec.update(snapshot(env, "post_", with_obs=obs, rew=rew))
+        rec["post_act_clamped"] = np_(torch.stack([a.action.u for a in env.world.agents], dim=1))
+        for key in ["rot", "distance_left_b", "distance_right_b", "is_collision_with_agents", "rew_total", "rew_near_other_agents", "rew_collide_lane"]:
+            rec["post_info_" + key] = np_(torch.stack([info[i][key].reshape(B, -1)[:, 0] if info[i][key].ndim > 1 else info[i][key] for i in range(N)], dim=1))
+        done = sc.done().clone()
+        rec["done"] = np_(done)
+        if not no_reset:
+            for e in torch.where(done)[0].tolist():
+                env.reset_env(e)
+        if done.any() or any(ev["step"] == t for ev in events):
+            obs = env.observe()
+        rec.update(snapshot(env, "next_", with_obs=obs))
+        steps.append(rec)
+    for k in steps[0]:
+        out[k] = np.stack([s[k] for s in steps], axis=0)
+    ne = len(events)
+    out["ev_step"] = np.asarray([e["step"] for e in events], np.int32).reshape(ne)
+    out["ev_kind"] = np.asarray([e["kind"] for e in events], np.int32).reshape(ne)
+    out["ev_env"] = np.asarray([e["env"] for e in events], np.int32).reshape(ne)
+    out["ev_agent"] = np.asarray([e["agent"] for e in events], np.int32).reshape(ne)
+    for k in ["pos", "rot", "vel", "speed", "steering", "sideslip", "scenario_id", "path_id", "point_id"]:
+        shp = events[0][k].shape if ne else ((N, 2) if k in ("pos", "vel") else (N,))
+        out["ev_" + k] = np.stack([e[k] for e in events], axis=0) if ne else np.zeros((0,) + shp, np.float32)
+    meta = dict(kw)
+    meta.update(dict(
+        n_agents=N, T=T, B=B, seed=seed, dt=p.dt, no_reset=bool(no_reset), rew_method=p.rew_method, scenario_type=p.scenario_type,
+        is_use_mtv_distance=p.is_use_mtv_distance,
+        thresholds=dict(
+            near_boundary_low=float(sc.thresholds.near_boundary_low), near_boundary_high=float(sc.thresholds.near_boundary_high),
+            near_other_agents_low=float(sc.thresholds.near_other_agents_low), near_other_agents_high=float(sc.thresholds.near_other_agents_high),
+            ttc_low=float(sc.thresholds.ttc_low), ttc_high=float(sc.thresholds.ttc_high),
+        ),
+        penalties=dict(
+            near_boundary=float(sc.penalties.near_boundary), near_other_agents=float(sc.penalties.near_other_agents),
+            collide_with_agents=float(sc.penalties.collide_with_agents), collide_with_boundaries=float(sc.penalties.collide_with_boundaries),
+        ),
+        rewards=dict(progress=float(sc.rewards.progress), reach_goal=float(sc.rewards.reach_goal)),
+        n_events=ne, n_done=int(out["done"].sum()),
+        n_col_agents=int(out["post_col_agents"].any(-1).sum()), n_col_lane=int(out["post_col_lane"].sum()),
+        n_exit=int(out["post_col_exit"].sum()), n_entry=int(out["post_col_entry"].sum()),
+    ))
+    out["meta_json"] = np.asarray(json.dumps(meta))
+    path = os.path.join(OUT, f"traj_{name}.npz")
+    np.savez_compressed(path, **out)
+    print(name, {k: meta[k] for k in ["n_events", "n_done", "n_col_agents", "n_col_lane", "n_exit", "n_entry"]},
+          f"{os.path.getsize(path)/1e6:.2f} MB")
+
+
+# --------------------------------------------------------------------------- #
+# function-level goldens (direct calls into sigmarl/helper_scenario.py etc.)
+# --------------------------------------------------------------------------- #
+def gen_functions():
+    from sigmarl.constants import AGENTS
+    from sigmarl.dynamics import KinematicBicycleModel
+    from sigmarl.helper_scenario import (
+        angle_eliminate_two_pi, get_distances_between_agents, get_perpendicular_distances,
+        get_rectangle_vertices, get_short_term_reference_path, interX,
+        transform_from_global_to_local_coordinate,
+    )
+    from sigmarl.helper_training import WorldCustom
+    from sigmarl.helper_common import Vehicle
+    from sigmarl.interX_original import interX as interX_np
+    import refshim as rs
+
+    g = torch.Generator().manual_seed(7)
+    out = {}
+
+    # G1: WorldCustom.step (helper_training.py:797-861) + KinematicBicycleModel (dynamics.py:62-192)
+    Bn = 4096
+    for dt_name, dt in (("dt05", 0.05), ("dt10", 0.1)):
+        world = WorldCustom(Bn, torch.device("cpu"), x_semidim=torch.tensor(4.5), y_semidim=torch.tensor(4.0), dt=dt)
+        veh = Vehicle(
+            name="a", shape=rs.Box(AGENTS["length"], AGENTS["width"]), u_range=[AGENTS["max_speed"], AGENTS["max_steering"]],
+            u_multiplier=[1, 1], max_speed=AGENTS["max_speed"],
+            dynamics=KinematicBicycleModel(
+                l_f=AGENTS["l_f"], l_r=AGENTS["l_r"], max_speed=AGENTS["max_speed"], min_speed=AGENTS["min_speed"],
+                max_steering=AGENTS["max_steering"], min_steering=AGENTS["min_steering"], max_acc=AGENTS["max_acc"],
+                min_acc=AGENTS["min_acc"], max_steering_rate=AGENTS["max_steering_rate"],
+                min_steering_rate=AGENTS["min_steering_rate"], device="cpu"),
+        )
+        world.add_agent(veh)
+        pos = torch.rand(Bn, 2, generator=g) * 4
+        rot = (torch.rand(Bn, 1, generator=g) * 2 - 1) * 7.0
+        speed = torch.rand(Bn, 1, generator=g) * 1.2 - 0.1
+        steering = (torch.rand(Bn, 1, generator=g) * 2 - 1) * 0.6
+        u = torch.stack([torch.rand(Bn, generator=g) * 1.6 - 0.3, (torch.rand(Bn, generator=g) * 2 - 1) * 0.8], dim=-1)
+        veh.state.pos, veh.state.rot, veh.state.speed, veh.state.steering = pos.clone(), rot.clone(), speed.clone(), steering.clone()
+        veh.action.u = u.clone()
+        world.step()
+        out[f"g1_{dt_name}_in"] = np_(torch.cat([pos, rot, speed, steering, u], dim=-1))
+        out[f"g1_{dt_name}_out"] = np_(torch.cat(
+            [veh.state.pos, veh.state.rot, veh.state.speed, veh.state.steering, veh.state.vel, veh.state.sideslip_angle, veh.action.u], dim=-1))
+
+    # G2: get_rectangle_vertices (helper_scenario.py:695-826)
+    c = torch.rand(2048, 2, generator=g) * 4
+    y = (torch.rand(2048, 1, generator=g) * 2 - 1) * 7
+    out["g2_in"] = np_(torch.cat([c, y], dim=-1))
+    out["g2_out"] = np_(get_rectangle_vertices(c, y, AGENTS["width"], AGENTS["length"], True))
+
+    # G5: get_distances_between_agents c2c / mtv (helper_scenario.py:999-1145) on a relative-pose grid
+    # (the known-answer generator of mtv_based_sm_predictor.py:181-235, reduced) + random poses incl. overlaps
+    xs = torch.linspace(-0.5, 0.5, 15)
+    ys = torch.linspace(-0.5, 0.5, 15)
+    ps = torch.linspace(-math.pi, math.pi, 13)
+    gx, gy, gp = torch.meshgrid(xs, ys, ps, indexing="ij")
+    rel = torch.stack([gx.reshape(-1), gy.reshape(-1), gp.reshape(-1)], dim=-1)
+    extra = torch.cat([(torch.rand(3000, 2, generator=g) - 0.5) * 0.6, (torch.rand(3000, 1, generator=g) * 2 - 1) * math.pi], dim=-1)
+    rel = torch.cat([rel, extra], dim=0)
+    nb = rel.shape[0]
+    ego_pos = torch.rand(nb, 2, generator=g) * 3 + 0.5
+    ego_rot = (torch.rand(nb, 1, generator=g) * 2 - 1) * math.pi
+    oth_pos = ego_pos + rel[:, 0:2]
+    oth_rot = ego_rot + rel[:, 2:3]
+    v0 = get_rectangle_vertices(ego_pos, ego_rot, AGENTS["width"], AGENTS["length"], True)
+    v1 = get_rectangle_vertices(oth_pos, oth_rot, AGENTS["width"], AGENTS["length"], True)
+    verts = torch.stack([v0, v1], dim=1)  # [nb,2,5,2]
+    out["g5_vertices"] = np_(verts)
+    out["g5_mtv"] = np_(get_distances_between_agents(verts, "mtv", True, torch.tensor(4.5), torch.tensor(4.0)))
+    out["g5_c2c"] = np_(get_distances_between_agents(torch.stack([ego_pos, oth_pos]), "c2c", True, torch.tensor(4.5), torch.tensor(4.0)))
+    out["g5_pos"] = np_(torch.stack([ego_pos, oth_pos], dim=1))
+    # G6: interX rectangle/rectangle (helper_scenario.py:1148-1229), cross-checked with interX_original.py
+    hit = interX(v0, v1, False)
+    out["g6_hit"] = np_(hit)
+    chk = np.zeros(nb, bool)
+    for b in range(0, nb, 7):
+        chk[b] = bool(interX_np(v0[b].numpy().T.astype(np.float64), v1[b].numpy().T.astype(np.float64)))
+    out["g6_hit_original_every7"] = chk
+
+    # G3/G4/G6b: point->polyline, short-term path, rectangle/boundary interX on CPM paths (padded like world_state_rt.py:313-420)
+    p = Parameters(n_agents=2, scenario_type="cpm_entire", is_obs_noise=False, is_apply_mask=False, num_vmas_envs=1, is_use_mtv_distance=False)
+    env = refshim.RefEnv(p, 1)
+    ws = env.scenario.world_state
+    paths = env.scenario.map.parser.reference_paths
+    ext = ws.ref_paths_map_related.point_extended_all
+    q_pts, q_path, r_d, r_i, r_dl, r_il, r_dr, r_ir, r_st, r_hitl, r_hitr, q_rot = [], [], [], [], [], [], [], [], [], [], [], []
+    tables = {}
+    for pid in [0, 5, 17, 39]:
+        rp = paths[pid]
+        ws._reset_agent_related_ref_path(0, 0, rp, pid, ext)
+        ra = ws.ref_paths_agent_related
+        lt, lb, rb = ra.long_term[0, 0].clone(), ra.left_boundary[0, 0].clone(), ra.right_boundary[0, 0].clone()
+        n_lt, n_l, n_r = ra.n_points_long_term[0, 0].clone(), ra.n_points_left_b[0, 0].clone(), ra.n_points_right_b[0, 0].clone()
+        tables[f"g3_path{pid}_long_term"] = np_(lt)
+        tables[f"g3_path{pid}_left"] = np_(lb)
+        tables[f"g3_path{pid}_right"] = np_(rb)
+        tables[f"g3_path{pid}_n"] = np.asarray([int(n_lt), int(n_l), int(n_r), int(bool(rp["is_loop"]))], np.int32)
+        n = int(n_lt)
+        cl = rp["center_line"]
+        M = 400
+        idx = torch.randint(0, n, (M,), generator=g)
+        idx[:40] = torch.cat([torch.arange(0, 20), torch.arange(n - 20, n)])  # the loop seam
+        pts = cl[idx] + (torch.rand(M, 2, generator=g) - 0.5) * 0.16
+        rot = ra.long_term.new_tensor(rp["center_line_yaw"][idx.clamp(max=rp["center_line_yaw"].shape[0] - 1)]).reshape(M, 1) + (torch.rand(M, 1, generator=g) - 0.5) * 0.8
+        nn = n_lt.repeat(M)
+        d, i = get_perpendicular_distances(pts, lt.unsqueeze(0).expand(M, -1, -1), nn)
+        dl, il = get_perpendicular_distances(pts, lb.unsqueeze(0).expand(M, -1, -1), n_l.repeat(M))
+        dr, ir = get_perpendicular_distances(pts, rb.unsqueeze(0).expand(M, -1, -1), n_r.repeat(M))
+        st, _ = get_short_term_reference_path(
+            lt.unsqueeze(0).expand(M, -1, -1), i.to(torch.int32), 3, torch.device("cpu"),
+            torch.tensor(bool(rp["is_loop"])).repeat(M), nn, 2)
+        vv = get_rectangle_vertices(pts, rot, AGENTS["width"], AGENTS["length"], True)
+        hl = interX(vv, lb.unsqueeze(0).expand(M, -1, -1), False)
+        hr = interX(vv, rb.unsqueeze(0).expand(M, -1, -1), False)
+        q_pts.append(np_(pts)); q_rot.append(np_(rot)); q_path.append(np.full(M, pid, np.int32))
+        r_d.append(np_(d)); r_i.append(np_(i)); r_dl.append(np_(dl)); r_il.append(np_(il)); r_dr.append(np_(dr)); r_ir.append(np_(ir))
+        r_st.append(np_(st)); r_hitl.append(np_(hl)); r_hitr.append(np_(hr))
+    out.update(tables)
+    out["g3_pts"] = np.concatenate(q_pts); out["g3_rot"] = np.concatenate(q_rot); out["g3_path"] = np.concatenate(q_path)
+    out["g3_d_ref"] = np.concatenate(r_d); out["g3_i_ref"] = np.concatenate(r_i)
+    out["g3_d_left"] = np.concatenate(r_dl); out["g3_i_left"] = np.concatenate(r_il)
+    out["g3_d_right"] = np.concatenate(r_dr); out["g3_i_right"] = np.concatenate(r_ir)
+    out["g4_short_term"] = np.concatenate(r_st)
+    out["g6_hit_left"] = np.concatenate(r_hitl); out["g6_hit_right"] = np.concatenate(r_hitr)
+
+    # G8: ego transform + angle wrap (helper_scenario.py:1241-1289)
+    pi_ = torch.rand(1024, 2, generator=g) * 4
+    pj = pi_.unsqueeze(1) + (torch.rand(1024, 6, 2, generator=g) - 0.5) * 1.5
+    pj[:, 0] = pi_  # self-transform (atan2(0,0))
+    ri = (torch.rand(1024, 1, generator=g) * 2 - 1) * 9
+    out["g8_pos_i"], out["g8_pos_j"], out["g8_rot_i"] = np_(pi_), np_(pj), np_(ri)
+    out["g8_rel"] = np_(transform_from_global_to_local_coordinate(pi_, pj, ri))
+    ang = (torch.rand(4096, generator=g) * 2 - 1) * 20
+    out["g8_angle_in"] = np_(ang)
+    out["g8_angle_out"] = np_(angle_eliminate_two_pi(ang.clone()))
+
+    path = os.path.join(OUT, "functions.npz")
+    np.savez_compressed(path, **out)
+    print("functions", f"{os.path.getsize(path)/1e6:.2f} MB", "rect hits", int(out["g6_hit"].sum()), "lane hits", int(out["g6_hit_left"].sum()), int(out["g6_hit_right"].sum()),
+          "neg mtv", int((out["g5_mtv"][:, 0, 1] < 0).sum()), "zero mtv", int((out["g5_mtv"][:, 0, 1] == 0).sum()))
+    agree = (out["g6_hit"][::7] == chk[::7]).mean()
+    print("interX vs interX_original agreement on sampled cases:", agree)
+
+
+TRAJS = {
+    "cpm16_c2c": dict(T=32, B=4, seed=11, mode_pattern=[1, 0, 1, 1], n_agents=16, scenario_type="cpm_entire", dt=0.05,
+                      is_use_mtv_distance=False, rew_method="distance"),
+    "cpm16_mtv": dict(T=32, B=4, seed=12, mode_pattern=[1, 1, 0, 1], n_agents=16, scenario_type="cpm_entire", dt=0.1,
+                      is_use_mtv_distance=True, rew_method="ttc_sparse"),
+    "intersection4_c2c": dict(T=64, B=2, seed=13, mode_pattern=[1, 1], n_agents=4, scenario_type="intersection_1", dt=0.1,
+                              is_use_mtv_distance=False, rew_method="distance_sparse"),
+    "onramp6_mtv": dict(T=64, B=3, seed=14, mode_pattern=[1, 1, 0], n_agents=6, scenario_type="on_ramp_1", dt=0.1,
+                        is_use_mtv_distance=True, rew_method="ttc"),
+    # done envs are NOT reset: long runs with persistent collisions and agents far off their lanes
+    "cpm16_c2c_noreset": dict(T=40, B=3, seed=16, mode_pattern=[1, 0, 1], no_reset=True, n_agents=16, scenario_type="cpm_entire",
+                              dt=0.05, is_use_mtv_distance=False, rew_method="ttc"),
+    "cpm8_mtv_noreset": dict(T=40, B=3, seed=17, mode_pattern=[0, 1, 1], no_reset=True, n_agents=8, scenario_type="cpm_entire",
+                             dt=0.1, is_use_mtv_distance=True, rew_method="distance_sparse"),
+    "cpmmixed4_c2c": dict(T=48, B=4, seed=15, mode_pattern=[1, 0, 1, 1], n_agents=4, scenario_type="cpm_mixed", dt=0.05,
+                          is_use_mtv_distance=False, rew_method="sparse", cpm_scenario_probabilities=[1.0, 0.0, 0.0]),
+}
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or (["functions"] + list(TRAJS))
+    for nme in names:
+        if nme == "functions":
+            gen_functions()
+        else:
+            run_traj(nme, **TRAJS[nme])
