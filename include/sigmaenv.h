@@ -1,0 +1,178 @@
+/*
+ * sigmaenv.h -- C-ABI of the MI355X-native vectorized multi-agent CAV environment step.
+ *
+ * The reference (bassamlab/SigmaRL) has no FFI: its boundary for this path is the
+ * VMAS plugin surface driven by TorchRL's VmasEnv.  This header defines the C-ABI
+ * that sits directly underneath that surface; every entry point cites the reference
+ * interface it replaces (paths relative to /root/reference).
+ *
+ *   sigmaenv_create        <- ScenarioRoadTraffic.make_world            sigmarl/scenarios/road_traffic.py:104-110,112-768
+ *                             WorldStateRT._init_stateful_parameters     sigmarl/scenarios/world_state/world_state_rt/world_state_rt.py:119-277
+ *                             (+ _extend_map_related_ref_path :279-311, path padding :313-420)
+ *   sigmaenv_reset         <- ScenarioRoadTraffic.reset_world_at         sigmarl/scenarios/road_traffic.py:816-923
+ *                             WorldStateRTSimulation.reset               .../world_state_rt_sim.py:73-141 (deterministic part:
+ *                             the random draws of :215-311 are made by the caller and passed in)
+ *                             reset_init_distances_and_short_term_ref_path .../world_state_rt.py:422-576
+ *   sigmaenv_step          <- WorldCustom.step                           sigmarl/helper_training.py:797-861
+ *                             KinematicBicycleModel.ode/.step            sigmarl/dynamics.py:62-192
+ *                             ScenarioRoadTraffic.reward (all agents)    sigmarl/scenarios/road_traffic.py:925-1332
+ *                             ScenarioRoadTraffic.observation (all)      :1334-1366  (+ observation_provider_rt.py:345-961)
+ *                             ScenarioRoadTraffic.done                   :1368-1487  (flags + reset requests; the host performs the resets)
+ *   sigmaenv_observe       <- ScenarioRoadTraffic.observation called again after a reset (VmasEnv reset path)
+ *   sigmaenv_auto_reset    <- TorchRL step_and_maybe_reset -> Environment.reset_at -> reset_world_at for done envs, with the
+ *                             rejection sampler of world_state_rt_sim.py:215-311 run on device from a counter-based RNG
+ *                             (distributional parity only: the reference draws from torch's global generator)
+ *   sigmaenv_get           <- the tensors ScenarioRoadTraffic.info exposes   sigmarl/scenarios/road_traffic.py:1489-1635
+ *
+ * Conventions: return 0 on success, negative SIGMAENV_E* otherwise.  The handle is thread-compatible (the caller
+ * serialises calls).  All work is enqueued on the HIP stream given at create; no call synchronises the host except
+ * sigmaenv_create / sigmaenv_destroy / sigmaenv_reset (host inputs are copied before it returns).  Output buffers are owned by
+ * the library until destroy; pointers returned by sigmaenv_get are DEVICE pointers valid for the handle's lifetime.
+ *
+ * The CPU oracle (oracle/sigmaenv_oracle.c, test infrastructure) exports the same entry points with the prefix
+ * sigmaenv_oracle_ operating on host memory.
+ */
+#ifndef SIGMAENV_H
+#define SIGMAENV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SIGMAENV_ABI_VERSION 1
+
+/* error codes */
+#define SIGMAENV_OK 0
+#define SIGMAENV_EINVAL (-22)      /* bad argument / unsupported configuration */
+#define SIGMAENV_ENOMEM (-12)
+#define SIGMAENV_EHIP (-5)         /* HIP runtime error, see sigmaenv_last_error */
+#define SIGMAENV_ENODEV (-19)      /* no usable gfx950 device */
+
+/* distance_type (helper_scenario.py:999-1145) */
+#define SIGMAENV_DIST_C2C 0
+#define SIGMAENV_DIST_MTV 1
+
+/* rew_flags, decoded from Parameters.rew_method exactly as road_traffic.py:1056-1151 tests the string */
+#define SIGMAENV_REW_DISTANCE 1     /* "distance" in rew_method */
+#define SIGMAENV_REW_TTC 2          /* "ttc" in rew_method */
+#define SIGMAENV_REW_EXACT_SPARSE 4 /* rew_method == "sparse" */
+#define SIGMAENV_REW_HAS_SPARSE 8   /* "sparse" in rew_method */
+
+#define SIGMAENV_N_SHORT_TERM 3     /* n_points_short_term (config.json:27) */
+#define SIGMAENV_MAX_NEARING 4      /* n_nearing_agents_observed <= 4 (default 2) */
+#define SIGMAENV_MAX_AGENTS 64
+#define SIGMAENV_N_REWARD_INFO 12   /* RewardInfo fields, helper_scenario.py:101-114 */
+
+typedef struct sigmaenv_config {
+  int32_t abi_version;   /* SIGMAENV_ABI_VERSION */
+  int32_t n_envs;        /* VMAS batch_dim (this shard) */
+  int32_t n_agents;
+  int32_t distance_type; /* SIGMAENV_DIST_* ; Parameters.is_use_mtv_distance */
+  int32_t rew_flags;     /* SIGMAENV_REW_* */
+  int32_t is_testing_mode;
+  int32_t has_entry_exit;/* scenario_type != "cpm_entire": per-agent reset requests for entry/exit leavers (road_traffic.py:1456-1473) */
+  int32_t max_steps;     /* Parameters.max_steps */
+  int32_t n_nearing;     /* min(n_nearing_agents_observed, n_agents-1) */
+  int32_t reserved0;
+  float dt;
+  float length, width, l_f, l_r;                    /* constants.py:628-636 */
+  float max_speed, max_steering;                    /* constants.py:637-640 */
+  float min_acc, max_acc, min_steering_rate, max_steering_rate;
+  float world_x_dim, world_y_dim;                   /* parser.bounds */
+  float lane_width;                                 /* SCENARIOS[...]["lane_width"]; normalizers.distance_lanelet = 3*lane_width */
+  float reward_progress, reward_reach_goal;         /* road_traffic.py:133-137,217-219 */
+  float penalty_near_boundary, penalty_near_other_agents;
+  float penalty_collide_with_agents, penalty_collide_with_boundaries;
+  float threshold_near_boundary_low, threshold_near_boundary_high;
+  float threshold_near_other_agents_low, threshold_near_other_agents_high;
+  float ttc_low, ttc_high;
+} sigmaenv_config_t;
+
+/* Unpadded reference-path table (output of the map parser, sigmarl/map_manager.py:13-40).  The library builds the padded
+ * per-path polylines itself exactly as world_state_rt.py:279-420 does (centre line + 6 extended points + last-point padding;
+ * boundaries padded with their last point). */
+typedef struct sigmaenv_map {
+  int32_t n_paths;
+  int32_t stride_points;     /* points per path in the arrays below */
+  const float* center;       /* [n_paths, stride_points, 2]  ref_path["center_line"] */
+  const float* left;         /* [n_paths, stride_points, 2]  ref_path["left_boundary_shared"] */
+  const float* right;        /* [n_paths, stride_points, 2]  ref_path["right_boundary_shared"] */
+  const float* yaw;          /* [n_paths, stride_points]     ref_path["center_line_yaw"] */
+  const int32_t* n_center;   /* [n_paths] */
+  const int32_t* n_left;
+  const int32_t* n_right;
+  const uint8_t* is_loop;    /* [n_paths] */
+} sigmaenv_map_t;
+
+/* buffers readable through sigmaenv_get; shapes with B = n_envs, N = n_agents, K = n_nearing, D = obs_dim */
+typedef enum sigmaenv_buf {
+  SIGMAENV_BUF_STATE = 0,        /* f32 [B,N,8]  x, y, psi, speed, steering, vx, vy, sideslip                */
+  SIGMAENV_BUF_PREV_POS = 1,     /* f32 [B,N,2]  state_buffer.get_latest(1)[..., 0:2]                      */
+  SIGMAENV_BUF_VERTICES = 2,     /* f32 [B,N,5,2]                                                           */
+  SIGMAENV_BUF_PATH = 3,         /* i32 [B,N,4]  global path index, scenario_id, path_id, point_id        */
+  SIGMAENV_BUF_SHORT_TERM = 4,   /* f32 [B,N,3,2]                                                           */
+  SIGMAENV_BUF_DIST_REF = 5,     /* f32 [B,N]                                                               */
+  SIGMAENV_BUF_DIST_LEFT = 6,    /* f32 [B,N,5]  CG - width/2, then the 4 corners                          */
+  SIGMAENV_BUF_DIST_RIGHT = 7,   /* f32 [B,N,5]                                                             */
+  SIGMAENV_BUF_DIST_BOUND = 8,   /* f32 [B,N]                                                               */
+  SIGMAENV_BUF_CLOSEST = 9,      /* i32 [B,N,3]  closest point on ref path / left / right (already +1)      */
+  SIGMAENV_BUF_DIST_AGENTS = 10, /* f32 [B,N,N]                                                             */
+  SIGMAENV_BUF_COL_AGENTS = 11,  /* u8  [B,N,N]                                                             */
+  SIGMAENV_BUF_COL_FLAGS = 12,   /* u8  [B,N,4]  with_lanelets, with_entry_segments, with_exit_segments, reset_request */
+  SIGMAENV_BUF_REWARD = 13,      /* f32 [B,N]                                                               */
+  SIGMAENV_BUF_REWARD_INFO = 14, /* f32 [12,B,N] RewardInfo fields in declaration order                     */
+  SIGMAENV_BUF_OBS = 15,         /* f32 [B,N,D]                                                             */
+  SIGMAENV_BUF_NEARING = 16,     /* i32 [B,N,K]                                                             */
+  SIGMAENV_BUF_DONE = 17,        /* u8  [B]                                                                 */
+  SIGMAENV_BUF_TIMER = 18,       /* i32 [B,4]    timer.step, num_task_tries, task_success_times, episodes_reset */
+  SIGMAENV_BUF_ACTION = 19,      /* f32 [B,N,2]  clamped action (agent.action.u after WorldCustom.step)     */
+  SIGMAENV_BUF_COUNT = 20
+} sigmaenv_buf_t;
+
+typedef struct sigmaenv sigmaenv_t;
+
+/* obs_dim for the default observation flags (config.json:36-45): 1 + 2*3 + 3 + K*(8+2+1) */
+int sigmaenv_obs_dim(int32_t n_nearing);
+
+/* device_id: HIP device ordinal.  hip_stream: hipStream_t to enqueue on (NULL = the device's default stream). */
+int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_t* map, int device_id, void* hip_stream,
+                    sigmaenv_t** out);
+void sigmaenv_destroy(sigmaenv_t* h);
+const char* sigmaenv_last_error(const sigmaenv_t* h);
+
+/* Host-chosen resets.  n entries (HOST pointers), entry k resets agent agent_idx[k] of env env_idx[k]:
+ *   path_ids[k*4 + {0,1,2,3}] = global path index, scenario_id, path_id, point_id
+ *   state8[k*8 + ...]         = x, y, psi, speed, steering, vx, vy, sideslip
+ * After applying the entries every touched env gets: initial distances / vertices / short-term path of the reset agents,
+ * mutual distances recomputed, collision flags cleared, prev_pos := pos (road_traffic.py:888-923).
+ * full_env != 0: additionally timer.step := 0 and the clamped-action buffer of the env is zeroed (world.reset(e)). */
+int sigmaenv_reset(sigmaenv_t* h, int32_t n, const int32_t* env_idx, const int32_t* agent_idx, const int32_t* path_ids,
+                   const float* state8, int32_t full_env);
+
+/* One fused environment step for all envs.  actions: DEVICE pointer f32 [B,N,2] (v_cmd, delta_cmd), not modified. */
+int sigmaenv_step(sigmaenv_t* h, const float* actions);
+
+/* Recompute observations from the current state (observation() called again after resets). */
+int sigmaenv_observe(sigmaenv_t* h);
+
+/* Device-side reset of every env whose done flag is set: rejection sampling of collision-free starts
+ * (bounded retries), then the same deterministic reset as sigmaenv_reset(full_env=1) and a fresh observation.
+ * seed/counter select the counter-based random stream. */
+int sigmaenv_auto_reset(sigmaenv_t* h, uint64_t seed, uint64_t counter);
+
+int sigmaenv_get(sigmaenv_t* h, sigmaenv_buf_t which, void** dev_ptr, size_t* bytes);
+
+/* Blocks until everything enqueued on the handle's stream has finished. */
+int sigmaenv_sync(sigmaenv_t* h);
+
+/* Average device time (ms) of the last `sigmaenv_step` launches measured with HIP events on the handle's stream
+ * since the previous call; n_launches receives the count.  Profiling aid for bench.py. */
+int sigmaenv_step_time_ms(sigmaenv_t* h, double* avg_ms, int32_t* n_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIGMAENV_H */

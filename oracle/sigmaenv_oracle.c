@@ -1,0 +1,835 @@
+/*
+ * sigmaenv_oracle.c -- CPU restatement of SigmaRL's environment-step hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the parity checker for the HIP product
+ * (sigmarl_amd/csrc).  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it; the product never links, imports or calls it.
+ *
+ * Parity status: PINNED.  tests/test_oracle_golden.py checks every function below
+ * against golden vectors produced by running the reference itself in the build
+ * container (tests/golden/*.npz, generator tests/golden/gen/gen_golden.py).
+ * Third-party pieces the reference pulls from packages absent from
+ * /root/reference are restated from their published behaviour and are "unpinned":
+ *   torchdiffeq==0.2.5 odeint(method="euler")  -> one explicit Euler step
+ *   vmas==1.4.3 call order                     -> world.step; reward(a) for all a; observation(a) for all a; done()
+ *
+ * Arithmetic contract (shared with the HIP kernels, stated in DESIGN.md):
+ *   - fp32 everywhere, one IEEE operation per reference torch op, no FMA contraction
+ *     (-ffp-contract=off) EXCEPT torch.norm over a length-2 dim, which PyTorch-CPU
+ *     evaluates as sqrt(fma(y, y, x*x)) [measured in the build container];
+ *   - sin/cos/tan/atan/atan2 are the correctly rounded fp32 value, obtained as
+ *     (float)f((double)x) (the reference uses SLEEF, within 1 ulp of this);
+ *   - argmin/top-k ties resolve to the lowest index (torch.min semantics).
+ *
+ * Every function cites the reference lines it follows (paths relative to
+ * /root/reference/sigmarl).
+ */
+#include "../include/sigmaenv.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define NS SIGMAENV_N_SHORT_TERM
+#define PI32 3.14159274101257324f  /* float32(math.pi)   */
+#define TWO_PI32 6.28318548202514648f /* float32(2*math.pi) */
+
+typedef struct sigmaenv_oracle {
+  sigmaenv_config_t cfg;
+  int B, N, K, D, P, n_paths, yaw_stride;
+  float *center, *left, *right; /* [n_paths][P][2] padded as world_state_rt.py:313-420 */
+  float* yaw;                   /* [n_paths][yaw_stride] */
+  int32_t *n_center, *n_left, *n_right;
+  uint8_t* is_loop;
+  float *state, *prev_pos, *vertices, *short_term, *dist_ref, *dist_left, *dist_right, *dist_bound, *dist_agents;
+  float *reward, *reward_info, *obs, *action;
+  int32_t *path, *closest, *nearing, *timer;
+  uint8_t *col_agents, *col_flags, *done;
+  char err[256];
+} oracle_t;
+
+/* ---- scalar helpers ------------------------------------------------------------------------------------------- */
+static inline float cr_sin(float x) { return (float)sin((double)x); }
+static inline float cr_cos(float x) { return (float)cos((double)x); }
+static inline float cr_tan(float x) { return (float)tan((double)x); }
+static inline float cr_atan(float x) { return (float)atan((double)x); }
+static inline float cr_atan2(float y, float x) { return (float)atan2((double)y, (double)x); }
+/* torch.norm(..., dim=<len-2 dim>) on PyTorch-CPU == sqrt(fma(y,y,x*x)) */
+static inline float norm2(float x, float y) { return sqrtf(fmaf(y, y, x * x)); }
+static inline float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+/* torch.remainder(a, b), b > 0 (fmod, then shift negatives): dynamics.py:158, helper_scenario.py:1286-1289 */
+static inline float remainder_pos(float a, float b) {
+  float m = fmodf(a, b);
+  if (m != 0.0f && m < 0.0f) m += b;
+  return m;
+}
+static inline float angle_eliminate_two_pi(float a) { /* helper_scenario.py:1276-1289 */
+  float r = remainder_pos(a, TWO_PI32);
+  if (r > PI32) r -= TWO_PI32;
+  return r;
+}
+/* decreasing_fcn(type="linear"), helper_scenario.py:960-996 */
+static inline float decreasing_lin(float x, float x0, float x1) {
+  x = clampf(x, x0, x1);
+  float denom = x1 - x0;
+  return 1.0f - (x - x0) / denom;
+}
+
+/* ---- K1: WorldCustom.step + KinematicBicycleModel, helper_training.py:797-861, dynamics.py:62-192 ----------------- */
+static void bicycle_step(const sigmaenv_config_t* c, float* s /*8*/, const float* u_in, float* u_clamped) {
+  float a0 = clampf(u_in[0], -c->max_speed, c->max_speed);        /* helper_training.py:807-812 */
+  float a1 = clampf(u_in[1], -c->max_steering, c->max_steering);  /* :813-818 */
+  u_clamped[0] = a0;
+  u_clamped[1] = a1;
+  float x = s[0], y = s[1], psi = s[2], v = s[3], delta = s[4];
+  float u_acc = (a0 - v) / c->dt;                                  /* :821 */
+  float u_sr = (a1 - delta) / c->dt;                               /* :822-824 */
+  u_acc = clampf(u_acc, c->min_acc, c->max_acc);                   /* :829-831 */
+  u_sr = clampf(u_sr, c->min_steering_rate, c->max_steering_rate); /* :832-836 */
+  float l_wb = (float)((double)c->l_f + (double)c->l_r);
+  float k_beta = (float)((double)c->l_r / ((double)c->l_f + (double)c->l_r));
+  float beta = cr_atan(k_beta * cr_tan(delta));                    /* dynamics.py:103 */
+  float dx0 = v * cr_cos(psi + beta);                              /* :107 */
+  float dx1 = v * cr_sin(psi + beta);                              /* :108 */
+  float dx2 = (v / l_wb) * cr_tan(delta) * cr_cos(beta);           /* :109-111 */
+  float dt = c->dt;                                                /* t = linspace(0, dt, 2); one Euler step :149-156 */
+  x = x + dt * dx0;
+  y = y + dt * dx1;
+  psi = psi + dt * dx2;
+  v = v + dt * u_acc;
+  delta = delta + dt * u_sr;
+  delta = remainder_pos(delta + PI32, TWO_PI32) - PI32;            /* :158 */
+  float beta1 = cr_atan(k_beta * cr_tan(delta));                   /* :161-163 */
+  float course = psi + beta1;                                      /* :166 */
+  s[0] = x; s[1] = y; s[2] = psi; s[3] = v; s[4] = delta;
+  s[5] = v * cr_cos(course);                                       /* :167 */
+  s[6] = v * cr_sin(course);                                       /* :168 */
+  s[7] = beta1;
+}
+
+/* ---- K2: get_rectangle_vertices, helper_scenario.py:695-826 (is_close_shape=True) ------------------------------- */
+static void rect_vertices(const sigmaenv_config_t* c, float px, float py, float psi, float* v /*5x2*/) {
+  float lh = (float)((double)c->length / 2.0), wh = (float)((double)c->width / 2.0);
+  const float bx[5] = {lh, lh, -lh, -lh, lh};
+  const float by[5] = {wh, -wh, -wh, wh, wh};
+  float cs = cr_cos(psi), sn = cr_sin(psi);
+  float nsn = -sn;
+  for (int k = 0; k < 5; ++k) { /* bmm [[c,-s],[s,c]] x [bx;by], plain mul/add (measured) then + centre :819-824 */
+    v[2 * k] = (cs * bx[k] + nsn * by[k]) + px;
+    v[2 * k + 1] = (sn * bx[k] + cs * by[k]) + py;
+  }
+}
+
+/* ---- K3: get_perpendicular_distances, helper_scenario.py:829-889 ------------------------------------------------- */
+/* Entries >= n-1 are overwritten with entry n-2 (:874-879), so (min, first argmin) runs over the n-1 real segments. */
+static void point_polyline(float px, float py, const float* poly, int n, float* dist, int32_t* idx_plus1) {
+  float best = INFINITY;
+  int bi = 0;
+  for (int k = 0; k + 1 < n; ++k) {
+    float sx = poly[2 * k], sy = poly[2 * k + 1];
+    float lx = poly[2 * k + 2] - sx, ly = poly[2 * k + 3] - sy; /* line_vecs :858 */
+    float vx = px - sx, vy = py - sy;                           /* point_vecs :859 */
+    float len2 = lx * lx + ly * ly;                             /* :862 */
+    float proj = (vx * lx + vy * ly) / len2;                    /* :863 */
+    float t = clampf(proj, 0.0f, 1.0f);                         /* :866 */
+    float cx = sx + lx * t, cy = sy + ly * t;                   /* :869 */
+    float d = norm2(cx - px, cy - py);                          /* :872 */
+    if (d < best) { best = d; bi = k; }                         /* torch.min: first minimal index :883 */
+  }
+  *dist = best;
+  *idx_plus1 = bi + 1; /* :885-887 */
+}
+
+/* ---- K6: get_short_term_reference_path, helper_scenario.py:892-957 (sample_interval=2, n_points_shift=1) ---------- */
+static void short_term_path(const float* center, int n, int is_loop, int32_t cp, float* out /*NSx2*/) {
+  for (int k = 0; k < NS; ++k) {
+    int id = k * 2 + cp + 1;                                    /* :930-934 */
+    if (is_loop && id >= n - 1) id = (id + 1) % n;              /* :941-947 */
+    out[2 * k] = center[2 * id];
+    out[2 * k + 1] = center[2 * id + 1];
+  }
+}
+
+/* ---- K5: interX, helper_scenario.py:1148-1229 (is_return_points=False) -------------------------------------------- */
+static int interx(const float* L1, int n1, const float* L2, int n2) {
+  int hit = 0;
+  for (int i = 0; i + 1 < n1; ++i) {
+    float x1a = L1[2 * i], y1a = L1[2 * i + 1], x1b = L1[2 * i + 2], y1b = L1[2 * i + 3];
+    float dx1 = x1b - x1a, dy1 = y1b - y1a;                     /* :1170 */
+    float S1 = dx1 * y1a - dy1 * x1a;                           /* :1174 */
+    for (int j = 0; j + 1 < n2; ++j) {
+      float x2a = L2[2 * j], y2a = L2[2 * j + 1], x2b = L2[2 * j + 2], y2b = L2[2 * j + 3];
+      float dx2 = x2b - x2a, dy2 = y2b - y2a;                   /* :1171 */
+      float S2 = dx2 * y2a - dy2 * x2a;                         /* :1175 */
+      float ma = dx1 * y2a - dy1 * x2a, mb = dx1 * y2b - dy1 * x2b;   /* :1183 */
+      int C1 = ((ma - S1) * (mb - S1)) < 0.0f;                  /* D(), :1178-1187 */
+      float wa = y1a * dx2 - x1a * dy2, wb = y1b * dx2 - x1b * dy2;   /* :1191 */
+      int C2 = ((wa - S2) * (wb - S2)) < 0.0f;                  /* :1188-1196 */
+      hit |= (C1 & C2);
+    }
+  }
+  return hit;
+}
+
+/* ---- K4: get_distances_between_agents "mtv", helper_scenario.py:1030-1138 ----------------------------------------- */
+static void rect_axes(const float* v, float ax[2][2]) { /* :1042-1045 */
+  for (int k = 0; k < 2; ++k) {
+    float ex = v[2 * (k + 1)] - v[2 * k], ey = v[2 * (k + 1) + 1] - v[2 * k + 1];
+    float nrm = norm2(ex, ey);
+    ax[k][0] = ex / nrm;
+    ax[k][1] = ey / nrm;
+  }
+}
+/* one direction: vertices of rectangle `a` against rectangle `b` on b's axes (:1059-1083) */
+static void mtv_half(const float* va, const float* vb, float axb[2][2], float pos_out[4], float* omin_out, int* any_inside) {
+  float maxbb[2], minbb[2], maxab[2], minab[2], pab[4][2];
+  for (int k = 0; k < 2; ++k) {
+    maxbb[k] = -INFINITY; minbb[k] = INFINITY; maxab[k] = -INFINITY; minab[k] = INFINITY;
+    for (int v = 0; v < 4; ++v) {
+      float pb = vb[2 * v] * axb[k][0] + vb[2 * v + 1] * axb[k][1];
+      float pa = va[2 * v] * axb[k][0] + va[2 * v + 1] * axb[k][1];
+      pab[v][k] = pa;
+      maxbb[k] = fmaxf(maxbb[k], pb); minbb[k] = fminf(minbb[k], pb);
+      maxab[k] = fmaxf(maxab[k], pa); minab[k] = fminf(minab[k], pa);
+    }
+  }
+  float ov0 = fminf(maxbb[0], maxab[0]) - fmaxf(minbb[0], minab[0]); /* :1079 */
+  float ov1 = fminf(maxbb[1], maxab[1]) - fmaxf(minbb[1], minab[1]);
+  float omin = fminf(ov0, ov1);
+  *omin_out = omin;
+  int inside_any = 0;
+  for (int v = 0; v < 4; ++v) {
+    float g[2];
+    int inside = 1;
+    for (int k = 0; k < 2; ++k) {
+      float p = pab[v][k];
+      g[k] = (p - minbb[k]) * (p <= minbb[k] ? 1.0f : 0.0f) + (maxbb[k] - p) * (p >= maxbb[k] ? 1.0f : 0.0f); /* :1072-1076 */
+      inside &= (p > minbb[k]) && (p < maxbb[k]);              /* :1081-1083 */
+    }
+    pos_out[v] = norm2(g[0], g[1]);                             /* :1077 */
+    float neg = -omin * (inside ? 1.0f : 0.0f);                 /* :1080 */
+    if (fabsf(neg) > 0.0f) inside_any = 1;                      /* :1118 */
+  }
+  *any_inside = inside_any;
+}
+static float mtv_pair(const float* vi, const float* vj) {
+  float axi[2][2], axj[2][2], pij[4], pji[4], omin_j, omin_i;
+  int neg_ij, neg_ji;
+  rect_axes(vi, axi);
+  rect_axes(vj, axj);
+  mtv_half(vi, vj, axj, pij, &omin_j, &neg_ij);
+  mtv_half(vj, vi, axi, pji, &omin_i, &neg_ji);
+  float d = INFINITY;                                            /* :1112-1117 */
+  for (int v = 0; v < 4; ++v) d = fminf(d, pij[v]);
+  for (int v = 0; v < 4; ++v) d = fminf(d, pji[v]);
+  if (neg_ij | neg_ji) d = -fminf(omin_j, omin_i);              /* :1118-1123 */
+  return d;
+}
+
+/* update_mutual_distances, world_state_rt_sim.py:360-373 (diagonal := sqrt(x_semidim^2+y_semidim^2), helper_scenario.py:1140-1143) */
+static void mutual_distances(oracle_t* o, int b) {
+  int N = o->N;
+  float diag = sqrtf(o->cfg.world_x_dim * o->cfg.world_x_dim + o->cfg.world_y_dim * o->cfg.world_y_dim);
+  float* D = o->dist_agents + (size_t)b * N * N;
+  for (int i = 0; i < N; ++i) {
+    for (int j = 0; j < N; ++j) {
+      float d;
+      if (i == j) d = diag;
+      else if (o->cfg.distance_type == SIGMAENV_DIST_C2C) {     /* helper_scenario.py:1012-1029 */
+        const float* si = o->state + ((size_t)b * N + i) * 8;
+        const float* sj = o->state + ((size_t)b * N + j) * 8;
+        float dx = si[0] - sj[0], dy = si[1] - sj[1];
+        d = sqrtf(dx * dx + dy * dy);
+      } else {
+        int a = i < j ? i : j, c = i < j ? j : i;               /* computed once for i<j, mirrored :1135-1138 */
+        d = mtv_pair(o->vertices + ((size_t)b * N + a) * 10, o->vertices + ((size_t)b * N + c) * 10);
+      }
+      D[i * N + j] = d;
+    }
+  }
+}
+
+/* update_distances for one agent, world_state_rt.py:582-656 (corner queries use whatever is in o->vertices) */
+static void agent_distances(oracle_t* o, int b, int i) {
+  int N = o->N, P = o->P;
+  size_t bi = (size_t)b * N + i;
+  int path = o->path[bi * 4];
+  const float* s = o->state + bi * 8;
+  const float* ctr = o->center + (size_t)path * P * 2;
+  const float* lb = o->left + (size_t)path * P * 2;
+  const float* rb = o->right + (size_t)path * P * 2;
+  int nl = o->n_left[path], nr = o->n_right[path];
+  float wh = (float)((double)o->cfg.width / 2.0);
+  float d;
+  int32_t id;
+  point_polyline(s[0], s[1], ctr, o->n_center[path], &o->dist_ref[bi], &o->closest[bi * 3 + 0]); /* :587-596 */
+  point_polyline(s[0], s[1], lb, nl, &d, &o->closest[bi * 3 + 1]);                                 /* :598-610 */
+  o->dist_left[bi * 5] = d - wh;
+  point_polyline(s[0], s[1], rb, nr, &d, &o->closest[bi * 3 + 2]);                                 /* :612-624 */
+  o->dist_right[bi * 5] = d - wh;
+  const float* v = o->vertices + bi * 10;
+  for (int c = 0; c < 4; ++c) {                                                                    /* :626-646 */
+    point_polyline(v[2 * c], v[2 * c + 1], lb, nl, &o->dist_left[bi * 5 + c + 1], &id);
+    point_polyline(v[2 * c], v[2 * c + 1], rb, nr, &o->dist_right[bi * 5 + c + 1], &id);
+  }
+  float m = INFINITY;                                                                              /* :648-656 */
+  for (int c = 0; c < 5; ++c) m = fminf(m, o->dist_left[bi * 5 + c]);
+  for (int c = 0; c < 5; ++c) m = fminf(m, o->dist_right[bi * 5 + c]);
+  o->dist_bound[bi] = m;
+}
+
+static void agent_short_term(oracle_t* o, int b, int i) { /* update_ref_paths_agent_related, world_state_rt.py:668-684 */
+  size_t bi = (size_t)b * o->N + i;
+  int path = o->path[bi * 4];
+  short_term_path(o->center + (size_t)path * o->P * 2, o->n_center[path], o->is_loop[path], o->closest[bi * 3], o->short_term + bi * NS * 2);
+}
+
+/* update_collisions, world_state_rt_sim.py:379-424 */
+static void update_collisions(oracle_t* o, int b) {
+  int N = o->N, P = o->P;
+  uint8_t* CA = o->col_agents + (size_t)b * N * N;
+  for (int i = 0; i < N; ++i) {
+    size_t bi = (size_t)b * N + i;
+    const float* vi = o->vertices + bi * 10;
+    if (o->cfg.distance_type == SIGMAENV_DIST_C2C) {            /* :382-393 */
+      for (int j = i + 1; j < N; ++j) {
+        if (interx(vi, 5, o->vertices + ((size_t)b * N + j) * 10, 5)) { CA[i * N + j] = 1; CA[j * N + i] = 1; }
+      }
+    } else {                                                     /* :394-396 two agents collide iff their mtv distance == 0 */
+      for (int j = 0; j < N; ++j) CA[i * N + j] = (o->dist_agents[(size_t)b * N * N + i * N + j] == 0.0f);
+    }
+    int path = o->path[bi * 4];
+    const float* lb = o->left + (size_t)path * P * 2;
+    const float* rb = o->right + (size_t)path * P * 2;
+    int nl = o->n_left[path], nr = o->n_right[path];
+    /* padded tail segments are degenerate (dx2=dy2=S2=0 -> C2 false), so only the real points matter :399-411 */
+    if (interx(vi, 5, lb, nl) | interx(vi, 5, rb, nr)) o->col_flags[bi * 4 + 0] = 1;
+    if (!o->is_loop[path]) {                                     /* :413-424 */
+      float entry[4] = {lb[0], lb[1], rb[0], rb[1]};             /* world_state_rt.py:394-399 */
+      float exit_[4] = {lb[2 * (nl - 1)], lb[2 * (nl - 1) + 1], rb[2 * (nr - 1)], rb[2 * (nr - 1) + 1]}; /* :401-406 */
+      o->col_flags[bi * 4 + 1] = (uint8_t)interx(vi, 5, entry, 2);
+      o->col_flags[bi * 4 + 2] = (uint8_t)interx(vi, 5, exit_, 2);
+    }
+  }
+}
+
+/* _apply_ttc_near_agent_penalty, road_traffic.py:1255-1332 */
+static float ttc_penalty(const oracle_t* o, int b, int i) {
+  int N = o->N;
+  const sigmaenv_config_t* c = &o->cfg;
+  const float eps = 1e-6f;
+  double d_safe = (double)c->threshold_near_other_agents_low;   /* :1281 */
+  float d_safe_sq = (float)(d_safe * d_safe);
+  float d_safe32 = c->threshold_near_other_agents_low, d_gate = c->threshold_near_other_agents_high;
+  const float* si = o->state + ((size_t)b * N + i) * 8;
+  float risk_sum = 0.0f;
+  for (int j = 0; j < N; ++j) {
+    const float* sj = o->state + ((size_t)b * N + j) * 8;
+    float px = sj[0] - si[0], py = sj[1] - si[1];               /* :1275 */
+    float vx = sj[5] - si[5], vy = sj[6] - si[6];               /* :1276 */
+    float a = vx * vx + vy * vy;                                 /* :1288 */
+    float bq = 2.0f * (px * vx + py * vy);                       /* :1289 */
+    float pp = px * px + py * py;
+    float cq = pp - d_safe_sq;                                   /* :1290 */
+    float disc = bq * bq - 4.0f * a * cq;                        /* :1292 */
+    float sq = sqrtf(fmaxf(disc, 0.0f));                         /* :1293-1294 */
+    float dist = sqrtf(fmaxf(pp, 0.0f));                         /* :1297 */
+    int valid = (a > eps) && (disc > 0.0f) && (bq < 0.0f);       /* :1303 */
+    float cand = (-bq - sq) / (2.0f * a + eps);                  /* :1307 */
+    float ttc = INFINITY;
+    if (valid && cand > 0.0f) ttc = cand;                        /* :1309 */
+    if (dist <= d_safe32) ttc = 0.0f;                            /* :1312 */
+    if (j == i) ttc = INFINITY;                                  /* :1315 */
+    if (!(dist <= d_gate)) ttc = INFINITY;                       /* :1318 */
+    float x = fminf(ttc, c->ttc_high);                           /* :1322 */
+    risk_sum += decreasing_lin(x, c->ttc_low, c->ttc_high);      /* :1323-1328 */
+  }
+  float risk = risk_sum / (float)(N - 1 > 1 ? N - 1 : 1);
+  return risk * c->penalty_near_other_agents;                    /* :1330 */
+}
+
+/* weighting_ref_directions = linspace(1, 0.2, 3) / sum, road_traffic.py:536-543 (bit patterns read from the reference) */
+static const uint32_t W_REF_BITS[3] = {0x3F0E38E3u, 0x3EAAAAABu, 0x3DE38E39u};
+
+/* ScenarioRoadTraffic.reward for one agent, road_traffic.py:925-1253 (state updates excluded) */
+static float agent_reward(oracle_t* o, int b, int i, float* near_other_out, int* has_near, float* goal_out, float* pca_out, float* pcl_out) {
+  int N = o->N;
+  const sigmaenv_config_t* c = &o->cfg;
+  size_t bi = (size_t)b * N + i;
+  const float* s = o->state + bi * 8;
+  const float* pp = o->prev_pos + bi * 2;
+  const float* st = o->short_term + bi * NS * 2;
+  float w[3];
+  memcpy(w, W_REF_BITS, sizeof(w));
+  float mvx = s[0] - pp[0], mvy = s[1] - pp[1];                 /* :972-974 */
+  float acc = 0.0f;
+  for (int k = 0; k < NS; ++k) {
+    float rx = st[2 * k] - pp[0], ry = st[2 * k + 1] - pp[1];   /* :976-980 */
+    float mp = mvx * rx + mvy * ry;                              /* :981 */
+    acc = acc + mp * w[k];                                       /* :982-984 (gemv; summation order not pinned) */
+  }
+  float denom = (float)((double)c->max_speed * (double)c->dt);
+  float rew = 0.0f;
+  rew += acc / denom * c->reward_progress;                       /* :986-991 */
+  int goal = o->col_flags[bi * 4 + 2];                           /* :996 */
+  float reward_goal = (float)goal * c->reward_reach_goal;        /* :997 */
+  int col_a = 0;
+  for (int j = 0; j < N; ++j) col_a |= o->col_agents[(size_t)b * N * N + i * N + j]; /* :1008-1013 */
+  float pca = (float)col_a * c->penalty_collide_with_agents;
+  int col_l = o->col_flags[bi * 4 + 0];
+  float pcl = (float)col_l * c->penalty_collide_with_boundaries; /* :1021-1026 */
+  o->timer[b * 4 + 2] += goal;                                   /* task_success_times :998-1002 */
+  if (col_a | col_l | goal) o->timer[b * 4 + 1] += 1;            /* num_task_tries :1030-1035 */
+  float pen_lane = decreasing_lin(o->dist_bound[bi], c->threshold_near_boundary_low, c->threshold_near_boundary_high) * c->penalty_near_boundary; /* :1040-1048 */
+  *has_near = 0;
+  if (c->is_testing_mode) {                                      /* :1050-1055 */
+    rew += reward_goal; rew += pca; rew += pcl;
+  } else {
+    if (c->rew_flags & SIGMAENV_REW_EXACT_SPARSE) { rew += pca; rew += pcl; }     /* :1058-1062 */
+    if (c->rew_flags & SIGMAENV_REW_TTC) {                                           /* :1064-1084 */
+      float p = ttc_penalty(o, b, i);
+      *near_other_out = p; *has_near = 1;
+      rew += p; rew += pen_lane; rew += pca; rew += pcl;
+      if (c->rew_flags & SIGMAENV_REW_HAS_SPARSE) { rew += pca; rew += pcl; }
+    }
+    if (c->rew_flags & SIGMAENV_REW_DISTANCE) {                                      /* :1086-1110 */
+      float ssum = 0.0f;
+      for (int j = 0; j < N; ++j)
+        ssum += decreasing_lin(o->dist_agents[(size_t)b * N * N + i * N + j], c->threshold_near_other_agents_low, c->threshold_near_other_agents_high);
+      float p = ssum * c->penalty_near_other_agents;
+      *near_other_out = p; *has_near = 1;
+      rew += p; rew += pen_lane;
+      if (c->rew_flags & SIGMAENV_REW_HAS_SPARSE) { rew += pca; rew += pcl; }
+    }
+  }
+  *goal_out = reward_goal; *pca_out = pca; *pcl_out = pcl;
+  return clampf(rew, -1.0f, 1.0f);                               /* :1249 */
+}
+
+/* ego-view transform, helper_scenario.py:1241-1273 */
+static inline void ego_transform(float pix, float piy, float rot_i, float pjx, float pjy, float* ox, float* oy) {
+  float dx = pjx - pix, dy = pjy - piy;
+  float ab = norm2(dx, dy);
+  float rr = cr_atan2(dy, dx) - rot_i;
+  *ox = cr_cos(rr) * ab;
+  *oy = cr_sin(rr) * ab;
+}
+
+/* observation of one agent, default flags: observation_provider_rt.py:345-588 (latest slot only), :594-925 */
+static void agent_observation(oracle_t* o, int b, int i) {
+  int N = o->N, K = o->K, D = o->D;
+  const sigmaenv_config_t* c = &o->cfg;
+  size_t bi = (size_t)b * N + i;
+  const float* si = o->state + bi * 8;
+  float* ob = o->obs + bi * D;
+  float n_pos = (float)((double)c->length * 10.0);               /* normalizers.pos, road_traffic.py:588-592 */
+  float n_v = c->max_speed;                                      /* :596 */
+  float n_dl = (float)((double)c->lane_width * 3.0);             /* :599-601 */
+  const float* Drow = o->dist_agents + (size_t)b * N * N + (size_t)i * N;
+  /* top-k smallest, ascending, lowest index on ties: observation_provider_rt.py:629-636 */
+  int32_t* near = o->nearing + bi * K;
+  uint64_t taken = 0;
+  for (int k = 0; k < K; ++k) {
+    int bj = -1;
+    float bd = INFINITY;
+    for (int j = 0; j < N; ++j) {
+      if ((taken >> j) & 1) continue;
+      if (bj < 0 || Drow[j] < bd) { bd = Drow[j]; bj = j; }
+    }
+    taken |= 1ull << bj;
+    near[k] = bj;
+  }
+  int p = 0;
+  /* [own] longitudinal speed: past_vel[b,i,i,0] = ||v_i|| * cos(wrap(psi_i - psi_i)) / v  (:441-449, :885-887) */
+  {
+    float rr = angle_eliminate_two_pi(si[2] - si[2]);
+    ob[p++] = (norm2(si[5], si[6]) * cr_cos(rr)) / n_v;
+  }
+  /* [own] short-term reference path in the ego frame (:451-460, :893-897) */
+  for (int k = 0; k < NS; ++k) {
+    float ox, oy;
+    ego_transform(si[0], si[1], si[2], o->short_term[bi * NS * 2 + 2 * k], o->short_term[bi * NS * 2 + 2 * k + 1], &ox, &oy);
+    ob[p++] = ox / n_pos;
+    ob[p++] = oy / n_pos;
+  }
+  /* [own] distances, all normalised by distance_lanelet (:373-389, :898-922) */
+  ob[p++] = o->dist_ref[bi] / n_dl;
+  float ml = INFINITY, mr = INFINITY;
+  for (int q = 0; q < 5; ++q) { ml = fminf(ml, o->dist_left[bi * 5 + q]); mr = fminf(mr, o->dist_right[bi * 5 + q]); }
+  ob[p++] = ml / n_dl;
+  ob[p++] = mr / n_dl;
+  /* [others] vertices (8), velocity (2), distance (1) per observed neighbour (:819-853) */
+  for (int k = 0; k < K; ++k) {
+    int j = near[k];
+    size_t bj = (size_t)b * N + j;
+    const float* sj = o->state + bj * 8;
+    const float* vj = o->vertices + bj * 10;
+    for (int q = 0; q < 4; ++q) {
+      float ox, oy;
+      ego_transform(si[0], si[1], si[2], vj[2 * q], vj[2 * q + 1], &ox, &oy);
+      ob[p++] = ox / n_pos;
+      ob[p++] = oy / n_pos;
+    }
+    float rr = angle_eliminate_two_pi(sj[2] - si[2]);           /* :439 */
+    float va = norm2(sj[5], sj[6]);                              /* :444 */
+    ob[p++] = (va * cr_cos(rr)) / n_v;
+    ob[p++] = (va * cr_sin(rr)) / n_v;
+    ob[p++] = Drow[j] / n_dl;                                    /* :373-375 */
+  }
+}
+
+/* done(), road_traffic.py:1368-1487 (flags only; the resets it triggers are requests to the host) */
+static void env_done(oracle_t* o, int b) {
+  int N = o->N;
+  const sigmaenv_config_t* c = &o->cfg;
+  int col_a = 0, col_l = 0;
+  for (int k = 0; k < N * N; ++k) col_a |= o->col_agents[(size_t)b * N * N + k];
+  for (int i = 0; i < N; ++i) col_l |= o->col_flags[((size_t)b * N + i) * 4];
+  int max_reached = o->timer[b * 4] == (c->max_steps - 1);      /* :1413 */
+  int done;
+  if (c->is_testing_mode) done = max_reached;                    /* :1429-1433 */
+  else done = max_reached | col_a | col_l;                       /* :1450-1455 */
+  o->done[b] = (uint8_t)done;
+  for (int i = 0; i < N; ++i) {
+    size_t bi = (size_t)b * N + i;
+    int rq = 0;
+    if (c->is_testing_mode) {                                    /* :1436-1447 */
+      int ca = 0;
+      for (int j = 0; j < N; ++j) ca |= o->col_agents[(size_t)b * N * N + i * N + j];
+      rq = ca | o->col_flags[bi * 4] | o->col_flags[bi * 4 + 1] | o->col_flags[bi * 4 + 2];
+    } else if (c->has_entry_exit) {                              /* :1456-1473 */
+      rq = o->col_flags[bi * 4 + 1] | o->col_flags[bi * 4 + 2];
+    }
+    o->col_flags[bi * 4 + 3] = (uint8_t)(rq && !done);
+  }
+}
+
+/* one env, the VMAS >= 1.4 call order: world.step; reward(a) for all a; observation(a) for all a; done() */
+static void step_env(oracle_t* o, int b, const float* actions) {
+  int N = o->N;
+  for (int i = 0; i < N; ++i) {
+    size_t bi = (size_t)b * N + i;
+    bicycle_step(&o->cfg, o->state + bi * 8, actions + bi * 2, o->action + bi * 2);
+  }
+  float* RI = o->reward_info;
+  size_t BN = (size_t)o->B * N;
+  for (int i = 0; i < N; ++i) {
+    size_t bi = (size_t)b * N + i;
+    if (i == 0) {
+      o->timer[b * 4] += 1;                                      /* road_traffic.py:954-962 */
+      mutual_distances(o, b);                                    /* world_state_rt.py:583-584: BEFORE update_vertices -> mtv sees last step's vertices */
+    }
+    agent_distances(o, b, i);                                    /* agent 0 still sees last step's vertices for its corners */
+    if (i == 0) {                                                /* world_state_rt_sim.py:442-448 */
+      memset(o->col_agents + (size_t)b * N * N, 0, (size_t)N * N);
+      for (int a = 0; a < N; ++a) { uint8_t* f = o->col_flags + ((size_t)b * N + a) * 4; f[0] = f[1] = f[2] = 0; }
+      for (int a = 0; a < N; ++a) {
+        const float* s = o->state + ((size_t)b * N + a) * 8;
+        rect_vertices(&o->cfg, s[0], s[1], s[2], o->vertices + ((size_t)b * N + a) * 10);
+      }
+      update_collisions(o, b);
+    }
+    float near_other = 0.0f, goal, pca, pcl;
+    int has_near;
+    float r = agent_reward(o, b, i, &near_other, &has_near, &goal, &pca, &pcl);
+    o->reward[bi] = r;
+    /* RewardInfo.reset() at the top of every reward() zeroes all fields of ALL agents except the three it skips
+     * (helper_scenario.py:128-138), so after the loop only the last agent's entries of the other fields survive. */
+    int last = (i == N - 1);
+    RI[1 * BN + bi] = last ? goal : 0.0f;
+    RI[8 * BN + bi] = last ? pcl : 0.0f;
+    RI[7 * BN + bi] = last ? pca : 0.0f;
+    RI[11 * BN + bi] = last ? r : 0.0f;
+    if (has_near) RI[4 * BN + bi] = near_other;
+    agent_short_term(o, b, i);                                   /* update_state_after_rewarding, world_state_rt_sim.py:450-454 */
+  }
+  for (int i = 0; i < N; ++i) {                                  /* state_buffer.add at the last agent, road_traffic.py:1226-1240 */
+    size_t bi = (size_t)b * N + i;
+    o->prev_pos[bi * 2] = o->state[bi * 8];
+    o->prev_pos[bi * 2 + 1] = o->state[bi * 8 + 1];
+  }
+  for (int i = 0; i < N; ++i) agent_observation(o, b, i);
+  env_done(o, b);
+}
+
+/* ---- reset ------------------------------------------------------------------------------------------------------ */
+/* reset_init_distances_and_short_term_ref_path for one agent, world_state_rt.py:422-529: vertices first, then corners */
+static void reset_agent_derived(oracle_t* o, int b, int i) {
+  size_t bi = (size_t)b * o->N + i;
+  const float* s = o->state + bi * 8;
+  rect_vertices(&o->cfg, s[0], s[1], s[2], o->vertices + bi * 10);
+  agent_distances(o, b, i);
+  agent_short_term(o, b, i);
+}
+static void reset_env_tail(oracle_t* o, int b, int full_env) { /* road_traffic.py:902-923 */
+  int N = o->N;
+  mutual_distances(o, b);
+  memset(o->col_agents + (size_t)b * N * N, 0, (size_t)N * N);
+  for (int a = 0; a < N; ++a) {
+    size_t ba = (size_t)b * N + a;
+    uint8_t* f = o->col_flags + ba * 4;
+    f[0] = f[1] = f[2] = f[3] = 0;
+    o->prev_pos[ba * 2] = o->state[ba * 8];
+    o->prev_pos[ba * 2 + 1] = o->state[ba * 8 + 1];
+    if (full_env) { o->action[ba * 2] = 0.0f; o->action[ba * 2 + 1] = 0.0f; }
+  }
+  if (full_env) { o->timer[b * 4] = 0; o->timer[b * 4 + 3] += 1; o->done[b] = 0; }
+}
+
+/* counter-based RNG shared (as a specification) with the HIP kernel: splitmix64 finaliser over (seed, counter, env, agent, draw) */
+static inline uint32_t rng_u32(uint64_t seed, uint64_t counter, uint32_t env, uint32_t agent, uint32_t draw) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (counter + 1);
+  z ^= ((uint64_t)env << 32) | ((uint64_t)agent << 16) | (uint64_t)draw;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (uint32_t)(z >> 32);
+}
+#define AUTO_RESET_MAX_TRIES 64
+
+/* Device-style auto reset of one env: rejection sampling of world_state_rt_sim.py:215-311 (non-testing mode: point in
+ * [3, n/2), min centre distance 1.5*sqrt(l^2+w^2)), bounded to AUTO_RESET_MAX_TRIES per agent, then :143-213 and the tail. */
+static void auto_reset_env(oracle_t* o, int b, uint64_t seed, uint64_t counter, int path_first, int path_count) {
+  int N = o->N;
+  const sigmaenv_config_t* c = &o->cfg;
+  float min_d = sqrtf((float)((double)c->length * (double)c->length + (double)c->width * (double)c->width)) * 1.5f; /* road_traffic.py:679-684 */
+  float min_d_sq = min_d * min_d;
+  for (int i = 0; i < N; ++i) {
+    size_t bi = (size_t)b * N + i;
+    float* s = o->state + bi * 8;
+    int path = path_first, pt = 3;
+    for (int t = 0; t < AUTO_RESET_MAX_TRIES; ++t) {
+      path = path_first + (int)(rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, 2u * t) % (uint32_t)path_count);
+      int n = o->n_center[path];
+      int end = n / 2;
+      if (end < 4) end = 4;
+      pt = 3 + (int)(rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, 2u * t + 1u) % (uint32_t)(end - 3));
+      float px = o->center[((size_t)path * o->P + pt) * 2], py = o->center[((size_t)path * o->P + pt) * 2 + 1];
+      s[0] = px; s[1] = py;
+      int ok = 1;
+      for (int j = 0; j < i; ++j) {
+        const float* sj = o->state + ((size_t)b * N + j) * 8;
+        float dx = px - sj[0], dy = py - sj[1];
+        float d2 = dx * dx + dy * dy;
+        if (!(d2 >= min_d_sq)) ok = 0;
+      }
+      if (ok) break;
+    }
+    float u = (float)(rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, 1000u) >> 8) * (1.0f / 16777216.0f);
+    int ny = o->yaw_stride;
+    int yi = pt < ny ? pt : ny - 1;
+    float rot = o->yaw[(size_t)path * o->yaw_stride + yi];
+    float speed = u * c->max_speed;                              /* world_state_rt_sim.py:195-198 */
+    s[2] = rot; s[3] = speed; s[4] = 0.0f; s[7] = 0.0f;
+    s[5] = speed * cr_cos(0.0f + rot);                           /* :199-204 */
+    s[6] = speed * cr_sin(0.0f + rot);
+    o->path[bi * 4 + 0] = path; o->path[bi * 4 + 1] = 0; o->path[bi * 4 + 2] = path - path_first; o->path[bi * 4 + 3] = pt;
+  }
+  for (int i = 0; i < N; ++i) reset_agent_derived(o, b, i);
+  reset_env_tail(o, b, 1);
+  for (int i = 0; i < N; ++i) agent_observation(o, b, i);
+}
+
+/* ---- C-ABI twin --------------------------------------------------------------------------------------------------- */
+int sigmaenv_oracle_obs_dim(int32_t n_nearing) { return 1 + 2 * NS + 3 + n_nearing * 11; }
+
+static void* xcalloc(size_t n, size_t sz) { return calloc(n ? n : 1, sz); }
+
+int sigmaenv_oracle_create(const sigmaenv_config_t* cfg, const sigmaenv_map_t* map, int device_id, void* stream, oracle_t** out) {
+  (void)device_id; (void)stream;
+  if (!cfg || !map || !out) return SIGMAENV_EINVAL;
+  if (cfg->abi_version != SIGMAENV_ABI_VERSION) return SIGMAENV_EINVAL;
+  if (cfg->n_envs < 1 || cfg->n_agents < 1 || cfg->n_agents > SIGMAENV_MAX_AGENTS) return SIGMAENV_EINVAL;
+  if (cfg->n_nearing < 0 || cfg->n_nearing > SIGMAENV_MAX_NEARING || cfg->n_nearing > cfg->n_agents - 1) return SIGMAENV_EINVAL;
+  if (cfg->distance_type != SIGMAENV_DIST_C2C && cfg->distance_type != SIGMAENV_DIST_MTV) return SIGMAENV_EINVAL;
+  oracle_t* o = (oracle_t*)calloc(1, sizeof(oracle_t));
+  if (!o) return SIGMAENV_ENOMEM;
+  o->cfg = *cfg;
+  int B = o->B = cfg->n_envs, N = o->N = cfg->n_agents, K = o->K = cfg->n_nearing;
+  o->D = sigmaenv_oracle_obs_dim(K);
+  int np = o->n_paths = map->n_paths, S = map->stride_points;
+  int maxc = 0;
+  for (int p = 0; p < np; ++p) {
+    if (map->n_center[p] > maxc) maxc = map->n_center[p];
+  }
+  /* max_ref_path_points = max centre-line points + n_points_short_term*sample_interval + 2, road_traffic.py:520-530 */
+  int P = maxc + NS * 2 + 2;
+  for (int p = 0; p < np; ++p) {
+    if (map->n_left[p] > P) P = map->n_left[p];
+    if (map->n_right[p] > P) P = map->n_right[p];
+  }
+  o->P = P;
+  o->yaw_stride = S;
+  o->center = xcalloc((size_t)np * P * 2, 4); o->left = xcalloc((size_t)np * P * 2, 4); o->right = xcalloc((size_t)np * P * 2, 4);
+  o->yaw = xcalloc((size_t)np * S, 4);
+  o->n_center = xcalloc(np, 4); o->n_left = xcalloc(np, 4); o->n_right = xcalloc(np, 4); o->is_loop = xcalloc(np, 1);
+  memcpy(o->yaw, map->yaw, (size_t)np * S * 4);
+  for (int p = 0; p < np; ++p) {
+    int n = map->n_center[p], nl = map->n_left[p], nr = map->n_right[p];
+    o->n_center[p] = n; o->n_left[p] = nl; o->n_right[p] = nr; o->is_loop[p] = map->is_loop[p];
+    const float* c = map->center + (size_t)p * S * 2;
+    float* dc = o->center + (size_t)p * P * 2;
+    memcpy(dc, c, (size_t)n * 8);
+    /* _extend_map_related_ref_path, world_state_rt.py:279-293: centre[-1] + k * (centre[-1]-centre[-2]), k = 1..6 */
+    float dirx = c[2 * (n - 1)] - c[2 * (n - 2)], diry = c[2 * (n - 1) + 1] - c[2 * (n - 2) + 1];
+    int ne = NS * 2;
+    for (int k = 1; k <= ne; ++k) {
+      dc[2 * (n + k - 1)] = c[2 * (n - 1)] + (float)k * dirx;
+      dc[2 * (n + k - 1) + 1] = c[2 * (n - 1) + 1] + (float)k * diry;
+    }
+    for (int k = n + ne; k < P; ++k) { dc[2 * k] = dc[2 * (n + ne - 1)]; dc[2 * k + 1] = dc[2 * (n + ne - 1) + 1]; } /* :337-345 */
+    const float* l = map->left + (size_t)p * S * 2;
+    float* dl = o->left + (size_t)p * P * 2;
+    memcpy(dl, l, (size_t)nl * 8);
+    for (int k = nl; k < P; ++k) { dl[2 * k] = l[2 * (nl - 1)]; dl[2 * k + 1] = l[2 * (nl - 1) + 1]; }              /* :372-374 */
+    const float* r = map->right + (size_t)p * S * 2;
+    float* dr = o->right + (size_t)p * P * 2;
+    memcpy(dr, r, (size_t)nr * 8);
+    for (int k = nr; k < P; ++k) { dr[2 * k] = r[2 * (nr - 1)]; dr[2 * k + 1] = r[2 * (nr - 1) + 1]; }              /* :386-388 */
+  }
+  size_t BN = (size_t)B * N;
+  o->state = xcalloc(BN * 8, 4); o->prev_pos = xcalloc(BN * 2, 4); o->vertices = xcalloc(BN * 10, 4);
+  o->short_term = xcalloc(BN * NS * 2, 4); o->dist_ref = xcalloc(BN, 4); o->dist_left = xcalloc(BN * 5, 4);
+  o->dist_right = xcalloc(BN * 5, 4); o->dist_bound = xcalloc(BN, 4); o->dist_agents = xcalloc(BN * N, 4);
+  o->reward = xcalloc(BN, 4); o->reward_info = xcalloc(BN * SIGMAENV_N_REWARD_INFO, 4); o->obs = xcalloc(BN * o->D, 4);
+  o->action = xcalloc(BN * 2, 4); o->path = xcalloc(BN * 4, 4); o->closest = xcalloc(BN * 3, 4);
+  o->nearing = xcalloc(BN * (K ? K : 1), 4); o->timer = xcalloc((size_t)B * 4, 4);
+  o->col_agents = xcalloc(BN * N, 1); o->col_flags = xcalloc(BN * 4, 1); o->done = xcalloc(B, 1);
+  *out = o;
+  return SIGMAENV_OK;
+}
+
+void sigmaenv_oracle_destroy(oracle_t* o) {
+  if (!o) return;
+  void* ptrs[] = {o->center, o->left, o->right, o->yaw, o->n_center, o->n_left, o->n_right, o->is_loop, o->state, o->prev_pos,
+                  o->vertices, o->short_term, o->dist_ref, o->dist_left, o->dist_right, o->dist_bound, o->dist_agents, o->reward,
+                  o->reward_info, o->obs, o->action, o->path, o->closest, o->nearing, o->timer, o->col_agents, o->col_flags, o->done};
+  for (size_t k = 0; k < sizeof(ptrs) / sizeof(ptrs[0]); ++k) free(ptrs[k]);
+  free(o);
+}
+
+const char* sigmaenv_oracle_last_error(const oracle_t* o) { return o ? o->err : "null handle"; }
+
+int sigmaenv_oracle_reset(oracle_t* o, int32_t n, const int32_t* env_idx, const int32_t* agent_idx, const int32_t* path_ids,
+                          const float* state8, int32_t full_env) {
+  if (!o || n < 0) return SIGMAENV_EINVAL;
+  for (int k = 0; k < n; ++k) {
+    int b = env_idx[k], i = agent_idx[k];
+    if (b < 0 || b >= o->B || i < 0 || i >= o->N || path_ids[4 * k] < 0 || path_ids[4 * k] >= o->n_paths) {
+      snprintf(o->err, sizeof(o->err), "reset entry %d out of range", k);
+      return SIGMAENV_EINVAL;
+    }
+  }
+  for (int k = 0; k < n; ++k) {
+    size_t bi = (size_t)env_idx[k] * o->N + agent_idx[k];
+    memcpy(o->state + bi * 8, state8 + 8 * (size_t)k, 32);
+    memcpy(o->path + bi * 4, path_ids + 4 * (size_t)k, 16);
+  }
+  for (int k = 0; k < n; ++k) reset_agent_derived(o, env_idx[k], agent_idx[k]);
+  for (int k = 0; k < n; ++k) {
+    int seen = 0;
+    for (int q = 0; q < k; ++q) seen |= (env_idx[q] == env_idx[k]);
+    if (!seen) reset_env_tail(o, env_idx[k], full_env);
+  }
+  return SIGMAENV_OK;
+}
+
+int sigmaenv_oracle_step(oracle_t* o, const float* actions) {
+  if (!o || !actions) return SIGMAENV_EINVAL;
+#pragma omp parallel for schedule(static)
+  for (int b = 0; b < o->B; ++b) step_env(o, b, actions);
+  return SIGMAENV_OK;
+}
+
+int sigmaenv_oracle_observe(oracle_t* o) {
+  if (!o) return SIGMAENV_EINVAL;
+#pragma omp parallel for schedule(static)
+  for (int b = 0; b < o->B; ++b)
+    for (int i = 0; i < o->N; ++i) agent_observation(o, b, i);
+  return SIGMAENV_OK;
+}
+
+int sigmaenv_oracle_auto_reset(oracle_t* o, uint64_t seed, uint64_t counter, int32_t path_first, int32_t path_count) {
+  if (!o || path_first < 0 || path_count < 1 || path_first + path_count > o->n_paths) return SIGMAENV_EINVAL;
+#pragma omp parallel for schedule(static)
+  for (int b = 0; b < o->B; ++b)
+    if (o->done[b]) auto_reset_env(o, b, seed, counter, path_first, path_count);
+  return SIGMAENV_OK;
+}
+
+int sigmaenv_oracle_get(oracle_t* o, sigmaenv_buf_t which, void** ptr, size_t* bytes) {
+  if (!o || !ptr || !bytes) return SIGMAENV_EINVAL;
+  size_t BN = (size_t)o->B * o->N;
+  switch (which) {
+    case SIGMAENV_BUF_STATE: *ptr = o->state; *bytes = BN * 32; break;
+    case SIGMAENV_BUF_PREV_POS: *ptr = o->prev_pos; *bytes = BN * 8; break;
+    case SIGMAENV_BUF_VERTICES: *ptr = o->vertices; *bytes = BN * 40; break;
+    case SIGMAENV_BUF_PATH: *ptr = o->path; *bytes = BN * 16; break;
+    case SIGMAENV_BUF_SHORT_TERM: *ptr = o->short_term; *bytes = BN * NS * 8; break;
+    case SIGMAENV_BUF_DIST_REF: *ptr = o->dist_ref; *bytes = BN * 4; break;
+    case SIGMAENV_BUF_DIST_LEFT: *ptr = o->dist_left; *bytes = BN * 20; break;
+    case SIGMAENV_BUF_DIST_RIGHT: *ptr = o->dist_right; *bytes = BN * 20; break;
+    case SIGMAENV_BUF_DIST_BOUND: *ptr = o->dist_bound; *bytes = BN * 4; break;
+    case SIGMAENV_BUF_CLOSEST: *ptr = o->closest; *bytes = BN * 12; break;
+    case SIGMAENV_BUF_DIST_AGENTS: *ptr = o->dist_agents; *bytes = BN * o->N * 4; break;
+    case SIGMAENV_BUF_COL_AGENTS: *ptr = o->col_agents; *bytes = BN * o->N; break;
+    case SIGMAENV_BUF_COL_FLAGS: *ptr = o->col_flags; *bytes = BN * 4; break;
+    case SIGMAENV_BUF_REWARD: *ptr = o->reward; *bytes = BN * 4; break;
+    case SIGMAENV_BUF_REWARD_INFO: *ptr = o->reward_info; *bytes = BN * SIGMAENV_N_REWARD_INFO * 4; break;
+    case SIGMAENV_BUF_OBS: *ptr = o->obs; *bytes = BN * o->D * 4; break;
+    case SIGMAENV_BUF_NEARING: *ptr = o->nearing; *bytes = BN * o->K * 4; break;
+    case SIGMAENV_BUF_DONE: *ptr = o->done; *bytes = (size_t)o->B; break;
+    case SIGMAENV_BUF_TIMER: *ptr = o->timer; *bytes = (size_t)o->B * 16; break;
+    case SIGMAENV_BUF_ACTION: *ptr = o->action; *bytes = BN * 8; break;
+    default: return SIGMAENV_EINVAL;
+  }
+  return SIGMAENV_OK;
+}
+
+int sigmaenv_oracle_sync(oracle_t* o) { (void)o; return SIGMAENV_OK; }
+
+/* padded path table access for tests (checks the padding against the reference's per-agent copies) */
+int sigmaenv_oracle_path_table(oracle_t* o, int32_t* P, const float** center, const float** left, const float** right) {
+  if (!o) return SIGMAENV_EINVAL;
+  *P = o->P; *center = o->center; *left = o->left; *right = o->right;
+  return SIGMAENV_OK;
+}
+
+/* ---- standalone entry points for the function-level goldens (tests only) ---------------------------------------- */
+void sigmaenv_oracle_fn_bicycle(const sigmaenv_config_t* cfg, int n, const float* in7 /*x,y,psi,v,delta,u0,u1*/, float* out10) {
+  for (int k = 0; k < n; ++k) {
+    float s[8] = {in7[7 * k], in7[7 * k + 1], in7[7 * k + 2], in7[7 * k + 3], in7[7 * k + 4], 0, 0, 0};
+    float uc[2];
+    bicycle_step(cfg, s, in7 + 7 * k + 5, uc);
+    memcpy(out10 + 10 * k, s, 32);
+    out10[10 * k + 8] = uc[0]; out10[10 * k + 9] = uc[1];
+  }
+}
+void sigmaenv_oracle_fn_vertices(const sigmaenv_config_t* cfg, int n, const float* in3, float* out10) {
+  for (int k = 0; k < n; ++k) rect_vertices(cfg, in3[3 * k], in3[3 * k + 1], in3[3 * k + 2], out10 + 10 * k);
+}
+void sigmaenv_oracle_fn_point_polyline(int n, const float* pts, const float* poly, int n_points, float* dist, int32_t* idx) {
+  for (int k = 0; k < n; ++k) point_polyline(pts[2 * k], pts[2 * k + 1], poly, n_points, dist + k, idx + k);
+}
+void sigmaenv_oracle_fn_short_term(int n, const float* poly, int n_points, int is_loop, const int32_t* cp, float* out6) {
+  for (int k = 0; k < n; ++k) short_term_path(poly, n_points, is_loop, cp[k], out6 + 6 * k);
+}
+void sigmaenv_oracle_fn_interx(int n, const float* L1, int n1, int stride1, const float* L2, int n2, int stride2, uint8_t* hit) {
+  for (int k = 0; k < n; ++k) hit[k] = (uint8_t)interx(L1 + (size_t)k * stride1, n1, L2 + (size_t)k * stride2, n2);
+}
+void sigmaenv_oracle_fn_mtv(int n, const float* verts /*[n,2,5,2]*/, float* d) {
+  for (int k = 0; k < n; ++k) d[k] = mtv_pair(verts + 20 * (size_t)k, verts + 20 * (size_t)k + 10);
+}
+void sigmaenv_oracle_fn_ego(int n, const float* pi, const float* roti, int m, const float* pj, float* out) {
+  for (int k = 0; k < n; ++k)
+    for (int q = 0; q < m; ++q)
+      ego_transform(pi[2 * k], pi[2 * k + 1], roti[k], pj[((size_t)k * m + q) * 2], pj[((size_t)k * m + q) * 2 + 1],
+                    out + ((size_t)k * m + q) * 2, out + ((size_t)k * m + q) * 2 + 1);
+}
+void sigmaenv_oracle_fn_wrap(int n, const float* a, float* out) {
+  for (int k = 0; k < n; ++k) out[k] = angle_eliminate_two_pi(a[k]);
+}

@@ -1,0 +1,145 @@
+"""ctypes mirror of ``include/sigmaenv.h`` (the C-ABI of the HIP environment step).
+
+The structures here are the single Python-side definition of the ABI; the product
+binds ``libsigmaenv.so`` with them and the tests bind the CPU oracle
+(``oracle/libsigmaenv_oracle.so``, prefix ``sigmaenv_oracle_``) with the very same
+definitions, so both sides are driven through identical calls.
+
+The product path fails loudly when the HIP library is missing: there is no CPU
+fallback (``load_library`` raises).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+
+ABI_VERSION = 1
+DIST_C2C, DIST_MTV = 0, 1
+REW_DISTANCE, REW_TTC, REW_EXACT_SPARSE, REW_HAS_SPARSE = 1, 2, 4, 8
+N_SHORT_TERM = 3
+MAX_NEARING = 4
+N_REWARD_INFO = 12
+
+(BUF_STATE, BUF_PREV_POS, BUF_VERTICES, BUF_PATH, BUF_SHORT_TERM, BUF_DIST_REF, BUF_DIST_LEFT, BUF_DIST_RIGHT,
+ BUF_DIST_BOUND, BUF_CLOSEST, BUF_DIST_AGENTS, BUF_COL_AGENTS, BUF_COL_FLAGS, BUF_REWARD, BUF_REWARD_INFO, BUF_OBS,
+ BUF_NEARING, BUF_DONE, BUF_TIMER, BUF_ACTION) = range(20)
+
+REWARD_INFO_FIELDS = (
+    "rew_progress", "rew_reach_goal", "rew_speed", "rew_centerline", "rew_near_other_agents", "rew_near_left_lane",
+    "rew_near_right_lane", "rew_collide_other_agents", "rew_collide_lane", "rew_energy_acceleration",
+    "rew_energy_steering", "rew_total",
+)  # RewardInfo declaration order, sigmarl/helper_scenario.py:101-114
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("n_envs", C.c_int32), ("n_agents", C.c_int32), ("distance_type", C.c_int32),
+        ("rew_flags", C.c_int32), ("is_testing_mode", C.c_int32), ("has_entry_exit", C.c_int32), ("max_steps", C.c_int32),
+        ("n_nearing", C.c_int32), ("reserved0", C.c_int32),
+        ("dt", C.c_float), ("length", C.c_float), ("width", C.c_float), ("l_f", C.c_float), ("l_r", C.c_float),
+        ("max_speed", C.c_float), ("max_steering", C.c_float), ("min_acc", C.c_float), ("max_acc", C.c_float),
+        ("min_steering_rate", C.c_float), ("max_steering_rate", C.c_float),
+        ("world_x_dim", C.c_float), ("world_y_dim", C.c_float), ("lane_width", C.c_float),
+        ("reward_progress", C.c_float), ("reward_reach_goal", C.c_float),
+        ("penalty_near_boundary", C.c_float), ("penalty_near_other_agents", C.c_float),
+        ("penalty_collide_with_agents", C.c_float), ("penalty_collide_with_boundaries", C.c_float),
+        ("threshold_near_boundary_low", C.c_float), ("threshold_near_boundary_high", C.c_float),
+        ("threshold_near_other_agents_low", C.c_float), ("threshold_near_other_agents_high", C.c_float),
+        ("ttc_low", C.c_float), ("ttc_high", C.c_float),
+    ]
+
+
+class Map(C.Structure):
+    _fields_ = [
+        ("n_paths", C.c_int32), ("stride_points", C.c_int32),
+        ("center", C.c_void_p), ("left", C.c_void_p), ("right", C.c_void_p), ("yaw", C.c_void_p),
+        ("n_center", C.c_void_p), ("n_left", C.c_void_p), ("n_right", C.c_void_p), ("is_loop", C.c_void_p),
+    ]
+
+
+# vehicle constants of the reference, sigmarl/constants.py:628-647
+AGENTS = {
+    "width": 0.107, "length": 0.22, "l_f": 0.075, "l_r": 0.075, "l_wb": 0.15,
+    "max_speed": 1.0, "min_speed": -0.5,
+    "max_steering": 31 * math.pi / 180, "min_steering": -31 * math.pi / 180,
+    "max_acc": 5.0, "min_acc": -5.0, "max_steering_rate": math.pi / 2, "min_steering_rate": -math.pi / 2,
+    "n_actions": 2,
+}
+
+
+def rew_flags_from_method(rew_method: str) -> int:
+    """Decode ``Parameters.rew_method`` the way sigmarl/scenarios/road_traffic.py:1056-1151 tests the string."""
+    if "cbf" in rew_method:
+        raise ValueError("rew_method containing 'cbf' needs the CBF-QP path (SURVEY.md section 8 config 5): not built")
+    f = 0
+    if "distance" in rew_method:
+        f |= REW_DISTANCE
+    if "ttc" in rew_method:
+        f |= REW_TTC
+    if rew_method == "sparse":
+        f |= REW_EXACT_SPARSE
+    if "sparse" in rew_method:
+        f |= REW_HAS_SPARSE
+    return f
+
+
+def obs_dim(n_nearing: int) -> int:
+    return 1 + 2 * N_SHORT_TERM + 3 + n_nearing * 11
+
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_PKG_DIR, "csrc", "libsigmaenv.so")
+
+_SIGS = {
+    "obs_dim": (C.c_int, [C.c_int32]),
+    "create": (C.c_int, [C.POINTER(Config), C.POINTER(Map), C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "destroy": (None, [C.c_void_p]),
+    "last_error": (C.c_char_p, [C.c_void_p]),
+    "reset": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    "step": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "observe": (C.c_int, [C.c_void_p]),
+    "auto_reset": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32]),
+    "get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "sync": (C.c_int, [C.c_void_p]),
+}
+_PRODUCT_ONLY = {"step_time_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)])}
+
+
+class Library:
+    """A loaded C-ABI library; ``fn.<name>`` are the typed entry points."""
+
+    def __init__(self, path: str, prefix: str = "sigmaenv_", extra: dict | None = None):
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"{path} not found. The HIP extension is required (no CPU fallback): build it with "
+                f"`python -c 'import __graft_entry__ as g; g.build()'` or `make -C sigmarl_amd/csrc`."
+            )
+        self.path = path
+        self.prefix = prefix
+        self.cdll = C.CDLL(path)
+        sigs = dict(_SIGS)
+        sigs.update(extra or {})
+        self.names = list(sigs)
+        for name, (res, args) in sigs.items():
+            f = getattr(self.cdll, prefix + name)  # AttributeError if the symbol is missing
+            f.restype = res
+            f.argtypes = args
+            setattr(self, name, f)
+
+
+_product_lib = None
+
+
+def load_library(path: str | None = None) -> Library:
+    global _product_lib
+    if path is None:
+        if _product_lib is None:
+            _product_lib = Library(DEFAULT_LIB, "sigmaenv_", _PRODUCT_ONLY)
+        return _product_lib
+    return Library(path, "sigmaenv_", _PRODUCT_ONLY)
+
+
+def exported_symbols() -> list:
+    """Every function ``include/sigmaenv.h`` declares (checked by the CPU test-suite against the built .so)."""
+    return ["sigmaenv_" + n for n in list(_SIGS) + list(_PRODUCT_ONLY)]

@@ -1,0 +1,91 @@
+"""Reference-path tables (the map data the environment step consumes).
+
+The tables under ``assets/maps/*.npz`` are the OUTPUT of the reference's map parsers
+(``sigmarl/map_manager.py:13-40`` -> ``parse_xml.py`` / ``parse_osm.py``), dumped by
+``tests/golden/gen/gen_maps.py``.  An own parser for ``cpm.xml`` / ``*.osm`` is SURVEY.md section 8(f) rank 2.
+
+Path lists (``list_id``): 0 = ``parser.reference_paths``; for the CPM map 1/2/3 =
+``reference_paths_intersection`` / ``_merge_in`` / ``_merge_out`` (``world_state_rt_sim.py:313-358`` selects by
+``scenario_id``).  All lists are flattened into one table; the step addresses paths by their GLOBAL row.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import capi
+
+ASSET_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets", "maps")
+
+
+class MapTable:
+    def __init__(self, scenario_type: str):
+        path = os.path.join(ASSET_DIR, f"{scenario_type}.npz")
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"no map table for scenario_type={scenario_type!r} ({path})")
+        z = np.load(path)
+        self.scenario_type = scenario_type
+        self.n_paths = int(z["center"].shape[0])
+        stride = max(z["center"].shape[1], z["left"].shape[1], z["right"].shape[1])
+        self.stride = int(stride)
+
+        def pad(a, width):
+            out = np.zeros((a.shape[0], width) + a.shape[2:], a.dtype)
+            out[:, : a.shape[1]] = a
+            return np.ascontiguousarray(out)
+
+        self.center = pad(z["center"].astype(np.float32), stride)
+        self.left = pad(z["left"].astype(np.float32), stride)
+        self.right = pad(z["right"].astype(np.float32), stride)
+        self.yaw = pad(z["yaw"].astype(np.float32), stride)
+        self.n_center = np.ascontiguousarray(z["n_center"].astype(np.int32))
+        self.n_yaw = np.ascontiguousarray(z["n_yaw"].astype(np.int32))
+        self.n_left = np.ascontiguousarray(z["n_left"].astype(np.int32))
+        self.n_right = np.ascontiguousarray(z["n_right"].astype(np.int32))
+        self.is_loop = np.ascontiguousarray(z["is_loop"].astype(np.uint8))
+        self.lanelet_ids = z["lanelet_ids"].astype(np.int32)
+        self.n_lanelet_ids = z["n_lanelet_ids"].astype(np.int32)
+        self.list_id = z["list_id"].astype(np.int32)
+        self.local_id = z["local_id"].astype(np.int32)
+        self.world_x_dim = float(z["world_x_dim"])
+        self.world_y_dim = float(z["world_y_dim"])
+        self.lane_width = float(z["lane_width"])  # SCENARIOS[...]["lane_width"]: the normaliser
+        self.parser_lane_width = float(z["parser_lane_width"])  # Parameters.lane_width the table was parsed with
+        self.default_n_agents = int(z["default_n_agents"])
+        self.n_lanelets_all = int(z["n_lanelets_all"])
+        # first global row and length of every list
+        self.list_first = {}
+        self.list_count = {}
+        for li in range(4):
+            rows = np.nonzero(self.list_id == li)[0]
+            self.list_first[li] = int(rows[0]) if len(rows) else 0
+            self.list_count[li] = int(len(rows))
+
+    def global_path(self, scenario_id: int, path_id: int) -> int:
+        """(scenario_id, list-local path_id) -> global row.  scenario_id 0 = all paths, 1..3 = CPM sub-scenarios."""
+        return self.list_first[int(scenario_id)] + int(path_id)
+
+    def as_struct(self) -> capi.Map:
+        m = capi.Map()
+        m.n_paths = self.n_paths
+        m.stride_points = self.stride
+        m.center = self.center.ctypes.data_as(C.c_void_p)
+        m.left = self.left.ctypes.data_as(C.c_void_p)
+        m.right = self.right.ctypes.data_as(C.c_void_p)
+        m.yaw = self.yaw.ctypes.data_as(C.c_void_p)
+        m.n_center = self.n_center.ctypes.data_as(C.c_void_p)
+        m.n_left = self.n_left.ctypes.data_as(C.c_void_p)
+        m.n_right = self.n_right.ctypes.data_as(C.c_void_p)
+        m.is_loop = self.is_loop.ctypes.data_as(C.c_void_p)
+        return m
+
+
+_cache = {}
+
+
+def load_map(scenario_type: str) -> MapTable:
+    if scenario_type not in _cache:
+        _cache[scenario_type] = MapTable(scenario_type)
+    return _cache[scenario_type]

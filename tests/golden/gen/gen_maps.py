@@ -34,8 +34,12 @@ OUT = os.path.abspath(os.path.join(HERE, "..", "..", "..", "sigmarl_amd", "asset
 
 def dump(scenario_type: str) -> None:
     sc = SCENARIOS[scenario_type]
+    # ScenarioRoadTraffic builds MapManager(lane_width=parameters.lane_width) (road_traffic.py:463-467); for the OSM maps the
+    # parser offsets the boundaries (and shifts all coordinates) by that width (parse_osm.py:97-98,300-304), so the table is
+    # the one of Parameters' default lane_width = 0.25 (helper_common.py:119).  The CPM parser ignores it.
+    parser_lane_width = 0.25
     with contextlib.redirect_stdout(io.StringIO()):
-        m = MapManager(scenario_type=scenario_type, device="cpu", lane_width=sc.get("lane_width"))
+        m = MapManager(scenario_type=scenario_type, device="cpu", lane_width=parser_lane_width)
     p = m.parser
     lists = [p.reference_paths, p.reference_paths_intersection, p.reference_paths_merge_in, p.reference_paths_merge_out]
     paths, list_id, local_id = [], [], []
@@ -82,7 +86,7 @@ def dump(scenario_type: str) -> None:
         is_loop=is_loop, lanelet_ids=lanelet_ids, n_lanelet_ids=n_lanelet_ids,
         list_id=np.asarray(list_id, np.int32), local_id=np.asarray(local_id, np.int32),
         world_x_dim=np.float64(p.bounds["world_x_dim"]), world_y_dim=np.float64(p.bounds["world_y_dim"]),
-        lane_width=np.float64(sc["lane_width"]), default_n_agents=np.int32(sc.get("n_agents", 4)),
+        lane_width=np.float64(sc["lane_width"]), parser_lane_width=np.float64(parser_lane_width), default_n_agents=np.int32(sc.get("n_agents", 4)),
         n_lanelets_all=np.int32(len(p.lanelets_all)),
     )
     print(scenario_type, n, "paths", max_c, max_l, max_r)

@@ -1,0 +1,157 @@
+"""ctypes binding of the CPU oracle (oracle/libsigmaenv_oracle.so) for the test-suite.
+
+Test infrastructure: imported by tests/, ``__graft_entry__.smoke()`` and bench.py's ``cpu_baseline`` leg only.
+Uses the product's ABI definitions (``sigmarl_amd.capi``) so oracle and HIP library are driven identically.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from sigmarl_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "libsigmaenv_oracle.so")
+
+_f32p = C.POINTER(C.c_float)
+
+
+def build_oracle(force: bool = False) -> str:
+    src = os.path.join(ORACLE_DIR, "sigmaenv_oracle.c")
+    if force or not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-B", "libsigmaenv_oracle.so"], stdout=subprocess.DEVNULL)
+    return ORACLE_SO
+
+
+_lib = None
+
+
+def load_oracle() -> capi.Library:
+    global _lib
+    if _lib is None:
+        build_oracle()
+        extra = {
+            "fn_bicycle": (None, [C.POINTER(capi.Config), C.c_int, C.c_void_p, C.c_void_p]),
+            "fn_vertices": (None, [C.POINTER(capi.Config), C.c_int, C.c_void_p, C.c_void_p]),
+            "fn_point_polyline": (None, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+            "fn_short_term": (None, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+            "fn_interx": (None, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+            "fn_mtv": (None, [C.c_int, C.c_void_p, C.c_void_p]),
+            "fn_ego": (None, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+            "fn_wrap": (None, [C.c_int, C.c_void_p, C.c_void_p]),
+            "path_table": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(_f32p), C.POINTER(_f32p), C.POINTER(_f32p)]),
+        }
+        _lib = capi.Library(ORACLE_SO, "sigmaenv_oracle_", extra)
+    return _lib
+
+
+def ptr(a: np.ndarray):
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+_BUF_SPEC = {
+    capi.BUF_STATE: (np.float32, lambda B, N, K, D: (B, N, 8)),
+    capi.BUF_PREV_POS: (np.float32, lambda B, N, K, D: (B, N, 2)),
+    capi.BUF_VERTICES: (np.float32, lambda B, N, K, D: (B, N, 5, 2)),
+    capi.BUF_PATH: (np.int32, lambda B, N, K, D: (B, N, 4)),
+    capi.BUF_SHORT_TERM: (np.float32, lambda B, N, K, D: (B, N, 3, 2)),
+    capi.BUF_DIST_REF: (np.float32, lambda B, N, K, D: (B, N)),
+    capi.BUF_DIST_LEFT: (np.float32, lambda B, N, K, D: (B, N, 5)),
+    capi.BUF_DIST_RIGHT: (np.float32, lambda B, N, K, D: (B, N, 5)),
+    capi.BUF_DIST_BOUND: (np.float32, lambda B, N, K, D: (B, N)),
+    capi.BUF_CLOSEST: (np.int32, lambda B, N, K, D: (B, N, 3)),
+    capi.BUF_DIST_AGENTS: (np.float32, lambda B, N, K, D: (B, N, N)),
+    capi.BUF_COL_AGENTS: (np.uint8, lambda B, N, K, D: (B, N, N)),
+    capi.BUF_COL_FLAGS: (np.uint8, lambda B, N, K, D: (B, N, 4)),
+    capi.BUF_REWARD: (np.float32, lambda B, N, K, D: (B, N)),
+    capi.BUF_REWARD_INFO: (np.float32, lambda B, N, K, D: (12, B, N)),
+    capi.BUF_OBS: (np.float32, lambda B, N, K, D: (B, N, D)),
+    capi.BUF_NEARING: (np.int32, lambda B, N, K, D: (B, N, K)),
+    capi.BUF_DONE: (np.uint8, lambda B, N, K, D: (B,)),
+    capi.BUF_TIMER: (np.int32, lambda B, N, K, D: (B, 4)),
+    capi.BUF_ACTION: (np.float32, lambda B, N, K, D: (B, N, 2)),
+}
+
+
+def buf_spec(which, B, N, K, D):
+    dt, shp = _BUF_SPEC[which]
+    return dt, shp(B, N, K, D)
+
+
+class OracleEnv:
+    """Host-memory twin of ``sigmarl_amd.env.SigmaEnv`` backed by the C oracle."""
+
+    def __init__(self, cfg: capi.Config, map_table):
+        self.lib = load_oracle()
+        self.cfg = cfg
+        self.map = map_table
+        self._map_struct = map_table.as_struct()
+        self.B, self.N, self.K = cfg.n_envs, cfg.n_agents, cfg.n_nearing
+        self.D = capi.obs_dim(self.K)
+        h = C.c_void_p()
+        rc = self.lib.create(C.byref(cfg), C.byref(self._map_struct), 0, None, C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"sigmaenv_oracle_create failed: {rc}")
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.lib.destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self, env_idx, agent_idx, path_ids, state8, full_env):
+        env_idx = np.ascontiguousarray(env_idx, np.int32)
+        agent_idx = np.ascontiguousarray(agent_idx, np.int32)
+        path_ids = np.ascontiguousarray(path_ids, np.int32).reshape(-1, 4)
+        state8 = np.ascontiguousarray(state8, np.float32).reshape(-1, 8)
+        n = len(env_idx)
+        rc = self.lib.reset(self.h, n, ptr(env_idx), ptr(agent_idx), ptr(path_ids), ptr(state8), int(full_env))
+        if rc != 0:
+            raise RuntimeError(f"oracle reset failed: {rc} {self.lib.last_error(self.h)}")
+
+    def step(self, actions):
+        a = np.ascontiguousarray(actions, np.float32).reshape(self.B, self.N, 2)
+        rc = self.lib.step(self.h, ptr(a))
+        if rc != 0:
+            raise RuntimeError(f"oracle step failed: {rc}")
+
+    def observe(self):
+        assert self.lib.observe(self.h) == 0
+
+    def auto_reset(self, seed, counter, path_first, path_count):
+        rc = self.lib.auto_reset(self.h, int(seed), int(counter), int(path_first), int(path_count))
+        if rc != 0:
+            raise RuntimeError(f"oracle auto_reset failed: {rc}")
+
+    def get(self, which, copy=True):
+        p = C.c_void_p()
+        nb = C.c_size_t()
+        rc = self.lib.get(self.h, int(which), C.byref(p), C.byref(nb))
+        if rc != 0:
+            raise RuntimeError(f"oracle get({which}) failed: {rc}")
+        dt, shp = buf_spec(which, self.B, self.N, self.K, self.D)
+        n = int(np.prod(shp))
+        assert n * np.dtype(dt).itemsize == nb.value, (which, shp, nb.value)
+        if n == 0:
+            return np.zeros(shp, dt)
+        arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(np.ctypeslib.as_ctypes_type(dt))), shape=(n,)).reshape(shp)
+        return arr.copy() if copy else arr
+
+    def path_table(self):
+        P = C.c_int32()
+        c, l, r = _f32p(), _f32p(), _f32p()
+        assert self.lib.path_table(self.h, C.byref(P), C.byref(c), C.byref(l), C.byref(r)) == 0
+        n = self.map.n_paths * P.value * 2
+        shp = (self.map.n_paths, P.value, 2)
+        return tuple(np.ctypeslib.as_array(x, shape=(n,)).reshape(shp).copy() for x in (c, l, r))

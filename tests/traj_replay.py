@@ -1,0 +1,176 @@
+"""Replays a golden trajectory (tests/golden/traj_*.npz) through an environment twin and reports deviations.
+
+The env object only needs ``reset/step/observe/get`` with numpy in/out (``OracleEnv`` or the numpy adapter of the HIP
+``SigmaEnv``), so the same replay checks the oracle against the reference goldens and the HIP path against both.
+"""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+
+from sigmarl_amd import capi
+from sigmarl_amd.maps import load_map
+from sigmarl_amd.params import Parameters, make_config
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+TRAJ_NAMES = ["cpm16_c2c", "cpm16_mtv", "intersection4_c2c", "onramp6_mtv", "cpm16_c2c_noreset", "cpm8_mtv_noreset", "cpmmixed4_c2c"]
+
+
+def load_fixture(name):
+    z = np.load(os.path.join(GOLDEN_DIR, f"traj_{name}.npz"))
+    meta = json.loads(str(z["meta_json"]))
+    return z, meta
+
+
+def params_from_meta(meta) -> Parameters:
+    keys = ["n_agents", "dt", "scenario_type", "is_use_mtv_distance", "rew_method", "is_testing_mode", "max_steps",
+            "is_obs_noise", "is_apply_mask", "cpm_scenario_probabilities"]
+    kw = {k: meta[k] for k in keys if k in meta}
+    return Parameters(**kw)
+
+
+def config_from_meta(meta, n_envs=None):
+    p = params_from_meta(meta)
+    mp = load_map(meta["scenario_type"])
+    cfg = make_config(p, mp, n_envs if n_envs is not None else meta["B"])
+    return cfg, mp
+
+
+def _state8(pos, rot, speed, steering, vel, sideslip):
+    return np.concatenate([pos, rot[..., None], speed[..., None], steering[..., None], vel, sideslip[..., None]], axis=-1).astype(np.float32)
+
+
+class Report:
+    def __init__(self):
+        self.max_abs = {}
+        self.mismatch = {}
+        self.count = {}
+
+    def f(self, key, got, want):
+        got = np.asarray(got, np.float64)
+        want = np.asarray(want, np.float64)
+        if got.size == 0:
+            return
+        d = np.abs(got - want)
+        d = np.where(np.isfinite(d), d, np.where(got == want, 0.0, np.inf))
+        self.max_abs[key] = max(self.max_abs.get(key, 0.0), float(d.max()))
+
+    def i(self, key, got, want):
+        got = np.asarray(got)
+        want = np.asarray(want)
+        self.mismatch[key] = self.mismatch.get(key, 0) + int((got.astype(np.int64) != want.astype(np.int64)).sum())
+        self.count[key] = self.count.get(key, 0) + int(got.size)
+
+    def worst_float(self):
+        return max(self.max_abs.values()) if self.max_abs else 0.0
+
+    def total_mismatch(self):
+        return sum(self.mismatch.values())
+
+    def __str__(self):
+        fl = ", ".join(f"{k}={v:.2e}" for k, v in sorted(self.max_abs.items(), key=lambda kv: -kv[1])[:8])
+        mm = ", ".join(f"{k}={v}/{self.count[k]}" for k, v in self.mismatch.items() if v)
+        return f"max|err|: {fl} | mismatches: {mm or 'none'}"
+
+
+def compare_snapshot(rep: Report, env, z, prefix, t, envs=None, with_reward=False, with_obs=True):
+    def sel(a):
+        return a if envs is None else a[envs]
+
+    def ref(key):
+        a = z[prefix + key]
+        return sel(a[t] if t is not None else a)
+
+    st = sel(env.get(capi.BUF_STATE))
+    rep.f("pos", st[..., 0:2], ref("pos"))
+    rep.f("rot", st[..., 2], ref("rot"))
+    rep.f("speed", st[..., 3], ref("speed"))
+    rep.f("steering", st[..., 4], ref("steering"))
+    rep.f("vel", st[..., 5:7], ref("vel"))
+    rep.f("sideslip", st[..., 7], ref("sideslip"))
+    rep.f("prev_pos", sel(env.get(capi.BUF_PREV_POS)), ref("prev_pos"))
+    rep.f("vertices", sel(env.get(capi.BUF_VERTICES)), ref("vertices"))
+    rep.f("short_term", sel(env.get(capi.BUF_SHORT_TERM)), ref("short_term"))
+    rep.f("dist_ref", sel(env.get(capi.BUF_DIST_REF)), ref("dist_ref"))
+    rep.f("dist_left", sel(env.get(capi.BUF_DIST_LEFT)), ref("dist_left"))
+    rep.f("dist_right", sel(env.get(capi.BUF_DIST_RIGHT)), ref("dist_right"))
+    rep.f("dist_bound", sel(env.get(capi.BUF_DIST_BOUND)), ref("dist_bound"))
+    rep.f("dist_agents", sel(env.get(capi.BUF_DIST_AGENTS)), ref("dist_agents"))
+    cl = sel(env.get(capi.BUF_CLOSEST))
+    rep.i("cp_ref", cl[..., 0], ref("cp_ref"))
+    rep.i("cp_left", cl[..., 1], ref("cp_left"))
+    rep.i("cp_right", cl[..., 2], ref("cp_right"))
+    rep.i("col_agents", sel(env.get(capi.BUF_COL_AGENTS)), ref("col_agents"))
+    cf = sel(env.get(capi.BUF_COL_FLAGS))
+    rep.i("col_lane", cf[..., 0], ref("col_lane"))
+    rep.i("col_entry", cf[..., 1], ref("col_entry"))
+    rep.i("col_exit", cf[..., 2], ref("col_exit"))
+    tm = sel(env.get(capi.BUF_TIMER))
+    rep.i("timer_step", tm[..., 0], ref("timer_step"))
+    if with_obs:
+        rep.f("obs", sel(env.get(capi.BUF_OBS)), ref("obs"))
+        rep.i("nearing_idx", sel(env.get(capi.BUF_NEARING)), ref("nearing_idx"))
+    if with_reward:
+        rep.f("reward", sel(env.get(capi.BUF_REWARD)), ref("reward"))
+        ri = env.get(capi.BUF_REWARD_INFO)
+        for k, name in enumerate(capi.REWARD_INFO_FIELDS):
+            rep.f(name, sel(ri[k]), ref(name))
+        rep.i("num_task_tries", tm[..., 1], ref("num_task_tries"))
+        rep.i("task_success_times", tm[..., 2], ref("task_success_times"))
+        rep.f("act_clamped", sel(env.get(capi.BUF_ACTION)), ref("act_clamped"))
+
+
+def apply_initial_reset(env, z, mp):
+    B, N = z["init_pos"].shape[:2]
+    env_idx = np.repeat(np.arange(B), N)
+    agent_idx = np.tile(np.arange(N), B)
+    ids = np.zeros((B, N, 4), np.int32)
+    ids[..., 1] = z["init_scenario_id"]
+    ids[..., 2] = z["init_path_id"]
+    ids[..., 3] = z["init_point_id"]
+    for b in range(B):
+        for i in range(N):
+            ids[b, i, 0] = mp.global_path(ids[b, i, 1], ids[b, i, 2])
+    st = _state8(z["init_pos"], z["init_rot"], z["init_speed"], z["init_steering"], z["init_vel"], z["init_sideslip"])
+    env.reset(env_idx, agent_idx, ids.reshape(-1, 4), st.reshape(-1, 8), 1)
+    env.observe()
+
+
+def apply_events(env, z, mp, t):
+    """Replays the reset draws the reference made at step t; returns the list of envs that were touched."""
+    touched = []
+    N = z["init_pos"].shape[1]
+    for k in np.nonzero(z["ev_step"] == t)[0]:
+        e, kind, a = int(z["ev_env"][k]), int(z["ev_kind"][k]), int(z["ev_agent"][k])
+        agents = list(range(N)) if kind == 1 else [a]
+        ids = np.zeros((len(agents), 4), np.int32)
+        st = np.zeros((len(agents), 8), np.float32)
+        for q, i in enumerate(agents):
+            sid, pid, ptid = int(z["ev_scenario_id"][k][i]), int(z["ev_path_id"][k][i]), int(z["ev_point_id"][k][i])
+            ids[q] = (mp.global_path(sid, pid), sid, pid, ptid)
+            st[q] = _state8(z["ev_pos"][k][i], z["ev_rot"][k][i], z["ev_speed"][k][i], z["ev_steering"][k][i],
+                            z["ev_vel"][k][i], z["ev_sideslip"][k][i])
+        env.reset(np.full(len(agents), e, np.int32), np.asarray(agents, np.int32), ids, st, 1 if kind == 1 else 0)
+        if e not in touched:
+            touched.append(e)
+    return touched
+
+
+def replay(env, z, meta, mp, steps=None, check_next=True) -> Report:
+    rep = Report()
+    T = int(meta["T"]) if steps is None else min(int(steps), int(meta["T"]))
+    apply_initial_reset(env, z, mp)
+    compare_snapshot(rep, env, z, "init_", None)
+    for t in range(T):
+        env.step(z["act"][t])
+        compare_snapshot(rep, env, z, "post_", t, with_reward=True)
+        rep.i("done", env.get(capi.BUF_DONE), z["done"][t])
+        touched = apply_events(env, z, mp, t)
+        if touched:
+            env.observe()
+            if check_next:
+                compare_snapshot(rep, env, z, "next_", t, envs=np.asarray(touched))
+    return rep
