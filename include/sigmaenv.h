@@ -159,9 +159,9 @@ int sigmaenv_step(sigmaenv_t* h, const float* actions);
 int sigmaenv_observe(sigmaenv_t* h);
 
 /* Device-side reset of every env whose done flag is set: rejection sampling of collision-free starts
- * (bounded retries), then the same deterministic reset as sigmaenv_reset(full_env=1) and a fresh observation.
- * seed/counter select the counter-based random stream. */
-int sigmaenv_auto_reset(sigmaenv_t* h, uint64_t seed, uint64_t counter);
+ * (bounded retries) on the paths [path_first, path_first + path_count) of the table, then the same deterministic
+ * reset as sigmaenv_reset(full_env=1) and a fresh observation.  seed/counter select the counter-based random stream. */
+int sigmaenv_auto_reset(sigmaenv_t* h, uint64_t seed, uint64_t counter, int32_t path_first, int32_t path_count);
 
 int sigmaenv_get(sigmaenv_t* h, sigmaenv_buf_t which, void** dev_ptr, size_t* bytes);
 

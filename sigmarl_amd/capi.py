@@ -132,7 +132,11 @@ _product_lib = None
 
 
 def load_library(path: str | None = None) -> Library:
+    """Loads ``libsigmaenv.so``.  torch is imported first on purpose: PyTorch-ROCm ships its own ``libamdhip64``; loading ours
+    before torch's would put two HIP runtimes in the process (observed: hipGetDeviceCount fails in the second one)."""
     global _product_lib
+    import torch  # noqa: F401  (must precede the CDLL below)
+
     if path is None:
         if _product_lib is None:
             _product_lib = Library(DEFAULT_LIB, "sigmaenv_", _PRODUCT_ONLY)

@@ -1,0 +1,275 @@
+// sigmaenv_device.h -- gfx950 device functions of the fused environment step.
+//
+// Arithmetic contract (DESIGN.md "Arithmetic contract"): fp32, one IEEE operation per torch op of the reference,
+// compiled with -ffp-contract=off so nothing is fused implicitly; the only fused operation is the explicit fmaf in
+// norm2 (PyTorch-CPU evaluates torch.norm over a length-2 dim as sqrt(fma(y,y,x*x))).  Division and sqrt are the
+// correctly rounded forms (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).  sin/cos/tan/atan/atan2 are the
+// correctly rounded fp32 value obtained through the fp64 OCML routine: (float)f((double)x).
+//
+// Reference citations are relative to /root/reference/sigmarl.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sigmaenv.h"
+
+#define NS SIGMAENV_N_SHORT_TERM
+#define PI32 3.14159274101257324f
+#define TWO_PI32 6.28318548202514648f
+
+namespace sigmadev {
+
+struct DevMap {
+  const float* center;  // [n_paths][P][2] padded (world_state_rt.py:313-420)
+  const float* left;
+  const float* right;
+  const float* yaw;     // [n_paths][yaw_stride]
+  const int32_t* n_center;
+  const int32_t* n_left;
+  const int32_t* n_right;
+  const uint8_t* is_loop;
+  int32_t P, n_paths, yaw_stride;
+};
+
+struct DevBufs {
+  float *state, *prev_pos, *vertices, *short_term, *dist_ref, *dist_left, *dist_right, *dist_bound, *dist_agents;
+  float *reward, *reward_info, *obs, *action;
+  int32_t *path, *closest, *nearing, *timer;
+  uint8_t *col_agents, *col_flags, *done;
+  unsigned long long* reset_mask;  // [B] bit i: agent i needs its derived state rebuilt
+  uint8_t* reset_full;             // [B] full-env reset pending
+};
+
+// ---- scalar helpers ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float cr_sin(float x) { return (float)sin((double)x); }
+__device__ __forceinline__ float cr_cos(float x) { return (float)cos((double)x); }
+__device__ __forceinline__ float cr_tan(float x) { return (float)tan((double)x); }
+__device__ __forceinline__ float cr_atan(float x) { return (float)atan((double)x); }
+__device__ __forceinline__ float cr_atan2(float y, float x) { return (float)atan2((double)y, (double)x); }
+__device__ __forceinline__ float norm2(float x, float y) { return sqrtf(fmaf(y, y, x * x)); }
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+__device__ __forceinline__ float remainder_pos(float a, float b) {  // torch.remainder, b > 0
+  float m = fmodf(a, b);
+  if (m != 0.0f && m < 0.0f) m += b;
+  return m;
+}
+__device__ __forceinline__ float angle_eliminate_two_pi(float a) {  // helper_scenario.py:1276-1289
+  float r = remainder_pos(a, TWO_PI32);
+  if (r > PI32) r -= TWO_PI32;
+  return r;
+}
+__device__ __forceinline__ float decreasing_lin(float x, float x0, float x1) {  // helper_scenario.py:960-996
+  x = clampf(x, x0, x1);
+  float denom = x1 - x0;
+  return 1.0f - (x - x0) / denom;
+}
+
+// ---- K1: WorldCustom.step + KinematicBicycleModel (helper_training.py:797-861, dynamics.py:62-192) ----------------
+__device__ inline void bicycle_step(const sigmaenv_config_t& c, float s[8], float u0, float u1, float uc[2]) {
+  float a0 = clampf(u0, -c.max_speed, c.max_speed);
+  float a1 = clampf(u1, -c.max_steering, c.max_steering);
+  uc[0] = a0;
+  uc[1] = a1;
+  float x = s[0], y = s[1], psi = s[2], v = s[3], delta = s[4];
+  float u_acc = (a0 - v) / c.dt;
+  float u_sr = (a1 - delta) / c.dt;
+  u_acc = clampf(u_acc, c.min_acc, c.max_acc);
+  u_sr = clampf(u_sr, c.min_steering_rate, c.max_steering_rate);
+  float l_wb = (float)((double)c.l_f + (double)c.l_r);
+  float k_beta = (float)((double)c.l_r / ((double)c.l_f + (double)c.l_r));
+  float tan_d = cr_tan(delta);
+  float beta = cr_atan(k_beta * tan_d);
+  float dx0 = v * cr_cos(psi + beta);
+  float dx1 = v * cr_sin(psi + beta);
+  float dx2 = (v / l_wb) * tan_d * cr_cos(beta);
+  float dt = c.dt;
+  x = x + dt * dx0;
+  y = y + dt * dx1;
+  psi = psi + dt * dx2;
+  v = v + dt * u_acc;
+  delta = delta + dt * u_sr;
+  delta = remainder_pos(delta + PI32, TWO_PI32) - PI32;
+  float beta1 = cr_atan(k_beta * cr_tan(delta));
+  float course = psi + beta1;
+  s[0] = x; s[1] = y; s[2] = psi; s[3] = v; s[4] = delta;
+  s[5] = v * cr_cos(course);
+  s[6] = v * cr_sin(course);
+  s[7] = beta1;
+}
+
+// ---- K2: get_rectangle_vertices (helper_scenario.py:695-826) ------------------------------------------------------
+__device__ inline void rect_vertices(const sigmaenv_config_t& c, float px, float py, float psi, float* v /*5x2*/) {
+  float lh = (float)((double)c.length / 2.0), wh = (float)((double)c.width / 2.0);
+  float cs = cr_cos(psi), sn = cr_sin(psi);
+  float nsn = -sn;
+  const float bx[5] = {lh, lh, -lh, -lh, lh};
+  const float by[5] = {wh, -wh, -wh, wh, wh};
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    v[2 * k] = (cs * bx[k] + nsn * by[k]) + px;
+    v[2 * k + 1] = (sn * bx[k] + cs * by[k]) + py;
+  }
+}
+
+// point -> segment distance, helper_scenario.py:858-872
+__device__ __forceinline__ float point_segment(float px, float py, float sx, float sy, float lx, float ly, float len2) {
+  float vx = px - sx, vy = py - sy;
+  float proj = (vx * lx + vy * ly) / len2;
+  float t = clampf(proj, 0.0f, 1.0f);
+  float cx = sx + lx * t, cy = sy + ly * t;
+  return norm2(cx - px, cy - py);
+}
+
+// one rectangle edge against one polyline segment, helper_scenario.py:1165-1196
+struct Edge {
+  float xa, ya, xb, yb, dx, dy, S;
+};
+__device__ __forceinline__ Edge make_edge(float xa, float ya, float xb, float yb) {
+  Edge e;
+  e.xa = xa; e.ya = ya; e.xb = xb; e.yb = yb;
+  e.dx = xb - xa;
+  e.dy = yb - ya;
+  e.S = e.dx * ya - e.dy * xa;
+  return e;
+}
+__device__ __forceinline__ bool edge_hits_segment(const Edge& e, float x2a, float y2a, float x2b, float y2b, float dx2, float dy2, float S2) {
+  float ma = e.dx * y2a - e.dy * x2a, mb = e.dx * y2b - e.dy * x2b;
+  bool C1 = ((ma - e.S) * (mb - e.S)) < 0.0f;
+  float wa = e.ya * dx2 - e.xa * dy2, wb = e.yb * dx2 - e.xb * dy2;
+  bool C2 = ((wa - S2) * (wb - S2)) < 0.0f;
+  return C1 && C2;
+}
+// interX for two closed rectangles (5 points each)
+__device__ inline bool interx_rect_rect(const float* va, const float* vb) {
+  bool hit = false;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    Edge e = make_edge(va[2 * i], va[2 * i + 1], va[2 * i + 2], va[2 * i + 3]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float x2a = vb[2 * j], y2a = vb[2 * j + 1], x2b = vb[2 * j + 2], y2b = vb[2 * j + 3];
+      float dx2 = x2b - x2a, dy2 = y2b - y2a;
+      float S2 = dx2 * y2a - dy2 * x2a;
+      hit |= edge_hits_segment(e, x2a, y2a, x2b, y2b, dx2, dy2, S2);
+    }
+  }
+  return hit;
+}
+// interX of a closed rectangle against one 2-point segment (entry / exit), world_state_rt_sim.py:413-424
+__device__ inline bool interx_rect_seg(const float* v, float x2a, float y2a, float x2b, float y2b) {
+  float dx2 = x2b - x2a, dy2 = y2b - y2a;
+  float S2 = dx2 * y2a - dy2 * x2a;
+  bool hit = false;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    Edge e = make_edge(v[2 * i], v[2 * i + 1], v[2 * i + 2], v[2 * i + 3]);
+    hit |= edge_hits_segment(e, x2a, y2a, x2b, y2b, dx2, dy2, S2);
+  }
+  return hit;
+}
+
+// ---- K4: mtv distance (helper_scenario.py:1030-1138) ---------------------------------------------------------------
+__device__ inline void rect_axes(const float* v, float ax[2][2]) {
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    float ex = v[2 * (k + 1)] - v[2 * k], ey = v[2 * (k + 1) + 1] - v[2 * k + 1];
+    float nrm = norm2(ex, ey);
+    ax[k][0] = ex / nrm;
+    ax[k][1] = ey / nrm;
+  }
+}
+__device__ inline void mtv_half(const float* va, const float* vb, const float axb[2][2], float& pos_min, float& omin_out, bool& any_inside) {
+  float maxbb[2], minbb[2], maxab[2], minab[2], pab[4][2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    maxbb[k] = -INFINITY; minbb[k] = INFINITY; maxab[k] = -INFINITY; minab[k] = INFINITY;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      float pb = vb[2 * v] * axb[k][0] + vb[2 * v + 1] * axb[k][1];
+      float pa = va[2 * v] * axb[k][0] + va[2 * v + 1] * axb[k][1];
+      pab[v][k] = pa;
+      maxbb[k] = fmaxf(maxbb[k], pb); minbb[k] = fminf(minbb[k], pb);
+      maxab[k] = fmaxf(maxab[k], pa); minab[k] = fminf(minab[k], pa);
+    }
+  }
+  float ov0 = fminf(maxbb[0], maxab[0]) - fmaxf(minbb[0], minab[0]);
+  float ov1 = fminf(maxbb[1], maxab[1]) - fmaxf(minbb[1], minab[1]);
+  float omin = fminf(ov0, ov1);
+  omin_out = omin;
+  bool inside_any = false;
+  float pm = INFINITY;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    float g[2];
+    bool inside = true;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      float p = pab[v][k];
+      g[k] = (p - minbb[k]) * (p <= minbb[k] ? 1.0f : 0.0f) + (maxbb[k] - p) * (p >= maxbb[k] ? 1.0f : 0.0f);
+      inside = inside && (p > minbb[k]) && (p < maxbb[k]);
+    }
+    pm = fminf(pm, norm2(g[0], g[1]));
+    float neg = -omin * (inside ? 1.0f : 0.0f);
+    if (fabsf(neg) > 0.0f) inside_any = true;
+  }
+  pos_min = pm;
+  any_inside = inside_any;
+}
+__device__ inline float mtv_pair(const float* vi, const float* vj) {
+  float axi[2][2], axj[2][2], pij, pji, omin_j, omin_i;
+  bool neg_ij, neg_ji;
+  rect_axes(vi, axi);
+  rect_axes(vj, axj);
+  mtv_half(vi, vj, axj, pij, omin_j, neg_ij);
+  mtv_half(vj, vi, axi, pji, omin_i, neg_ji);
+  float d = fminf(pij, pji);
+  if (neg_ij || neg_ji) d = -fminf(omin_j, omin_i);
+  return d;
+}
+
+// ---- K6: short-term reference path (helper_scenario.py:892-957) ----------------------------------------------------
+__device__ inline void short_term_path(const float* center, int n, bool is_loop, int cp, float* out /*NSx2*/) {
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    int id = k * 2 + cp + 1;
+    if (is_loop && id >= n - 1) id = (id + 1) % n;
+    out[2 * k] = center[2 * id];
+    out[2 * k + 1] = center[2 * id + 1];
+  }
+}
+
+// ---- ego-view transform (helper_scenario.py:1241-1273) -------------------------------------------------------------
+__device__ __forceinline__ void ego_transform(float pix, float piy, float rot_i, float pjx, float pjy, float& ox, float& oy) {
+  float dx = pjx - pix, dy = pjy - piy;
+  float ab = norm2(dx, dy);
+  float rr = cr_atan2(dy, dx) - rot_i;
+  ox = cr_cos(rr) * ab;
+  oy = cr_sin(rr) * ab;
+}
+
+// ---- wave-level (64 lanes) reductions -------------------------------------------------------------------------------
+// lexicographic (distance, index) minimum: torch.min returns the first minimal index (helper_scenario.py:883)
+__device__ __forceinline__ void wave_argmin(float& d, int& k) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    float od = __shfl_xor(d, off, 64);
+    int ok = __shfl_xor(k, off, 64);
+    if (od < d || (od == d && ok < k)) { d = od; k = ok; }
+  }
+}
+
+// counter-based RNG (specification shared with the oracle): splitmix64 finaliser over (seed, counter, env, agent, draw)
+__device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint64_t counter, uint32_t env, uint32_t agent, uint32_t draw) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (counter + 1);
+  z ^= ((uint64_t)env << 32) | ((uint64_t)agent << 16) | (uint64_t)draw;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (uint32_t)(z >> 32);
+}
+
+}  // namespace sigmadev

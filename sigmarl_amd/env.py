@@ -1,0 +1,249 @@
+"""``SigmaEnv``: device-buffer front end of the HIP environment step (thin Python over the C-ABI).
+
+PyTorch is used for plumbing only: device selection, the HIP stream, and zero-copy ``torch.Tensor`` views of the
+library-owned output buffers (``sigmaenv_get``).  All arithmetic of the path happens in ``csrc/sigmaenv.hip``.
+There is no CPU fallback: constructing a ``SigmaEnv`` without the built extension or without a GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import capi
+from .maps import MapTable, load_map
+from .params import Parameters, make_config
+
+_TORCH_DTYPES = {"f32": (torch.float32, "<f4", 4), "i32": (torch.int32, "<i4", 4), "u8": (torch.uint8, "|u1", 1)}
+
+
+def _buf_layout(B, N, K, D):
+    return {
+        capi.BUF_STATE: ("f32", (B, N, 8)), capi.BUF_PREV_POS: ("f32", (B, N, 2)), capi.BUF_VERTICES: ("f32", (B, N, 5, 2)),
+        capi.BUF_PATH: ("i32", (B, N, 4)), capi.BUF_SHORT_TERM: ("f32", (B, N, 3, 2)), capi.BUF_DIST_REF: ("f32", (B, N)),
+        capi.BUF_DIST_LEFT: ("f32", (B, N, 5)), capi.BUF_DIST_RIGHT: ("f32", (B, N, 5)), capi.BUF_DIST_BOUND: ("f32", (B, N)),
+        capi.BUF_CLOSEST: ("i32", (B, N, 3)), capi.BUF_DIST_AGENTS: ("f32", (B, N, N)), capi.BUF_COL_AGENTS: ("u8", (B, N, N)),
+        capi.BUF_COL_FLAGS: ("u8", (B, N, 4)), capi.BUF_REWARD: ("f32", (B, N)), capi.BUF_REWARD_INFO: ("f32", (12, B, N)),
+        capi.BUF_OBS: ("f32", (B, N, D)), capi.BUF_NEARING: ("i32", (B, N, K)), capi.BUF_DONE: ("u8", (B,)),
+        capi.BUF_TIMER: ("i32", (B, 4)), capi.BUF_ACTION: ("f32", (B, N, 2)),
+    }
+
+
+# ---- zero-copy torch view of a raw device pointer ---------------------------------------------------------------
+class _CudaArray:
+    def __init__(self, ptr, shape, typestr, owner):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2, "strides": None}
+        self._owner = owner
+
+
+class _DLDevice(C.Structure):
+    _fields_ = [("device_type", C.c_int32), ("device_id", C.c_int32)]
+
+
+class _DLDataType(C.Structure):
+    _fields_ = [("code", C.c_uint8), ("bits", C.c_uint8), ("lanes", C.c_uint16)]
+
+
+class _DLTensor(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("device", _DLDevice), ("ndim", C.c_int32), ("dtype", _DLDataType),
+                ("shape", C.POINTER(C.c_int64)), ("strides", C.POINTER(C.c_int64)), ("byte_offset", C.c_uint64)]
+
+
+class _DLManagedTensor(C.Structure):
+    pass
+
+
+_DELETER = C.CFUNCTYPE(None, C.POINTER(_DLManagedTensor))
+_DLManagedTensor._fields_ = [("dl_tensor", _DLTensor), ("manager_ctx", C.c_void_p), ("deleter", _DELETER)]
+_noop_deleter = _DELETER(lambda p: None)
+_keepalive = []
+
+
+def _view_dlpack(ptr, shape, kind, device_index):
+    code, bits = {"f32": (2, 32), "i32": (0, 32), "u8": (1, 8)}[kind]
+    shp = (C.c_int64 * len(shape))(*shape)
+    mt = _DLManagedTensor()
+    mt.dl_tensor.data = int(ptr)
+    mt.dl_tensor.device = _DLDevice(10, device_index)  # kDLROCM
+    mt.dl_tensor.ndim = len(shape)
+    mt.dl_tensor.dtype = _DLDataType(code, bits, 1)
+    mt.dl_tensor.shape = shp
+    mt.dl_tensor.strides = None
+    mt.dl_tensor.byte_offset = 0
+    mt.manager_ctx = None
+    mt.deleter = _noop_deleter
+    _keepalive.append((mt, shp))
+    C.pythonapi.PyCapsule_New.restype = C.py_object
+    C.pythonapi.PyCapsule_New.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
+    cap = C.pythonapi.PyCapsule_New(C.addressof(mt), b"dltensor", None)
+    return torch.utils.dlpack.from_dlpack(cap)
+
+
+def device_view(ptr, shape, kind, device_index, owner):
+    """torch.Tensor aliasing ``ptr`` (no copy).  Empty shapes get an ordinary empty tensor."""
+    tdtype, typestr, _ = _TORCH_DTYPES[kind]
+    if int(np.prod(shape)) == 0:
+        return torch.empty(shape, dtype=tdtype, device=f"cuda:{device_index}")
+    try:
+        t = torch.as_tensor(_CudaArray(ptr, shape, typestr, owner), device=f"cuda:{device_index}")
+        if t.data_ptr() == int(ptr):
+            return t
+    except Exception:
+        pass
+    t = _view_dlpack(ptr, shape, kind, device_index)
+    assert t.data_ptr() == int(ptr), "zero-copy view of the device buffer failed"
+    return t
+
+
+class SigmaEnv:
+    """One env shard on one GPU.  ``step(actions)`` is one fused HIP launch over agents x envs."""
+
+    def __init__(self, parameters: Parameters | None = None, n_envs: int | None = None, device=None, *, cfg: capi.Config | None = None,
+                 map_table: MapTable | None = None, make_world_scenario_type: str = "cpm_entire", lib_path: str | None = None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("sigmarl_amd.SigmaEnv needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+        self.lib = capi.load_library(lib_path)
+        if cfg is None:
+            if parameters is None:
+                raise ValueError("pass `parameters` (+ n_envs) or a ready `cfg` + `map_table`")
+            map_table = map_table or load_map(parameters.scenario_type)
+            cfg = make_config(parameters, map_table, int(n_envs if n_envs is not None else parameters.num_vmas_envs), make_world_scenario_type)
+        self.parameters = parameters
+        self.cfg = cfg
+        self.map = map_table
+        self.device = torch.device(device if device is not None else "cuda:0")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.B, self.N, self.K = cfg.n_envs, cfg.n_agents, cfg.n_nearing
+        self.D = capi.obs_dim(self.K)
+        self._map_struct = map_table.as_struct()
+        with torch.cuda.device(self.device):
+            self.stream = torch.cuda.current_stream(self.device)
+            h = C.c_void_p()
+            rc = self.lib.create(C.byref(cfg), C.byref(self._map_struct), self.device.index, C.c_void_p(self.stream.cuda_stream), C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"sigmaenv_create failed with code {rc}")
+        self.h = h
+        self._views = {}
+        layout = _buf_layout(self.B, self.N, self.K, self.D)
+        for which, (kind, shape) in layout.items():
+            p = C.c_void_p()
+            nb = C.c_size_t()
+            self._chk(self.lib.get(self.h, which, C.byref(p), C.byref(nb)), "get")
+            assert int(np.prod(shape)) * _TORCH_DTYPES[kind][2] == nb.value, (which, shape, nb.value)
+            self._views[which] = device_view(p.value, shape, kind, self.device.index, self)
+        self._reset_counter = 0
+
+    # ---- plumbing ---------------------------------------------------------------------------------------------
+    def _chk(self, rc, what):
+        if rc != 0:
+            msg = self.lib.last_error(self.h)
+            raise RuntimeError(f"sigmaenv_{what} failed with code {rc}: {msg.decode() if msg else ''}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.destroy(self.h)
+            self.h = None
+            self._views = {}
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def buffer(self, which) -> torch.Tensor:
+        """Zero-copy view of a library-owned device buffer (see ``sigmaenv_buf_t``)."""
+        return self._views[which]
+
+    # ---- the C-ABI calls ----------------------------------------------------------------------------------------
+    def reset(self, env_idx, agent_idx, path_ids, state8, full_env: bool):
+        env_idx = np.ascontiguousarray(env_idx, np.int32)
+        agent_idx = np.ascontiguousarray(agent_idx, np.int32)
+        path_ids = np.ascontiguousarray(path_ids, np.int32).reshape(-1, 4)
+        state8 = np.ascontiguousarray(state8, np.float32).reshape(-1, 8)
+        n = len(env_idx)
+        assert len(agent_idx) == n and len(path_ids) == n and len(state8) == n
+        with torch.cuda.device(self.device):
+            self._chk(self.lib.reset(self.h, n, env_idx.ctypes.data_as(C.c_void_p), agent_idx.ctypes.data_as(C.c_void_p),
+                                     path_ids.ctypes.data_as(C.c_void_p), state8.ctypes.data_as(C.c_void_p), int(bool(full_env))), "reset")
+
+    def step(self, actions: torch.Tensor):
+        """actions: float32 CUDA tensor [B, N, 2] (v_cmd, delta_cmd); enqueues one fused step on the env's stream."""
+        if not (isinstance(actions, torch.Tensor) and actions.is_cuda and actions.dtype == torch.float32 and actions.is_contiguous()):
+            raise TypeError("actions must be a contiguous float32 CUDA tensor")
+        if tuple(actions.shape) != (self.B, self.N, 2):
+            raise ValueError(f"actions must have shape {(self.B, self.N, 2)}, got {tuple(actions.shape)}")
+        self._chk(self.lib.step(self.h, C.c_void_p(actions.data_ptr())), "step")
+
+    def observe(self):
+        self._chk(self.lib.observe(self.h), "observe")
+
+    def auto_reset(self, seed: int = 0, counter: int | None = None, path_first: int | None = None, path_count: int | None = None):
+        if counter is None:
+            counter = self._reset_counter
+            self._reset_counter += 1
+        if path_first is None:
+            path_first, path_count = self.map.list_first[0], self.map.list_count[0]
+        self._chk(self.lib.auto_reset(self.h, int(seed), int(counter), int(path_first), int(path_count)), "auto_reset")
+
+    def sync(self):
+        self._chk(self.lib.sync(self.h), "sync")
+
+    def step_time_ms(self):
+        avg = C.c_double()
+        n = C.c_int32()
+        self._chk(self.lib.step_time_ms(self.h, C.byref(avg), C.byref(n)), "step_time_ms")
+        return avg.value, n.value
+
+    # ---- convenience --------------------------------------------------------------------------------------------
+    @property
+    def obs(self):
+        return self._views[capi.BUF_OBS]
+
+    @property
+    def reward(self):
+        return self._views[capi.BUF_REWARD]
+
+    @property
+    def done(self):
+        return self._views[capi.BUF_DONE]
+
+    @property
+    def state(self):
+        return self._views[capi.BUF_STATE]
+
+    def reset_random(self, seed: int = 0):
+        """Initial reset of every env through the device-side sampler (marks all envs done first)."""
+        self._views[capi.BUF_DONE].fill_(1)
+        self.auto_reset(seed=seed)
+
+
+class NumpyAdapter:
+    """Host-array facade over ``SigmaEnv`` with the interface of ``tests/oracle_binding.OracleEnv`` (used by the parity tests)."""
+
+    def __init__(self, env: SigmaEnv):
+        self.env = env
+        self.B, self.N, self.K, self.D = env.B, env.N, env.K, env.D
+
+    def reset(self, env_idx, agent_idx, path_ids, state8, full_env):
+        self.env.reset(env_idx, agent_idx, path_ids, state8, full_env)
+
+    def step(self, actions):
+        a = torch.as_tensor(np.ascontiguousarray(actions, np.float32).reshape(self.B, self.N, 2)).to(self.env.device)
+        self.env.step(a)
+        self.env.sync()
+
+    def observe(self):
+        self.env.observe()
+
+    def auto_reset(self, seed, counter, path_first, path_count):
+        self.env.auto_reset(seed, counter, path_first, path_count)
+
+    def get(self, which, copy=True):
+        self.env.sync()
+        return self.env.buffer(which).cpu().numpy()
+
+    def close(self):
+        self.env.close()

@@ -1,0 +1,216 @@
+"""Parity tests proper (run with -m gpu on an MI355X): the HIP fused step, called through the C-ABI, against
+(1) the reference goldens, (2) the CPU oracle on seeded inputs, (3) size-independent properties at BASELINE sizes.
+
+Bar: masks / indices / counters bit-exact; fp32 states, rewards, observations within 1e-5 abs (mtv distance 5e-5 against
+the reference goldens only, see test_oracle_golden.py; HIP vs oracle share the arithmetic contract and are held to 1e-5).
+"""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import traj_replay as tr
+from sigmarl_amd import capi
+from sigmarl_amd.maps import load_map
+from sigmarl_amd.params import Parameters, make_config
+
+pytestmark = pytest.mark.gpu
+
+FTOL = 1e-5
+MTV_TOL = 5e-5
+
+INT_BUFS = [capi.BUF_PATH, capi.BUF_CLOSEST, capi.BUF_COL_AGENTS, capi.BUF_COL_FLAGS, capi.BUF_NEARING, capi.BUF_DONE, capi.BUF_TIMER]
+FLT_BUFS = [capi.BUF_STATE, capi.BUF_PREV_POS, capi.BUF_VERTICES, capi.BUF_SHORT_TERM, capi.BUF_DIST_REF, capi.BUF_DIST_LEFT,
+            capi.BUF_DIST_RIGHT, capi.BUF_DIST_BOUND, capi.BUF_DIST_AGENTS, capi.BUF_REWARD, capi.BUF_REWARD_INFO, capi.BUF_OBS, capi.BUF_ACTION]
+
+
+def _hip_env(cfg, mp):
+    from sigmarl_amd.env import NumpyAdapter, SigmaEnv
+
+    return NumpyAdapter(SigmaEnv(cfg=cfg, map_table=mp, device="cuda:0"))
+
+
+def test_extension_is_loaded_and_exports_abi():
+    lib = capi.load_library()
+    assert lib.path.endswith("sigmarl_amd/csrc/libsigmaenv.so")
+    assert lib.obs_dim(2) == 32
+
+
+@pytest.mark.parametrize("name", tr.TRAJ_NAMES)
+def test_hip_vs_reference_goldens(name):
+    z, meta = tr.load_fixture(name)
+    cfg, mp = tr.config_from_meta(meta)
+    env = _hip_env(cfg, mp)
+    rep = tr.replay(env, z, meta, mp)
+    env.close()
+    assert rep.total_mismatch() == 0, str(rep)
+    for key, err in rep.max_abs.items():
+        tol = MTV_TOL if (meta["is_use_mtv_distance"] and key in ("dist_agents", "obs", "reward", "rew_total", "rew_near_other_agents")) else FTOL
+        assert err <= tol, (key, err, str(rep))
+
+
+def _compare_all(dev, ora, tag):
+    n_float_diff = 0
+    for which in INT_BUFS:
+        a, b = dev.get(which), ora.get(which)
+        assert np.array_equal(a, b), f"{tag}: integer/mask buffer {which}: {(a != b).sum()} mismatches"
+    for which in FLT_BUFS:
+        a, b = dev.get(which), ora.get(which)
+        both_inf = np.isinf(a) & np.isinf(b) & (np.sign(a) == np.sign(b))
+        d = np.where(both_inf, 0.0, np.abs(a.astype(np.float64) - b.astype(np.float64)))
+        assert d.max() <= FTOL, f"{tag}: float buffer {which}: max |err| {d.max()}"
+        n_float_diff += int((a != b).sum() - (np.isnan(a) & np.isnan(b)).sum())
+    return n_float_diff
+
+
+CASES = [
+    # scenario, N, B, mtv, rew_method, dt, testing, steps
+    ("cpm_entire", 16, 64, False, "distance", 0.05, False, 12),
+    ("cpm_entire", 16, 48, True, "ttc_sparse", 0.1, False, 12),
+    ("cpm_entire", 5, 33, False, "sparse", 0.05, False, 10),       # ragged: N not a divisor of the wave count, odd B
+    ("cpm_entire", 32, 16, True, "distance_sparse", 0.05, False, 8),  # 32 agents: two agents per wavefront slot
+    ("cpm_entire", 2, 7, False, "ttc", 0.05, True, 10),            # minimum: 2 agents, 1 neighbour, testing-mode reward/done
+    ("intersection_1", 4, 40, False, "distance", 0.1, False, 16),  # non-loop map: entry/exit segments, reset requests
+    ("on_ramp_1", 6, 40, True, "ttc", 0.1, False, 16),
+]
+
+
+@pytest.mark.parametrize("scen,N,B,mtv,rew,dt,testing,steps", CASES)
+def test_hip_vs_oracle_seeded(scen, N, B, mtv, rew, dt, testing, steps):
+    """Same seeded inputs through the HIP path and the oracle, incl. the shared-specification device-side resets."""
+    p = Parameters(n_agents=N, scenario_type=scen, is_use_mtv_distance=mtv, rew_method=rew, dt=dt, is_testing_mode=testing,
+                   is_apply_mask=False, is_obs_noise=False, max_steps=9)
+    mp = load_map(scen)
+    cfg = make_config(p, mp, B)
+    dev, ora = _hip_env(cfg, mp), ob.OracleEnv(cfg, mp)
+    dev.env.buffer(capi.BUF_DONE).fill_(1)
+    ora.get(capi.BUF_DONE, copy=False)[:] = 1
+    pf, pc = mp.list_first[0], mp.list_count[0]
+    dev.auto_reset(5, 0, pf, pc)
+    ora.auto_reset(5, 0, pf, pc)
+    _compare_all(dev, ora, "after initial reset")
+    rng = np.random.default_rng(123)
+    n_diff = 0
+    seen_done = 0
+    for t in range(steps):
+        act = np.stack([rng.uniform(-0.2, 1.3, (B, N)), rng.uniform(-0.7, 0.7, (B, N))], axis=-1).astype(np.float32)
+        if t % 3 == 2:  # gentle actions so that some episodes live long enough to hit max_steps
+            act = np.stack([rng.uniform(0.0, 0.3, (B, N)), rng.uniform(-0.05, 0.05, (B, N))], axis=-1).astype(np.float32)
+        dev.step(act)
+        ora.step(act)
+        n_diff += _compare_all(dev, ora, f"step {t}")
+        seen_done += int(ora.get(capi.BUF_DONE).sum())
+        dev.auto_reset(5, t + 1, pf, pc)
+        ora.auto_reset(5, t + 1, pf, pc)
+        n_diff += _compare_all(dev, ora, f"reset after step {t}")
+    assert seen_done > 0
+    # the two sides share the arithmetic contract: expect (almost) no differing fp32 word at all
+    print(f"{scen} N={N} B={B}: differing fp32 words over the run: {n_diff}")
+    dev.close()
+    ora.close()
+
+
+def test_forced_overlaps_and_edge_cases():
+    """Injected states: overlapping rectangles (collision masks, negative mtv), coincident agents (atan2(0,0), zero distance),
+    an agent far outside the map, zero speed, steering beyond the clamp."""
+    for mtv in (False, True):
+        p = Parameters(n_agents=6, scenario_type="cpm_entire", is_use_mtv_distance=mtv, rew_method="distance_sparse", is_apply_mask=False,
+                       is_obs_noise=False)
+        mp = load_map("cpm_entire")
+        B = 4
+        cfg = make_config(p, mp, B)
+        dev, ora = _hip_env(cfg, mp), ob.OracleEnv(cfg, mp)
+        c = mp.center[3]
+        st = np.zeros((B, 6, 8), np.float32)
+        ids = np.zeros((B, 6, 4), np.int32)
+        ids[..., 0] = 3
+        ids[..., 2] = 3
+        for b in range(B):
+            for i in range(6):
+                k = 5 + 9 * i
+                st[b, i, 0:2] = c[k]
+                st[b, i, 2] = mp.yaw[3][k]
+        st[0, 1, 0:2] = st[0, 0, 0:2] + np.float32([0.05, 0.01])  # overlapping pair
+        st[0, 1, 2] = st[0, 0, 2] + 0.4
+        st[1, 2] = st[1, 3]                                         # coincident agents
+        st[2, 4, 0:2] = np.float32([9.0, -3.0])                     # far outside the 4.5 x 4.0 world
+        st[3, :, 3] = 0.9
+        st[3, :, 4] = 0.5
+        env_idx = np.repeat(np.arange(B), 6)
+        agent_idx = np.tile(np.arange(6), B)
+        for e in (dev, ora):
+            e.reset(env_idx, agent_idx, ids.reshape(-1, 4), st.reshape(-1, 8), 1)
+            e.observe()
+        _compare_all(dev, ora, f"mtv={mtv} injected reset")
+        rng = np.random.default_rng(7)
+        for t in range(5):
+            act = np.stack([rng.uniform(-2, 2, (B, 6)), rng.uniform(-2, 2, (B, 6))], axis=-1).astype(np.float32)
+            dev.step(act)
+            ora.step(act)
+            _compare_all(dev, ora, f"mtv={mtv} step {t}")
+        ca = ora.get(capi.BUF_COL_AGENTS)
+        da = ora.get(capi.BUF_DIST_AGENTS)
+        if not mtv:
+            assert ca[0, 0, 1] == 1 and ca[0, 1, 0] == 1
+        else:
+            assert da[0, 0, 1] < 0
+        dev.close()
+        ora.close()
+
+
+@pytest.mark.parametrize("N,B", [(16, 4096), (32, 8192)])
+def test_full_size_properties(N, B):
+    """BASELINE sizes (config 2: 16 x 4096, config 4 shape: 32 x 8192): determinism, invariants, and oracle parity on a slice."""
+    scen = "cpm_entire"
+    p = Parameters(n_agents=N, scenario_type=scen, is_use_mtv_distance=False, rew_method="distance", is_apply_mask=False, is_obs_noise=False)
+    mp = load_map(scen)
+    cfg = make_config(p, mp, B)
+    pf, pc = mp.list_first[0], mp.list_count[0]
+    rng = np.random.default_rng(1)
+    acts = [np.stack([rng.uniform(0, 1, (B, N)), rng.uniform(-0.25, 0.25, (B, N))], axis=-1).astype(np.float32) for _ in range(3)]
+
+    def run():
+        dev = _hip_env(cfg, mp)
+        dev.env.buffer(capi.BUF_DONE).fill_(1)
+        dev.auto_reset(9, 0, pf, pc)
+        outs = []
+        for t, a in enumerate(acts):
+            dev.step(a)
+            outs.append({w: dev.get(w) for w in INT_BUFS + FLT_BUFS})
+            dev.auto_reset(9, t + 1, pf, pc)
+        dev.close()
+        return outs
+
+    o1, o2 = run(), run()
+    for a, b in zip(o1, o2):  # same input -> bit-identical output across launches (no atomics / races in the data path)
+        for w in a:
+            assert a[w].tobytes() == b[w].tobytes(), f"non-deterministic buffer {w}"
+    last = o1[-1]
+    st = last[capi.BUF_STATE]
+    assert np.isfinite(st).all() and np.isfinite(last[capi.BUF_OBS]).all() and np.isfinite(last[capi.BUF_REWARD]).all()
+    assert (np.abs(last[capi.BUF_REWARD]) <= 1.0).all()
+    assert np.array_equal(last[capi.BUF_PREV_POS], st[..., 0:2])          # state_buffer.add after the last agent
+    da = last[capi.BUF_DIST_AGENTS]
+    assert np.array_equal(da, da.transpose(0, 2, 1))                      # symmetric matrix
+    assert (last[capi.BUF_DIST_REF] >= 0).all()
+    ca = last[capi.BUF_COL_AGENTS]
+    assert np.array_equal(ca, ca.transpose(0, 2, 1))
+    done = last[capi.BUF_DONE].astype(bool)
+    col = ca.reshape(B, -1).any(1) | last[capi.BUF_COL_FLAGS][..., 0].any(1)
+    assert np.array_equal(done, col | (last[capi.BUF_TIMER][:, 0] == cfg.max_steps - 1))
+    # nearest neighbours really are the two smallest entries of the distance row
+    near = last[capi.BUF_NEARING]
+    srt = np.sort(da, axis=-1)
+    picked = np.take_along_axis(da, near.astype(np.int64), axis=-1)
+    assert np.array_equal(picked, srt[..., : near.shape[-1]])
+    # full-size oracle parity (the C oracle finishes this in seconds)
+    ora = ob.OracleEnv(cfg, mp)
+    ora.get(capi.BUF_DONE, copy=False)[:] = 1
+    ora.auto_reset(9, 0, pf, pc)
+    for t, a in enumerate(acts):
+        ora.step(a)
+        for w in INT_BUFS:
+            assert np.array_equal(o1[t][w], ora.get(w)), f"full-size mismatch in buffer {w} at step {t}"
+        for w in FLT_BUFS:
+            assert np.abs(o1[t][w] - ora.get(w)).max() <= FTOL
+        ora.auto_reset(9, t + 1, pf, pc)
+    ora.close()
