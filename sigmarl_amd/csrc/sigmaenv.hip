@@ -147,6 +147,151 @@ __device__ inline void agent_scan(const DevMap& m, const sigmaenv_config_t& c, i
   r.dr[0] = r.dr[0] - wh;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// B2, pruned: the same (min, first argmin) / collision results as the full scan, but only the polyline chunks that can matter
+// are evaluated.  Exactness argument (DESIGN.md "Pruned scan"): a run of 8 consecutive segments is skipped only if the
+// distance from the agent's centre to the run's bounding box exceeds T, where T bounds (with a 1e-4 m margin, >> fp32 error)
+//   * the distance of every query point to the segment that was closest last step (an upper bound of its minimum), and
+//   * the rectangle's circumradius (a segment farther than that cannot intersect an edge).
+// So every segment whose computed distance can equal or beat the running minimum, and every segment that can hit the
+// rectangle, is still evaluated with the very same arithmetic; ties still resolve to the lowest index.
+// Lanes 0-31 scan the left boundary, lanes 32-63 the right one; the centre line uses all 64 lanes.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t chunk_mask(const float4* __restrict__ box, int nch, int lane, float px, float py, float T) {
+  bool cand = false;
+  if (lane < nch) {
+    float4 b = box[lane];
+    float dx = fmaxf(fmaxf(b.x - px, px - b.z), 0.0f);
+    float dy = fmaxf(fmaxf(b.y - py, py - b.w), 0.0f);
+    float lb = sqrtf(dx * dx + dy * dy);
+    cand = !(lb > T);  // a NaN threshold keeps every chunk
+  }
+  return (uint32_t)__ballot(cand);
+}
+__device__ __forceinline__ int nth_set_bit(uint32_t m, int c) {
+  for (int t = 0; t < c; ++t) m &= (m - 1u);
+  return m ? (__ffs((int)m) - 1) : -1;
+}
+__device__ __forceinline__ float guess_distance(const float* __restrict__ poly, int n, int cp_guess, float px, float py) {
+  int k = cp_guess - 1;
+  k = k < 0 ? 0 : (k > n - 2 ? n - 2 : k);
+  const float2* p2 = reinterpret_cast<const float2*>(poly);
+  float2 a = p2[k], b = p2[k + 1];
+  float lx = b.x - a.x, ly = b.y - a.y;
+  return point_segment(px, py, a.x, a.y, lx, ly, lx * lx + ly * ly);
+}
+
+template <bool COLLIDE>
+__device__ inline void agent_scan_pruned(const DevMap& m, const sigmaenv_config_t& c, int path, int lane, float cgx, float cgy, const float* qv,
+                                         const float* ev, const int* cp_guess, AgentScan& r) {
+  const float* ctr = m.center + (size_t)path * m.P * 2;
+  const float* lb = m.left + (size_t)path * m.P * 2;
+  const float* rb = m.right + (size_t)path * m.P * 2;
+  const int n = m.n_center[path], nl = m.n_left[path], nr = m.n_right[path];
+  const float4* box = m.chunk_box + (size_t)path * 3 * m.nch;
+  const float MARGIN = 1e-4f;
+  // radii of the query points / rectangle vertices around the centre of gravity
+  float Rq = 0.0f, Rv = 0.0f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float ax = qv[2 * q] - cgx, ay = qv[2 * q + 1] - cgy;
+    Rq = fmaxf(Rq, sqrtf(ax * ax + ay * ay));
+    float bx = ev[2 * q] - cgx, by = ev[2 * q + 1] - cgy;
+    Rv = fmaxf(Rv, sqrtf(bx * bx + by * by));
+  }
+  // ---- centre line (CG only), 64 lanes over the candidate segments
+  {
+    float T = guess_distance(ctr, n, cp_guess[0], cgx, cgy) + MARGIN;
+    int nch = (n - 1 + SIGMAENV_CHUNK - 1) / SIGMAENV_CHUNK;
+    uint32_t mc = chunk_mask(box, nch, lane, cgx, cgy, T);
+    int cnt = __popc(mc) * SIGMAENV_CHUNK;
+    float bd = INFINITY;
+    int bk = 0;
+    const float2* p2 = reinterpret_cast<const float2*>(ctr);
+    for (int base = 0; base < cnt; base += 64) {
+      int j = base + lane;
+      int ch = nth_set_bit(mc, j >> 3);
+      int k = ch * SIGMAENV_CHUNK + (j & 7);
+      if (ch >= 0 && k + 1 < n) {
+        float2 a = p2[k], b = p2[k + 1];
+        float lx = b.x - a.x, ly = b.y - a.y;
+        float d = point_segment(cgx, cgy, a.x, a.y, lx, ly, lx * lx + ly * ly);
+        if (d < bd || (d == bd && k < bk)) { bd = d; bk = k; }
+      }
+    }
+    wave_argmin(bd, bk);
+    r.d_ref = bd;
+    r.cp_ref = bk + 1;
+  }
+  // ---- boundaries: half-wave per side
+  const int half = lane >> 5, hl = lane & 31;
+  const float* poly = half ? rb : lb;
+  const int np = half ? nr : nl;
+  float Tl = fmaxf(guess_distance(lb, nl, cp_guess[1], cgx, cgy) + 2.0f * Rq, COLLIDE ? Rv : 0.0f) + MARGIN;
+  float Tr = fmaxf(guess_distance(rb, nr, cp_guess[2], cgx, cgy) + 2.0f * Rq, COLLIDE ? Rv : 0.0f) + MARGIN;
+  uint32_t ml = chunk_mask(box + m.nch, (nl - 1 + SIGMAENV_CHUNK - 1) / SIGMAENV_CHUNK, lane, cgx, cgy, Tl);
+  uint32_t mr = chunk_mask(box + 2 * m.nch, (nr - 1 + SIGMAENV_CHUNK - 1) / SIGMAENV_CHUNK, lane, cgx, cgy, Tr);
+  const uint32_t mm = half ? mr : ml;
+  const int cnt_max = max(__popc(ml), __popc(mr)) * SIGMAENV_CHUNK;
+  Edge e[4];
+  if (COLLIDE) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e[i] = make_edge(ev[2 * i], ev[2 * i + 1], ev[2 * i + 2], ev[2 * i + 3]);
+  }
+  float bd[5];
+  int bk = 0;
+#pragma unroll
+  for (int q = 0; q < 5; ++q) bd[q] = INFINITY;
+  bool h = false;
+  const float2* p2 = reinterpret_cast<const float2*>(poly);
+  for (int base = 0; base < cnt_max; base += 32) {
+    int j = base + hl;
+    int ch = nth_set_bit(mm, j >> 3);
+    int k = ch * SIGMAENV_CHUNK + (j & 7);
+    if (ch >= 0 && k + 1 < np) {
+      float2 a = p2[k], b = p2[k + 1];
+      float lx = b.x - a.x, ly = b.y - a.y;
+      float len2 = lx * lx + ly * ly;
+      float d0 = point_segment(cgx, cgy, a.x, a.y, lx, ly, len2);
+      if (d0 < bd[0] || (d0 == bd[0] && k < bk)) { bd[0] = d0; bk = k; }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bd[q + 1] = fminf(bd[q + 1], point_segment(qv[2 * q], qv[2 * q + 1], a.x, a.y, lx, ly, len2));
+      if (COLLIDE) {
+        float S2 = lx * a.y - ly * a.x;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h |= edge_hits_segment(e[i], a.x, a.y, b.x, b.y, lx, ly, S2);
+      }
+    }
+  }
+  // reductions inside each 32-lane half (xor offsets < 32 never cross the halves)
+#pragma unroll
+  for (int off = 16; off >= 1; off >>= 1) {
+    float od = __shfl_xor(bd[0], off, 64);
+    int ok = __shfl_xor(bk, off, 64);
+    if (od < bd[0] || (od == bd[0] && ok < bk)) { bd[0] = od; bk = ok; }
+#pragma unroll
+    for (int q = 1; q < 5; ++q) bd[q] = fminf(bd[q], __shfl_xor(bd[q], off, 64));
+  }
+  float wh = (float)((double)c.width / 2.0);
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    r.dl[q] = __shfl(bd[q], 0, 64);
+    r.dr[q] = __shfl(bd[q], 32, 64);
+  }
+  r.cp_l = __shfl(bk, 0, 64) + 1;
+  r.cp_r = __shfl(bk, 32, 64) + 1;
+  r.dl[0] = r.dl[0] - wh;
+  r.dr[0] = r.dr[0] - wh;
+  r.hit = COLLIDE ? (__ballot(h) != 0ull) : false;
+}
+
+template <bool COLLIDE>
+__device__ __forceinline__ void agent_scan_any(const DevMap& m, const sigmaenv_config_t& c, int path, int lane, float cgx, float cgy,
+                                               const float* qv, const float* ev, const int* cp_guess, AgentScan& r) {
+  if (m.nch > 0) agent_scan_pruned<COLLIDE>(m, c, path, lane, cgx, cgy, qv, ev, cp_guess, r);
+  else agent_scan<COLLIDE>(m, c, path, lane, cgx, cgy, qv, ev, r);
+}
+
 // mutual distance of pair (i, j), i != j  (update_mutual_distances, world_state_rt_sim.py:360-373)
 __device__ __forceinline__ float pair_distance(const sigmaenv_config_t& c, const float* st, const float* verts, int i, int j) {
   if (c.distance_type == SIGMAENV_DIST_C2C) {
@@ -297,6 +442,8 @@ __global__ void __launch_bounds__(1024) sigmaenv_step_kernel(sigmaenv_config_t c
 #pragma unroll
     for (int k = 0; k < 10; ++k) { s.vnew[i * 10 + k] = v[k]; g.vertices[bi * 10 + k] = v[k]; }
     s.path[i] = g.path[bi * 4];
+    // last step's closest-point indices: the pruned scan derives its distance upper bounds from them
+    s.cp[i * 3 + 0] = g.closest[bi * 3 + 0]; s.cp[i * 3 + 1] = g.closest[bi * 3 + 1]; s.cp[i * 3 + 2] = g.closest[bi * 3 + 2];
   }
   __syncthreads();
 
@@ -322,7 +469,7 @@ __global__ void __launch_bounds__(1024) sigmaenv_step_kernel(sigmaenv_config_t c
     const float* si = s.st + i * 8;
     const float* qv = (i == 0) ? (s.vold) : (s.vnew + i * 10);  // agent 0 queries its corners at last step's vertices
     AgentScan r;
-    agent_scan<true>(m, c, s.path[i], lane, si[0], si[1], qv, s.vnew + i * 10, r);
+    agent_scan_any<true>(m, c, s.path[i], lane, si[0], si[1], qv, s.vnew + i * 10, s.cp + i * 3, r);
     int path = s.path[i];
     bool entry = false, exit_ = false;
     if (!m.is_loop[path]) {  // world_state_rt_sim.py:413-424
@@ -491,64 +638,14 @@ __global__ void sigmaenv_reset_scatter_kernel(DevBufs g, int N, int n, const int
   if (full_env) g.reset_full[b] = 1;
 }
 
-// rejection sampler of world_state_rt_sim.py:215-311 (non-testing mode) with a counter-based RNG; one thread per done env
-__global__ void sigmaenv_reset_sample_kernel(sigmaenv_config_t c, DevMap m, DevBufs g, uint64_t seed, uint64_t counter, int path_first, int path_count) {
-  int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= c.n_envs || !g.done[b]) return;
-  const int N = c.n_agents;
-  float min_d = sqrtf((float)((double)c.length * (double)c.length + (double)c.width * (double)c.width)) * 1.5f;  // road_traffic.py:679-684
-  float min_d_sq = min_d * min_d;
-  for (int i = 0; i < N; ++i) {
-    size_t bi = (size_t)b * N + i;
-    float* s = g.state + bi * 8;
-    int path = path_first, pt = 3;
-    float px = 0.f, py = 0.f;
-    for (int t = 0; t < AUTO_RESET_MAX_TRIES; ++t) {
-      path = path_first + (int)(rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, 2u * t) % (uint32_t)path_count);
-      int n = m.n_center[path];
-      int end = n / 2;
-      if (end < 4) end = 4;
-      pt = 3 + (int)(rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, 2u * t + 1u) % (uint32_t)(end - 3));
-      px = m.center[((size_t)path * m.P + pt) * 2];
-      py = m.center[((size_t)path * m.P + pt) * 2 + 1];
-      bool ok = true;
-      for (int j = 0; j < i; ++j) {
-        const float* sj = g.state + ((size_t)b * N + j) * 8;
-        float dx = px - sj[0], dy = py - sj[1];
-        float d2 = dx * dx + dy * dy;
-        if (!(d2 >= min_d_sq)) ok = false;
-      }
-      if (ok) break;
-    }
-    float u = (float)(rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, 1000u) >> 8) * (1.0f / 16777216.0f);
-    int yi = pt < m.yaw_stride ? pt : m.yaw_stride - 1;
-    float rot = m.yaw[(size_t)path * m.yaw_stride + yi];
-    float speed = u * c.max_speed;
-    s[0] = px; s[1] = py; s[2] = rot; s[3] = speed; s[4] = 0.0f; s[7] = 0.0f;
-    s[5] = speed * cr_cos(0.0f + rot);
-    s[6] = speed * cr_sin(0.0f + rot);
-    g.path[bi * 4 + 0] = path; g.path[bi * 4 + 1] = 0; g.path[bi * 4 + 2] = path - path_first; g.path[bi * 4 + 3] = pt;
-  }
-  g.reset_mask[b] = (N >= 64) ? ~0ull : ((1ull << N) - 1ull);
-  g.reset_full[b] = 1;
-}
-
 // derived state of every marked agent (reset_init_distances_and_short_term_ref_path, world_state_rt.py:422-529) and the
-// per-env tail (road_traffic.py:902-923); with_obs: also a fresh observation of the env.  grid = n_envs
-__global__ void __launch_bounds__(1024) sigmaenv_reset_derive_kernel(sigmaenv_config_t c, DevMap m, DevBufs g, int with_obs) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int b = blockIdx.x;
-  const unsigned long long mask = g.reset_mask[b];
-  if (mask == 0ull) return;  // uniform per block
+// per-env tail (road_traffic.py:902-923); with_obs: also a fresh observation of the env.  Expects s.st / s.path / s.vnew of
+// the env in LDS.  All threads of the block participate.
+__device__ inline void reset_derive_body(const sigmaenv_config_t& c, const DevMap& m, const DevBufs& g, const Smem& s, int b, unsigned long long mask,
+                                         int full, int with_obs) {
   const int N = c.n_agents, K = c.n_nearing, D = 4 + 2 * NS + 11 * K;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
-  const int full = g.reset_full[b];
-  Smem s(smem_raw, N, K, D);
   const size_t bN = (size_t)b * N;
-  for (int k = tid; k < N * 8; k += blockDim.x) s.st[k] = g.state[bN * 8 + k];
-  for (int k = tid; k < N * 10; k += blockDim.x) s.vnew[k] = g.vertices[bN * 10 + k];
-  for (int k = tid; k < N; k += blockDim.x) s.path[k] = g.path[(bN + k) * 4];
-  __syncthreads();
   for (int i = tid; i < N; i += blockDim.x) {
     if ((mask >> i) & 1ull) {
       float v[10];
@@ -561,7 +658,7 @@ __global__ void __launch_bounds__(1024) sigmaenv_reset_derive_kernel(sigmaenv_co
   for (int i = wave; i < N; i += n_waves) {
     if (!((mask >> i) & 1ull)) continue;
     AgentScan r;
-    agent_scan<false>(m, c, s.path[i], lane, s.st[i * 8], s.st[i * 8 + 1], s.vnew + i * 10, s.vnew + i * 10, r);
+    agent_scan_any<false>(m, c, s.path[i], lane, s.st[i * 8], s.st[i * 8 + 1], s.vnew + i * 10, s.vnew + i * 10, s.cp + i * 3, r);
     if (lane == 0) {
       const size_t bi = bN + i;
       float mb = INFINITY;
@@ -605,6 +702,83 @@ __global__ void __launch_bounds__(1024) sigmaenv_reset_derive_kernel(sigmaenv_co
     load_env_for_observation(s, g, b, N);
     observe_env(c, s, g, b, N, K, D);
   }
+}
+
+// host-driven resets: grid = n_envs, only blocks whose env has marked agents do work
+__global__ void __launch_bounds__(1024) sigmaenv_reset_derive_kernel(sigmaenv_config_t c, DevMap m, DevBufs g, int with_obs) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int b = blockIdx.x;
+  const unsigned long long mask = g.reset_mask[b];
+  if (mask == 0ull) return;  // uniform per block
+  const int N = c.n_agents, K = c.n_nearing, D = 4 + 2 * NS + 11 * K;
+  const int full = g.reset_full[b];
+  Smem s(smem_raw, N, K, D);
+  const size_t bN = (size_t)b * N;
+  for (int k = threadIdx.x; k < N * 8; k += blockDim.x) s.st[k] = g.state[bN * 8 + k];
+  for (int k = threadIdx.x; k < N * 10; k += blockDim.x) s.vnew[k] = g.vertices[bN * 10 + k];
+  for (int k = threadIdx.x; k < N; k += blockDim.x) {
+    s.path[k] = g.path[(bN + k) * 4];
+    int pt = g.path[(bN + k) * 4 + 3];  // the agent was placed at (or near) this centre-line point: guess for the pruned scan
+    s.cp[k * 3 + 0] = pt; s.cp[k * 3 + 1] = pt; s.cp[k * 3 + 2] = pt;
+  }
+  __syncthreads();
+  reset_derive_body(c, m, g, s, b, mask, full, with_obs);
+}
+
+// Device-side reset of finished envs (grid = n_envs, blocks of unfinished envs exit at once).  Wavefront 0 runs the rejection
+// sampler of world_state_rt_sim.py:215-311 (non-testing mode) from a counter-based RNG: the 64 lanes evaluate tries 0..63 of one
+// agent at once and the FIRST feasible try wins, which is exactly the sequential loop's result for the same draws (bounded to
+// 64 tries; the reference loops without bound).  Then the deterministic reset as in sigmaenv_reset(full_env=1).
+__global__ void __launch_bounds__(1024) sigmaenv_auto_reset_kernel(sigmaenv_config_t c, DevMap m, DevBufs g, uint64_t seed, uint64_t counter,
+                                                                   int path_first, int path_count) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int b = blockIdx.x;
+  if (!g.done[b]) return;  // uniform per block
+  const int N = c.n_agents, K = c.n_nearing, D = 4 + 2 * NS + 11 * K;
+  Smem s(smem_raw, N, K, D);
+  const size_t bN = (size_t)b * N;
+  const int tid = threadIdx.x;
+  if (tid < 64) {
+    const int t = tid;  // try index of this lane
+    const float min_d = sqrtf((float)((double)c.length * (double)c.length + (double)c.width * (double)c.width)) * 1.5f;  // road_traffic.py:679-684
+    const float min_d_sq = min_d * min_d;
+    for (int i = 0; i < N; ++i) {
+      int path = path_first + (int)(rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, 2u * t) % (uint32_t)path_count);
+      int n = m.n_center[path];
+      int end = n / 2;
+      if (end < 4) end = 4;
+      int pt = 3 + (int)(rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, 2u * t + 1u) % (uint32_t)(end - 3));
+      float px = m.center[((size_t)path * m.P + pt) * 2];
+      float py = m.center[((size_t)path * m.P + pt) * 2 + 1];
+      bool ok = true;
+      for (int j = 0; j < i; ++j) {  // accepted agents 0..i-1 are in LDS (written by the winning lane below)
+        float dx = px - s.st[j * 8], dy = py - s.st[j * 8 + 1];
+        float d2 = dx * dx + dy * dy;
+        if (!(d2 >= min_d_sq)) ok = false;
+      }
+      unsigned long long feas = __ballot(ok);
+      int win = feas ? (__ffsll((long long)feas) - 1) : (AUTO_RESET_MAX_TRIES - 1);
+      if (t == win) {
+        float u = (float)(rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, 1000u) >> 8) * (1.0f / 16777216.0f);
+        int yi = pt < m.yaw_stride ? pt : m.yaw_stride - 1;
+        float rot = m.yaw[(size_t)path * m.yaw_stride + yi];
+        float speed = u * c.max_speed;
+        float st[8] = {px, py, rot, speed, 0.0f, speed * cr_cos(0.0f + rot), speed * cr_sin(0.0f + rot), 0.0f};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s.st[i * 8 + k] = st[k]; g.state[(bN + i) * 8 + k] = st[k]; }
+        s.path[i] = path;
+        s.cp[i * 3 + 0] = pt; s.cp[i * 3 + 1] = pt; s.cp[i * 3 + 2] = pt;
+        g.path[(bN + i) * 4 + 0] = path; g.path[(bN + i) * 4 + 1] = 0; g.path[(bN + i) * 4 + 2] = path - path_first; g.path[(bN + i) * 4 + 3] = pt;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  const unsigned long long mask = (N >= 64) ? ~0ull : ((1ull << N) - 1ull);
+  reset_derive_body(c, m, g, s, b, mask, 1, 1);
 }
 
 // =====================================================================================================================
@@ -753,7 +927,31 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
   H2D(d_y, map->yaw, (size_t)np * S * 4);
   H2D(d_nc, map->n_center, (size_t)np * 4); H2D(d_nl, map->n_left, (size_t)np * 4); H2D(d_nr, map->n_right, (size_t)np * 4);
   H2D(d_loop, map->is_loop, (size_t)np);
-  h->map = DevMap{d_c, d_l, d_r, d_y, d_nc, d_nl, d_nr, d_loop, P, np, S};
+  // pruning table: bounding boxes of runs of SIGMAENV_CHUNK consecutive real segments (points 8c .. min(8c+8, n-1))
+  int nch = (P - 1 + SIGMAENV_CHUNK - 1) / SIGMAENV_CHUNK;
+  bool prune = nch <= 32;  // the candidate masks are 32-bit; longer polylines fall back to the full scan
+  if (const char* e = getenv("SIGMAENV_PRUNE")) prune = prune && atoi(e) != 0;
+  float4* d_box = nullptr;
+  std::vector<float4> hb;  // must outlive the asynchronous upload below
+  if (prune) {
+    hb.assign((size_t)np * 3 * nch, make_float4(1e30f, 1e30f, -1e30f, -1e30f));
+    for (int p = 0; p < np; ++p) {
+      const float* polys[3] = {hc.data() + (size_t)p * P * 2, hl.data() + (size_t)p * P * 2, hr.data() + (size_t)p * P * 2};
+      const int cnt[3] = {map->n_center[p], map->n_left[p], map->n_right[p]};
+      for (int q = 0; q < 3; ++q) {
+        for (int k = 0; k + 1 < cnt[q]; ++k) {
+          float4& bx = hb[((size_t)p * 3 + q) * nch + k / SIGMAENV_CHUNK];
+          for (int e2 = 0; e2 < 2; ++e2) {
+            float x = polys[q][2 * (k + e2)], y = polys[q][2 * (k + e2) + 1];
+            bx.x = x < bx.x ? x : bx.x; bx.y = y < bx.y ? y : bx.y; bx.z = x > bx.z ? x : bx.z; bx.w = y > bx.w ? y : bx.w;
+          }
+        }
+      }
+    }
+    ALLOC(d_box, hb.size() * sizeof(float4));
+    H2D(d_box, hb.data(), hb.size() * sizeof(float4));
+  }
+  h->map = DevMap{d_c, d_l, d_r, d_y, d_nc, d_nl, d_nr, d_loop, P, np, S, d_box, prune ? nch : 0};
   const size_t BN = (size_t)B * N;
   DevBufs& g = h->buf;
   struct Spec { int id; void** p; size_t bytes; };
@@ -791,6 +989,7 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem_bytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_observe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem_bytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_reset_derive_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem_bytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_auto_reset_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem_bytes);
   }
   if (hipStreamSynchronize(h->stream) != hipSuccess) { sigmaenv_destroy(h); return SIGMAENV_EHIP; }
   *out = h;
@@ -873,10 +1072,10 @@ extern "C" int sigmaenv_observe(sigmaenv_t* h) {
 
 extern "C" int sigmaenv_auto_reset(sigmaenv_t* h, uint64_t seed, uint64_t counter, int32_t path_first, int32_t path_count) {
   if (!h || path_first < 0 || path_count < 1 || path_first + path_count > h->n_paths) return SIGMAENV_EINVAL;
-  hipLaunchKernelGGL(sigmaenv_reset_sample_kernel, dim3((h->B + 63) / 64), dim3(64), 0, h->stream, h->cfg, h->map, h->buf, seed, counter,
+  hipLaunchKernelGGL(sigmaenv_auto_reset_kernel, dim3(h->B), dim3(h->block), h->smem_bytes, h->stream, h->cfg, h->map, h->buf, seed, counter,
                      (int)path_first, (int)path_count);
   HIPCHK(h, hipGetLastError());
-  return launch_derive(h, 1);
+  return SIGMAENV_OK;
 }
 
 extern "C" int sigmaenv_get(sigmaenv_t* h, sigmaenv_buf_t which, void** dev_ptr, size_t* bytes) {

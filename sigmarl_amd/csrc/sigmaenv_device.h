@@ -30,7 +30,11 @@ struct DevMap {
   const int32_t* n_right;
   const uint8_t* is_loop;
   int32_t P, n_paths, yaw_stride;
+  // pruning table: axis-aligned boxes of runs of CHUNK consecutive real segments, [n_paths][3 (centre,left,right)][nch]
+  const float4* chunk_box;  // (min_x, min_y, max_x, max_y)
+  int32_t nch;              // boxes per polyline (stride); 0 disables pruning (brute-force scan)
 };
+#define SIGMAENV_CHUNK 8
 
 struct DevBufs {
   float *state, *prev_pos, *vertices, *short_term, *dist_ref, *dist_left, *dist_right, *dist_bound, *dist_agents;
