@@ -120,13 +120,11 @@ def main():
     gather = RolloutGather(B, N, env.D, device) if (world > 1 and not args.no_gather) else None
     pf, pc = env.map.list_first[0], env.map.list_count[0]
     counter = [1]
-    done_count = torch.zeros((), dtype=torch.int64, device=device)
 
     def one_step(t):
         env.step(acts[t % n_act])
         if gather is not None:
             gather.submit(env.obs, env.reward, env.done)
-        done_count.add_(env.done.sum())
         if not args.no_reset:
             env.auto_reset(seed=seed, counter=counter[0], path_first=pf, path_count=pc)
             counter[0] += 1
@@ -136,7 +134,7 @@ def main():
     if gather is not None:
         gather.wait_all()
     env.step_time_ms()  # arms the HIP-event bracketing of the step launches (on the env's stream)
-    done_count.zero_()
+    resets_before = int(env.buffer(capi.BUF_TIMER)[:, 3].sum().item())  # episodes_reset counters
 
     if world > 1:
         dist.barrier()
@@ -156,7 +154,7 @@ def main():
     elapsed = float(el.item())
 
     kernel_ms, n_launch = env.step_time_ms()
-    dones = int(done_count.item())
+    dones = int(env.buffer(capi.BUF_TIMER)[:, 3].sum().item()) - resets_before
     total_agent_steps = N * B * world * args.steps
     value = total_agent_steps / elapsed
     bytes_per = algorithmic_bytes_per_agent_step(N)

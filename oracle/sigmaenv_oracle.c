@@ -577,17 +577,17 @@ static void reset_env_tail(oracle_t* o, int b, int full_env) { /* road_traffic.p
   if (full_env) { o->timer[b * 4] = 0; o->timer[b * 4 + 3] += 1; o->done[b] = 0; }
 }
 
-/* counter-based RNG shared (as a specification) with the HIP kernel: splitmix64 finaliser over (seed, counter, env, agent, draw) */
+/* counter-based RNG shared (as a specification) with the HIP kernel: 32-bit multiplicative mix + murmur3 finalisers over (seed, counter, env, agent, draw) */
 static inline uint32_t rng_u32(uint64_t seed, uint64_t counter, uint32_t env, uint32_t agent, uint32_t draw) {
-  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (counter + 1);
-  z ^= ((uint64_t)env << 32) | ((uint64_t)agent << 16) | (uint64_t)draw;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (uint32_t)(z >> 32);
+  uint32_t h = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9E3779B9u);
+  h ^= ((uint32_t)counter + 0x7F4A7C15u) * 0x85EBCA6Bu;
+  h ^= (env + 0x165667B1u) * 0xC2B2AE35u;
+  h ^= (agent + 0x27D4EB2Fu) * 0x9E3779B1u;
+  h ^= (draw + 0x61C88647u) * 0x85EBCA77u;
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;   /* murmur3 fmix32, twice */
+  h += 0x9E3779B9u;
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
 }
 #define AUTO_RESET_MAX_TRIES 64
 
@@ -603,11 +603,11 @@ static void auto_reset_env(oracle_t* o, int b, uint64_t seed, uint64_t counter, 
     float* s = o->state + bi * 8;
     int path = path_first, pt = 3;
     for (int t = 0; t < AUTO_RESET_MAX_TRIES; ++t) {
-      path = path_first + (int)(rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, 2u * t) % (uint32_t)path_count);
+      path = path_first + (int)(((uint64_t)rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, 2u * t) * (uint64_t)(uint32_t)path_count) >> 32);
       int n = o->n_center[path];
       int end = n / 2;
       if (end < 4) end = 4;
-      pt = 3 + (int)(rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, 2u * t + 1u) % (uint32_t)(end - 3));
+      pt = 3 + (int)(((uint64_t)rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, 2u * t + 1u) * (uint64_t)(uint32_t)(end - 3)) >> 32);
       float px = o->center[((size_t)path * o->P + pt) * 2], py = o->center[((size_t)path * o->P + pt) * 2 + 1];
       s[0] = px; s[1] = py;
       int ok = 1;

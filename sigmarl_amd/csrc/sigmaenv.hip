@@ -1,13 +1,13 @@
 // sigmaenv.hip -- fused vectorized multi-agent CAV environment step for MI355X (gfx950) + its C-ABI (include/sigmaenv.h).
 //
-// One workgroup = one environment.  Phases of the fused step kernel (one launch per step, all agents x envs):
-//   A  per agent      : action clamp + kinematic bicycle Euler step, new rectangle vertices            (K1, K2)
-//   B1 per agent pair : mutual distances (c2c / mtv) and rectangle-rectangle collision masks          (K4, K5)
-//   B2 wave per agent : 11 point->polyline queries and 2 rectangle->boundary collision scans,
-//                       64 lanes across polyline segments, wavefront shuffles for (min, first argmin)   (K3, K5)
-//   C  per agent      : reward terms, short-term reference path, counters                               (K7, K6)
-//   D  per obs item   : top-k nearest agents, ego-view transforms, observation vector in LDS            (K8)
-//   E  per env        : done flag and per-agent reset requests, coalesced write-out                     (K9)
+// One workgroup = one WAVEFRONT'S WORTH OF AGENTS: G = floor(64 / N) environments (G*N <= 64 "slots").  That way the
+// per-agent phases fill a whole 64-lane wavefront instead of N lanes.  Phases of the fused step kernel (one launch per step):
+//   A  lane per agent : action clamp + kinematic bicycle Euler step, new rectangle vertices             (K1, K2)
+//   B1 lane per pair  : mutual distances (c2c / mtv) and rectangle-rectangle collision masks            (K4, K5)
+//   B2 wave per agent : 11 point->polyline queries and 2 rectangle->boundary collision scans: lanes across the polyline
+//                       segments that survive bounding-box pruning, wavefront shuffles for (min, first argmin)  (K3, K5)
+//   C  lane per agent : reward terms, short-term reference path; per-env done / counters by wavefront ballots   (K7, K6, K9)
+//   D  lane per item  : top-k nearest agents, ego-view transforms (uniform passes), observation rows staged in LDS  (K8)
 // Per-env agent poses / vertices / distance rows live in LDS between the phases; HBM sees each state word once in, once out.
 // MFMA is unused on purpose: there is no dense contraction in this path.
 //
@@ -30,35 +30,50 @@ __device__ __constant__ uint32_t W_REF_BITS[3] = {0x3F0E38E3u, 0x3EAAAAABu, 0x3D
 #define AUTO_RESET_MAX_TRIES 64
 
 // ---------------------------------------------------------------------------------------------------------------------
-// LDS carve-up for one environment
+// LDS carve-up for one workgroup: S = G*N agent slots (slot = env_local * N + agent)
 // ---------------------------------------------------------------------------------------------------------------------
 struct Smem {
-  float *st, *vold, *vnew, *shrt, *dref, *dleft, *dright, *dbound, *dist, *obs;
-  int *path, *cp, *near, *flags;
+  float *st, *vold, *vnew, *shrt, *dref, *dleft, *dright, *dbound, *dist, *obs, *thr;
+  int *path, *cp, *near, *flags, *npts;
   uint8_t* col;
-  __device__ Smem(char* base, int N, int K, int D) {
+  __device__ Smem(char* base, int S, int N, int K, int D) {
     float* f = reinterpret_cast<float*>(base);
-    st = f; f += N * 8;
-    vold = f; f += N * 10;
-    vnew = f; f += N * 10;
-    shrt = f; f += N * NS * 2;
-    dref = f; f += N;
-    dleft = f; f += N * 5;
-    dright = f; f += N * 5;
-    dbound = f; f += N;
-    dist = f; f += N * N;
-    obs = f; f += N * D;
+    st = f; f += S * 8;
+    vold = f; f += S * 10;
+    vnew = f; f += S * 10;
+    shrt = f; f += S * NS * 2;
+    dref = f; f += S;
+    dleft = f; f += S * 5;
+    dright = f; f += S * 5;
+    dbound = f; f += S;
+    dist = f; f += S * N;
+    obs = f; f += S * D;
+    thr = f; f += S * 3;   // pruning thresholds of the centre / left / right scan
     int* i = reinterpret_cast<int*>(f);
-    path = i; i += N;
-    cp = i; i += N * 3;
-    near = i; i += N * (K > 0 ? K : 1);
-    flags = i; i += N * 4;
+    path = i; i += S;
+    cp = i; i += S * 3;
+    near = i; i += S * (K > 0 ? K : 1);
+    flags = i; i += S * 4;
+    npts = i; i += S * 3;  // point counts of the agent's centre line / left / right boundary
     col = reinterpret_cast<uint8_t*>(i);
   }
-  static size_t bytes(int N, int K, int D) {
-    size_t f = (size_t)N * 8 + N * 10 * 2 + N * NS * 2 + N + N * 5 * 2 + N + (size_t)N * N + (size_t)N * D;
-    size_t i = (size_t)N + N * 3 + N * (K > 0 ? K : 1) + N * 4;
-    return (f + i) * 4 + (size_t)N * N + 16;
+  __host__ __device__ static size_t bytes(int S, int N, int K, int D) {
+    size_t f = (size_t)S * 8 + S * 10 * 2 + S * NS * 2 + S + S * 5 * 2 + S + (size_t)S * N + (size_t)S * D + S * 3;
+    size_t i = (size_t)S + S * 3 + S * (K > 0 ? K : 1) + S * 4 + S * 3;
+    return (f + i) * 4 + (size_t)S * N + 16;
+  }
+};
+
+// what a workgroup covers
+struct Tile {
+  int env0, nenv, slots, N, K, D;
+  size_t a0;  // global agent index of slot 0 (= env0 * N)
+  __device__ Tile(const sigmaenv_config_t& c, int G) {
+    N = c.n_agents; K = c.n_nearing; D = 4 + 2 * NS + 11 * K;
+    env0 = blockIdx.x * G;
+    nenv = min(G, c.n_envs - env0);
+    slots = nenv * N;
+    a0 = (size_t)env0 * N;
   }
 };
 
@@ -74,13 +89,14 @@ struct AgentScan {
   bool hit;
 };
 
+// full scan of one boundary (fallback when the polyline is too long for the 32-bit candidate masks, and A/B baseline)
 template <bool COLLIDE>
 __device__ __forceinline__ void boundary_scan(const float* __restrict__ poly, int n, int lane, float cgx, float cgy, const float* qv,
                                               const Edge* e, float d_out[5], int& cp_out, bool& hit) {
-  float bd[5];
+  float bd0 = INFINITY, bs[4];
   int bk = 0;
 #pragma unroll
-  for (int q = 0; q < 5; ++q) bd[q] = INFINITY;
+  for (int q = 0; q < 4; ++q) bs[q] = INFINITY;
   bool h = false;
   const float2* p2 = reinterpret_cast<const float2*>(poly);
   for (int k = lane; k + 1 < n; k += 64) {
@@ -88,38 +104,35 @@ __device__ __forceinline__ void boundary_scan(const float* __restrict__ poly, in
     float lx = b.x - a.x, ly = b.y - a.y;
     float len2 = lx * lx + ly * ly;
     float d0 = point_segment(cgx, cgy, a.x, a.y, lx, ly, len2);
-    if (d0 < bd[0]) { bd[0] = d0; bk = k; }
+    if (d0 < bd0) { bd0 = d0; bk = k; }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float d = point_segment(qv[2 * q], qv[2 * q + 1], a.x, a.y, lx, ly, len2);
-      bd[q + 1] = fminf(bd[q + 1], d);
-    }
+    for (int q = 0; q < 4; ++q) bs[q] = fminf(bs[q], point_segment_sq(qv[2 * q], qv[2 * q + 1], a.x, a.y, lx, ly, len2));
     if (COLLIDE) {
       float S2 = lx * a.y - ly * a.x;
 #pragma unroll
       for (int i = 0; i < 4; ++i) h |= edge_hits_segment(e[i], a.x, a.y, b.x, b.y, lx, ly, S2);
     }
   }
-  wave_argmin(bd[0], bk);
+  wave_argmin(bd0, bk);
 #pragma unroll
-  for (int q = 1; q < 5; ++q) {
+  for (int q = 0; q < 4; ++q) {
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) bd[q] = fminf(bd[q], __shfl_xor(bd[q], off, 64));
+    for (int off = 32; off >= 1; off >>= 1) bs[q] = fminf(bs[q], __shfl_xor(bs[q], off, 64));
   }
+  d_out[0] = bd0;
 #pragma unroll
-  for (int q = 0; q < 5; ++q) d_out[q] = bd[q];
+  for (int q = 0; q < 4; ++q) d_out[q + 1] = sqrtf(bs[q]);
   cp_out = bk + 1;
   if (COLLIDE) hit = hit || (__ballot(h) != 0ull);
 }
 
 template <bool COLLIDE>
-__device__ inline void agent_scan(const DevMap& m, const sigmaenv_config_t& c, int path, int lane, float cgx, float cgy, const float* qv,
-                                  const float* ev, AgentScan& r) {
+__device__ inline void agent_scan_full(const DevMap& m, const sigmaenv_config_t& c, int path, int lane, float cgx, float cgy, const float* qv,
+                                       const float* ev, AgentScan& r) {
   const float* ctr = m.center + (size_t)path * m.P * 2;
   const float* lb = m.left + (size_t)path * m.P * 2;
   const float* rb = m.right + (size_t)path * m.P * 2;
   int n = m.n_center[path], nl = m.n_left[path], nr = m.n_right[path];
-  // centre line: CG only
   {
     float bd = INFINITY;
     int bk = 0;
@@ -149,29 +162,14 @@ __device__ inline void agent_scan(const DevMap& m, const sigmaenv_config_t& c, i
 
 // ---------------------------------------------------------------------------------------------------------------------
 // B2, pruned: the same (min, first argmin) / collision results as the full scan, but only the polyline chunks that can matter
-// are evaluated.  Exactness argument (DESIGN.md "Pruned scan"): a run of 8 consecutive segments is skipped only if the
-// distance from the agent's centre to the run's bounding box exceeds T, where T bounds (with a 1e-4 m margin, >> fp32 error)
+// are evaluated.  Exactness argument (DESIGN.md "Pruned scan"): a run of SIGMAENV_CHUNK consecutive segments is skipped only
+// if the distance from the agent's centre to the run's bounding box exceeds T, where T bounds (with a 1e-4 m margin, >> fp32
+// error)
 //   * the distance of every query point to the segment that was closest last step (an upper bound of its minimum), and
 //   * the rectangle's circumradius (a segment farther than that cannot intersect an edge).
 // So every segment whose computed distance can equal or beat the running minimum, and every segment that can hit the
 // rectangle, is still evaluated with the very same arithmetic; ties still resolve to the lowest index.
-// Lanes 0-31 scan the left boundary, lanes 32-63 the right one; the centre line uses all 64 lanes.
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t chunk_mask(const float4* __restrict__ box, int nch, int lane, float px, float py, float T) {
-  bool cand = false;
-  if (lane < nch) {
-    float4 b = box[lane];
-    float dx = fmaxf(fmaxf(b.x - px, px - b.z), 0.0f);
-    float dy = fmaxf(fmaxf(b.y - py, py - b.w), 0.0f);
-    float lb = sqrtf(dx * dx + dy * dy);
-    cand = !(lb > T);  // a NaN threshold keeps every chunk
-  }
-  return (uint32_t)__ballot(cand);
-}
-__device__ __forceinline__ int nth_set_bit(uint32_t m, int c) {
-  for (int t = 0; t < c; ++t) m &= (m - 1u);
-  return m ? (__ffs((int)m) - 1) : -1;
-}
 __device__ __forceinline__ float guess_distance(const float* __restrict__ poly, int n, int cp_guess, float px, float py) {
   int k = cp_guess - 1;
   k = k < 0 ? 0 : (k > n - 2 ? n - 2 : k);
@@ -181,128 +179,159 @@ __device__ __forceinline__ float guess_distance(const float* __restrict__ poly, 
   return point_segment(px, py, a.x, a.y, lx, ly, lx * lx + ly * ly);
 }
 
-template <bool COLLIDE>
-__device__ inline void agent_scan_pruned(const DevMap& m, const sigmaenv_config_t& c, int path, int lane, float cgx, float cgy, const float* qv,
-                                         const float* ev, const int* cp_guess, AgentScan& r) {
-  const float* ctr = m.center + (size_t)path * m.P * 2;
-  const float* lb = m.left + (size_t)path * m.P * 2;
-  const float* rb = m.right + (size_t)path * m.P * 2;
-  const int n = m.n_center[path], nl = m.n_left[path], nr = m.n_right[path];
-  const float4* box = m.chunk_box + (size_t)path * 3 * m.nch;
-  const float MARGIN = 1e-4f;
-  // radii of the query points / rectangle vertices around the centre of gravity
-  float Rq = 0.0f, Rv = 0.0f;
+// exact radius of the corner-query points around the centre (used for agent 0, whose query points are last step's vertices)
+__device__ __forceinline__ float query_radius(const float* qv, float cgx, float cgy) {
+  float R = 0.0f;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     float ax = qv[2 * q] - cgx, ay = qv[2 * q + 1] - cgy;
-    Rq = fmaxf(Rq, sqrtf(ax * ax + ay * ay));
-    float bx = ev[2 * q] - cgx, by = ev[2 * q + 1] - cgy;
-    Rv = fmaxf(Rv, sqrtf(bx * bx + by * by));
+    R = fmaxf(R, sqrtf(ax * ax + ay * ay));
   }
-  // ---- centre line (CG only), 64 lanes over the candidate segments
+  return R * 1.000001f + 1e-6f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// B2, pruned, TWO agents per wavefront (the production path).  Lane groups of 16: [A-left | A-right | B-left | B-right] for the
+// boundary pass, half-waves [A | B] for the centre-line pass.  Chunks are runs of SIGMAENV_CHUNK consecutive segments; with the
+// CPM map ~3 chunks (12-16 segments) survive per boundary, so one 16-lane pass usually covers a boundary.
+// Results go straight to LDS (dref, dleft, dright, cp, flags[0]).
+// `stale_first`: in the step the first agent of every env queries its corners at last step's vertices (see step kernel).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int nth_set_bit64(unsigned long long m, int c) {
+  for (int t = 0; t < c; ++t) m &= (m - 1ull);
+  return m ? (__ffsll((long long)m) - 1) : -1;
+}
+__device__ __forceinline__ bool chunk_hit(const float4* __restrict__ box, int idx, int nch, float px, float py, float T) {
+  if (idx >= nch) return false;
+  float4 b = box[idx];
+  float dx = fmaxf(fmaxf(b.x - px, px - b.z), 0.0f);
+  float dy = fmaxf(fmaxf(b.y - py, py - b.w), 0.0f);
+  return !((dx * dx + dy * dy) > T * T);  // a NaN threshold keeps every chunk
+}
+
+// per-agent inputs of the pruned scan, computed by ONE lane per agent (all agents of the tile in parallel, so the dependent
+// global loads overlap): point counts and the pruning thresholds T (see the exactness argument above).
+template <bool COLLIDE>
+__device__ inline void scan_prepare(const DevMap& m, const Smem& s, int sl, bool stale) {
+  const int path = s.path[sl];
+  const float cgx = s.st[sl * 8], cgy = s.st[sl * 8 + 1];
+  const int n = m.n_center[path], nl = m.n_left[path], nr = m.n_right[path];
+  s.npts[sl * 3 + 0] = n; s.npts[sl * 3 + 1] = nl; s.npts[sl * 3 + 2] = nr;
+  const float MARGIN = 1e-4f;
+  const float Rv = m.rect_radius;
+  const float Rq = stale ? query_radius(s.vold + sl * 10, cgx, cgy) : Rv;
+  const float floor_b = COLLIDE ? Rv : 0.0f;
+  s.thr[sl * 3 + 0] = guess_distance(m.center + (size_t)path * m.P * 2, n, s.cp[sl * 3 + 0], cgx, cgy) + MARGIN;
+  s.thr[sl * 3 + 1] = fmaxf(guess_distance(m.left + (size_t)path * m.P * 2, nl, s.cp[sl * 3 + 1], cgx, cgy) + 2.0f * Rq, floor_b) + MARGIN;
+  s.thr[sl * 3 + 2] = fmaxf(guess_distance(m.right + (size_t)path * m.P * 2, nr, s.cp[sl * 3 + 2], cgx, cgy) + 2.0f * Rq, floor_b) + MARGIN;
+}
+
+template <bool COLLIDE>
+__device__ inline void pair_scan(const DevMap& m, const sigmaenv_config_t& c, const Smem& s, int slotA, int valid_mask, int lane, bool stale_first, int N) {
+  // valid_mask: bit 0 = scan agent slotA, bit 1 = scan agent slotA + 1 (an unselected half mirrors the selected one, results dropped)
+  const int grp = lane >> 4, ag = grp >> 1, side = grp & 1, gl = lane & 15, hl = lane & 31;
+  const bool valid = (valid_mask >> ag) & 1;
+  const int sl = slotA + (valid ? ag : (ag ^ 1));
+  const int path = s.path[sl];
+  const float cgx = s.st[sl * 8], cgy = s.st[sl * 8 + 1];
+  const bool stale = stale_first && (sl % N == 0);
+  const float* qv = stale ? (s.vold + sl * 10) : (s.vnew + sl * 10);
+  const float* ev = s.vnew + sl * 10;
+  const float2* ctr2 = reinterpret_cast<const float2*>(m.center + (size_t)path * m.P * 2);
+  const float2* pol2 = reinterpret_cast<const float2*>((side ? m.right : m.left) + (size_t)path * m.P * 2);
+  const int n = s.npts[sl * 3], np = s.npts[sl * 3 + 1 + side];
+  const float Tc = s.thr[sl * 3], Tb = s.thr[sl * 3 + 1 + side];
+  // ---- candidate chunk masks: each 16-lane group tests its own boundary, each half-wave its own centre line
+  unsigned long long mb = 0ull, mc = 0ull;
   {
-    float T = guess_distance(ctr, n, cp_guess[0], cgx, cgy) + MARGIN;
-    int nch = (n - 1 + SIGMAENV_CHUNK - 1) / SIGMAENV_CHUNK;
-    uint32_t mc = chunk_mask(box, nch, lane, cgx, cgy, T);
-    int cnt = __popc(mc) * SIGMAENV_CHUNK;
-    float bd = INFINITY;
-    int bk = 0;
-    const float2* p2 = reinterpret_cast<const float2*>(ctr);
-    for (int base = 0; base < cnt; base += 64) {
-      int j = base + lane;
-      int ch = nth_set_bit(mc, j >> 3);
-      int k = ch * SIGMAENV_CHUNK + (j & 7);
-      if (ch >= 0 && k + 1 < n) {
-        float2 a = p2[k], b = p2[k + 1];
-        float lx = b.x - a.x, ly = b.y - a.y;
-        float d = point_segment(cgx, cgy, a.x, a.y, lx, ly, lx * lx + ly * ly);
-        if (d < bd || (d == bd && k < bk)) { bd = d; bk = k; }
-      }
+    const float4* box = m.chunk_box + (size_t)path * 3 * m.nch;
+    const int nchb = (np - 1 + SIGMAENV_CHUNK - 1) / SIGMAENV_CHUNK, nchc = (n - 1 + SIGMAENV_CHUNK - 1) / SIGMAENV_CHUNK;
+    const float4* bb = box + (1 + side) * m.nch;
+    for (int base = 0; base < m.nch; base += 16) {
+      unsigned long long bal = __ballot(chunk_hit(bb, base + gl, nchb, cgx, cgy, Tb));
+      mb |= ((bal >> (grp * 16)) & 0xFFFFull) << base;
     }
-    wave_argmin(bd, bk);
-    r.d_ref = bd;
-    r.cp_ref = bk + 1;
+    for (int base = 0; base < m.nch; base += 32) {
+      unsigned long long bal = __ballot(chunk_hit(box, base + hl, nchc, cgx, cgy, Tc));
+      mc |= ((bal >> (ag * 32)) & 0xFFFFFFFFull) << base;
+    }
   }
-  // ---- boundaries: half-wave per side
-  const int half = lane >> 5, hl = lane & 31;
-  const float* poly = half ? rb : lb;
-  const int np = half ? nr : nl;
-  float Tl = fmaxf(guess_distance(lb, nl, cp_guess[1], cgx, cgy) + 2.0f * Rq, COLLIDE ? Rv : 0.0f) + MARGIN;
-  float Tr = fmaxf(guess_distance(rb, nr, cp_guess[2], cgx, cgy) + 2.0f * Rq, COLLIDE ? Rv : 0.0f) + MARGIN;
-  uint32_t ml = chunk_mask(box + m.nch, (nl - 1 + SIGMAENV_CHUNK - 1) / SIGMAENV_CHUNK, lane, cgx, cgy, Tl);
-  uint32_t mr = chunk_mask(box + 2 * m.nch, (nr - 1 + SIGMAENV_CHUNK - 1) / SIGMAENV_CHUNK, lane, cgx, cgy, Tr);
-  const uint32_t mm = half ? mr : ml;
-  const int cnt_max = max(__popc(ml), __popc(mr)) * SIGMAENV_CHUNK;
   Edge e[4];
   if (COLLIDE) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) e[i] = make_edge(ev[2 * i], ev[2 * i + 1], ev[2 * i + 2], ev[2 * i + 3]);
   }
-  float bd[5];
-  int bk = 0;
-#pragma unroll
-  for (int q = 0; q < 5; ++q) bd[q] = INFINITY;
+  const float q0x = qv[0], q0y = qv[1], q1x = qv[2], q1y = qv[3], q2x = qv[4], q2y = qv[5], q3x = qv[6], q3y = qv[7];
+  const int cnt_c = __popcll(mc) * SIGMAENV_CHUNK, cnt_b = __popcll(mb) * SIGMAENV_CHUNK;
+  float cd = INFINITY, bd0 = INFINITY, bs0 = INFINITY, bs1 = INFINITY, bs2 = INFINITY, bs3 = INFINITY;
+  int ck = 0, bk = 0;
   bool h = false;
-  const float2* p2 = reinterpret_cast<const float2*>(poly);
-  for (int base = 0; base < cnt_max; base += 32) {
-    int j = base + hl;
-    int ch = nth_set_bit(mm, j >> 3);
-    int k = ch * SIGMAENV_CHUNK + (j & 7);
-    if (ch >= 0 && k + 1 < np) {
-      float2 a = p2[k], b = p2[k + 1];
-      float lx = b.x - a.x, ly = b.y - a.y;
+  // one loop for both polylines so that the centre-line and boundary segment loads of a pass are in flight together
+  for (int it = 0; __any(it * 32 < cnt_c || it * 16 < cnt_b); ++it) {
+    const int jc = it * 32 + hl, jb = it * 16 + gl;
+    const int chc = (jc < cnt_c) ? nth_set_bit64(mc, jc / SIGMAENV_CHUNK) : -1;
+    const int chb = (jb < cnt_b) ? nth_set_bit64(mb, jb / SIGMAENV_CHUNK) : -1;
+    const int kc = chc * SIGMAENV_CHUNK + (jc % SIGMAENV_CHUNK), kb = chb * SIGMAENV_CHUNK + (jb % SIGMAENV_CHUNK);
+    const bool do_c = chc >= 0 && kc + 1 < n, do_b = chb >= 0 && kb + 1 < np;
+    float2 ca = make_float2(0.f, 0.f), cb = ca, ba = ca, bb2 = ca;
+    if (do_c) { ca = ctr2[kc]; cb = ctr2[kc + 1]; }
+    if (do_b) { ba = pol2[kb]; bb2 = pol2[kb + 1]; }
+    if (do_c) {
+      float lx = cb.x - ca.x, ly = cb.y - ca.y;
+      float d = point_segment(cgx, cgy, ca.x, ca.y, lx, ly, lx * lx + ly * ly);
+      if (d < cd || (d == cd && kc < ck)) { cd = d; ck = kc; }
+    }
+    if (do_b) {
+      float lx = bb2.x - ba.x, ly = bb2.y - ba.y;
       float len2 = lx * lx + ly * ly;
-      float d0 = point_segment(cgx, cgy, a.x, a.y, lx, ly, len2);
-      if (d0 < bd[0] || (d0 == bd[0] && k < bk)) { bd[0] = d0; bk = k; }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) bd[q + 1] = fminf(bd[q + 1], point_segment(qv[2 * q], qv[2 * q + 1], a.x, a.y, lx, ly, len2));
+      float d0 = point_segment(cgx, cgy, ba.x, ba.y, lx, ly, len2);
+      if (d0 < bd0 || (d0 == bd0 && kb < bk)) { bd0 = d0; bk = kb; }
+      bs0 = fminf(bs0, point_segment_sq(q0x, q0y, ba.x, ba.y, lx, ly, len2));
+      bs1 = fminf(bs1, point_segment_sq(q1x, q1y, ba.x, ba.y, lx, ly, len2));
+      bs2 = fminf(bs2, point_segment_sq(q2x, q2y, ba.x, ba.y, lx, ly, len2));
+      bs3 = fminf(bs3, point_segment_sq(q3x, q3y, ba.x, ba.y, lx, ly, len2));
       if (COLLIDE) {
-        float S2 = lx * a.y - ly * a.x;
+        float S2 = lx * ba.y - ly * ba.x;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) h |= edge_hits_segment(e[i], a.x, a.y, b.x, b.y, lx, ly, S2);
+        for (int i = 0; i < 4; ++i) h |= edge_hits_segment(e[i], ba.x, ba.y, bb2.x, bb2.y, lx, ly, S2);
       }
     }
   }
-  // reductions inside each 32-lane half (xor offsets < 32 never cross the halves)
-#pragma unroll
-  for (int off = 16; off >= 1; off >>= 1) {
-    float od = __shfl_xor(bd[0], off, 64);
-    int ok = __shfl_xor(bk, off, 64);
-    if (od < bd[0] || (od == bd[0] && ok < bk)) { bd[0] = od; bk = ok; }
-#pragma unroll
-    for (int q = 1; q < 5; ++q) bd[q] = fminf(bd[q], __shfl_xor(bd[q], off, 64));
+  // ---- reductions: DPP inside the rows of 16 lanes; the centre line needs one cross-row step
+  row16_argmin(bd0, bk);
+  bs0 = row16_min(bs0); bs1 = row16_min(bs1); bs2 = row16_min(bs2); bs3 = row16_min(bs3);
+  row16_argmin(cd, ck);
+  {
+    float od = __shfl_xor(cd, 16, 64);
+    int ok = __shfl_xor(ck, 16, 64);
+    if (od < cd || (od == cd && ok < ck)) { cd = od; ck = ok; }
   }
-  float wh = (float)((double)c.width / 2.0);
-#pragma unroll
-  for (int q = 0; q < 5; ++q) {
-    r.dl[q] = __shfl(bd[q], 0, 64);
-    r.dr[q] = __shfl(bd[q], 32, 64);
+  const unsigned long long hb = COLLIDE ? __ballot(h && valid) : 0ull;
+  if (gl == 0 && valid) {
+    float wh = (float)((double)c.width / 2.0);
+    float* dst = (side ? s.dright : s.dleft) + sl * 5;
+    dst[0] = bd0 - wh;  // world_state_rt.py:608-610
+    dst[1] = sqrtf(bs0); dst[2] = sqrtf(bs1); dst[3] = sqrtf(bs2); dst[4] = sqrtf(bs3);
+    s.cp[sl * 3 + 1 + side] = bk + 1;
+    if (side == 0) {
+      s.dref[sl] = cd;
+      s.cp[sl * 3] = ck + 1;
+      if (COLLIDE) s.flags[sl * 4 + 0] = ((hb >> (ag * 32)) & 0xFFFFFFFFull) ? 1 : 0;
+    }
   }
-  r.cp_l = __shfl(bk, 0, 64) + 1;
-  r.cp_r = __shfl(bk, 32, 64) + 1;
-  r.dl[0] = r.dl[0] - wh;
-  r.dr[0] = r.dr[0] - wh;
-  r.hit = COLLIDE ? (__ballot(h) != 0ull) : false;
 }
 
-template <bool COLLIDE>
-__device__ __forceinline__ void agent_scan_any(const DevMap& m, const sigmaenv_config_t& c, int path, int lane, float cgx, float cgy,
-                                               const float* qv, const float* ev, const int* cp_guess, AgentScan& r) {
-  if (m.nch > 0) agent_scan_pruned<COLLIDE>(m, c, path, lane, cgx, cgy, qv, ev, cp_guess, r);
-  else agent_scan<COLLIDE>(m, c, path, lane, cgx, cgy, qv, ev, r);
-}
-
-// mutual distance of pair (i, j), i != j  (update_mutual_distances, world_state_rt_sim.py:360-373)
-__device__ __forceinline__ float pair_distance(const sigmaenv_config_t& c, const float* st, const float* verts, int i, int j) {
+// mutual distance of slots (si, sj) of one env, si != sj  (update_mutual_distances, world_state_rt_sim.py:360-373)
+__device__ __forceinline__ float pair_distance(const sigmaenv_config_t& c, const float* st, const float* verts, int si, int sj) {
   if (c.distance_type == SIGMAENV_DIST_C2C) {
-    float dx = st[i * 8] - st[j * 8], dy = st[i * 8 + 1] - st[j * 8 + 1];
+    float dx = st[si * 8] - st[sj * 8], dy = st[si * 8 + 1] - st[sj * 8 + 1];
     return sqrtf(dx * dx + dy * dy);
   }
-  int a = i < j ? i : j, b = i < j ? j : i;
+  int a = si < sj ? si : sj, b = si < sj ? sj : si;
   return mtv_pair(verts + a * 10, verts + b * 10);
 }
 
-// _apply_ttc_near_agent_penalty, road_traffic.py:1255-1332
+// _apply_ttc_near_agent_penalty, road_traffic.py:1255-1332; st points at the env's first slot
 __device__ inline float ttc_penalty(const sigmaenv_config_t& c, const float* st, int N, int i) {
   const float eps = 1e-6f;
   double d_safe = (double)c.threshold_near_other_agents_low;
@@ -335,7 +364,7 @@ __device__ inline float ttc_penalty(const sigmaenv_config_t& c, const float* st,
   return risk * c.penalty_near_other_agents;
 }
 
-// top-k nearest agents of agent i (observation_provider_rt.py:629-636): ascending, lowest index on ties
+// top-k nearest agents of one agent (observation_provider_rt.py:629-636): ascending, lowest index on ties
 __device__ inline void topk_nearest(const float* Drow, int N, int K, int* out) {
   unsigned long long taken = 0ull;
   for (int k = 0; k < K; ++k) {
@@ -350,281 +379,313 @@ __device__ inline void topk_nearest(const float* Drow, int N, int K, int* out) {
   }
 }
 
-// one observation work item (observation_provider_rt.py:345-588 latest slot, :594-925 default flags); writes into s.obs
-__device__ inline void obs_item(const sigmaenv_config_t& c, const Smem& s, int N, int K, int D, int i, int q) {
-  const float* si = s.st + i * 8;
-  float* ob = s.obs + i * D;
-  float n_pos = (float)((double)c.length * 10.0);
-  float n_v = c.max_speed;
-  float n_dl = (float)((double)c.lane_width * 3.0);
-  if (q == 0) {
-    float rr = angle_eliminate_two_pi(si[2] - si[2]);
-    ob[0] = (norm2(si[5], si[6]) * cr_cos(rr)) / n_v;
-    ob[1 + 2 * NS] = s.dref[i] / n_dl;
+// D: observations of all slots of the tile (observation_provider_rt.py:345-588 latest slot, :594-925 default flags).
+// Three branch-free passes so that every lane of a wavefront runs the same code:
+//   1. ego-view transforms (own short-term path points, observed neighbours' vertices): atan2 + cos + sin each
+//   2. relative velocities (self + observed neighbours): angle wrap + cos + sin each
+//   3. normalised distances
+// Rows are assembled in LDS and written out coalesced.  All threads of the block participate.
+__device__ inline void observe_tile(const sigmaenv_config_t& c, const Smem& s, const DevBufs& g, const Tile& t) {
+  const int N = t.N, K = t.K, D = t.D;
+  const float n_pos = (float)((double)c.length * 10.0);   // normalizers.pos, road_traffic.py:588-592
+  const float n_v = c.max_speed;                            // :596
+  const float n_dl = (float)((double)c.lane_width * 3.0);   // :599-601 (distance_lanelet also normalises the agent distances)
+  for (int sl = threadIdx.x; sl < t.slots; sl += blockDim.x) topk_nearest(s.dist + sl * N, N, K, s.near + sl * K);
+  __syncthreads();
+  const int T1 = NS + 4 * K;
+  for (int w = threadIdx.x; w < t.slots * T1; w += blockDim.x) {
+    int sl = w / T1, q = w - sl * T1;
+    int ebase = (sl / N) * N;
+    const float* si = s.st + sl * 8;
+    float tx, ty;
+    int pos;
+    if (q < NS) {  // [own] short-term reference path (:451-460, :893-897)
+      tx = s.shrt[sl * NS * 2 + 2 * q]; ty = s.shrt[sl * NS * 2 + 2 * q + 1];
+      pos = 1 + 2 * q;
+    } else {       // [others] vertices of the k-th nearest agent (:485-492, :731-737)
+      int k = (q - NS) >> 2, v = (q - NS) & 3;
+      int sj = ebase + s.near[sl * K + k];
+      tx = s.vnew[sj * 10 + 2 * v]; ty = s.vnew[sj * 10 + 2 * v + 1];
+      pos = 4 + 2 * NS + 11 * k + 2 * v;
+    }
+    float ox, oy;
+    ego_transform(si[0], si[1], si[2], tx, ty, ox, oy);
+    s.obs[sl * D + pos] = ox / n_pos;
+    s.obs[sl * D + pos + 1] = oy / n_pos;
+  }
+  const int T2 = K + 1;
+  for (int w = threadIdx.x; w < t.slots * T2; w += blockDim.x) {
+    int sl = w / T2, q = w - sl * T2;
+    int ebase = (sl / N) * N;
+    const float* si = s.st + sl * 8;
+    int sj = (q == 0) ? sl : (ebase + s.near[sl * K + (q - 1)]);
+    const float* sjp = s.st + sj * 8;
+    float rr = angle_eliminate_two_pi(sjp[2] - si[2]);    // :439
+    float va = norm2(sjp[5], sjp[6]);                      // :444
+    float vx = (va * cr_cos(rr)) / n_v, vy = (va * cr_sin(rr)) / n_v;  // :447-449, :503
+    if (q == 0) {
+      s.obs[sl * D] = vx;  // [own] only the longitudinal component is observed (:864-868, :885-887)
+    } else {
+      int base = 4 + 2 * NS + 11 * (q - 1);
+      s.obs[sl * D + base + 8] = vx;
+      s.obs[sl * D + base + 9] = vy;
+    }
+  }
+  for (int sl = threadIdx.x; sl < t.slots; sl += blockDim.x) {
     float ml = INFINITY, mr = INFINITY;
 #pragma unroll
-    for (int t = 0; t < 5; ++t) { ml = fminf(ml, s.dleft[i * 5 + t]); mr = fminf(mr, s.dright[i * 5 + t]); }
-    ob[2 + 2 * NS] = ml / n_dl;
-    ob[3 + 2 * NS] = mr / n_dl;
-  } else if (q <= NS) {
-    int k = q - 1;
-    float ox, oy;
-    ego_transform(si[0], si[1], si[2], s.shrt[i * NS * 2 + 2 * k], s.shrt[i * NS * 2 + 2 * k + 1], ox, oy);
-    ob[1 + 2 * k] = ox / n_pos;
-    ob[2 + 2 * k] = oy / n_pos;
-  } else if (q < 1 + NS + 4 * K) {
-    int w = q - (1 + NS);
-    int k = w >> 2, v = w & 3;
-    int j = s.near[i * K + k];
-    float ox, oy;
-    ego_transform(si[0], si[1], si[2], s.vnew[j * 10 + 2 * v], s.vnew[j * 10 + 2 * v + 1], ox, oy);
-    int base = 4 + 2 * NS + 11 * k;
-    ob[base + 2 * v] = ox / n_pos;
-    ob[base + 2 * v + 1] = oy / n_pos;
-  } else {
-    int k = q - (1 + NS + 4 * K);
-    int j = s.near[i * K + k];
-    const float* sj = s.st + j * 8;
-    float rr = angle_eliminate_two_pi(sj[2] - si[2]);
-    float va = norm2(sj[5], sj[6]);
-    int base = 4 + 2 * NS + 11 * k;
-    ob[base + 8] = (va * cr_cos(rr)) / n_v;
-    ob[base + 9] = (va * cr_sin(rr)) / n_v;
-    ob[base + 10] = s.dist[i * N + j] / n_dl;
+    for (int q = 0; q < 5; ++q) { ml = fminf(ml, s.dleft[sl * 5 + q]); mr = fminf(mr, s.dright[sl * 5 + q]); }
+    s.obs[sl * D + 1 + 2 * NS] = s.dref[sl] / n_dl;        // :376-378, :898-904
+    s.obs[sl * D + 2 + 2 * NS] = ml / n_dl;                // :379-382
+    s.obs[sl * D + 3 + 2 * NS] = mr / n_dl;                // :383-386
+    for (int k = 0; k < K; ++k) s.obs[sl * D + 4 + 2 * NS + 11 * k + 10] = s.dist[sl * N + s.near[sl * K + k]] / n_dl;  // :373-375
   }
-}
-
-// D + write-out of the observation of one env: top-k, items, coalesced store.  All threads of the block participate.
-__device__ inline void observe_env(const sigmaenv_config_t& c, const Smem& s, const DevBufs& g, int b, int N, int K, int D) {
-  for (int i = threadIdx.x; i < N; i += blockDim.x) topk_nearest(s.dist + i * N, N, K, s.near + i * K);
   __syncthreads();
-  const int items = 1 + NS + 5 * K;
-  for (int w = threadIdx.x; w < N * items; w += blockDim.x) obs_item(c, s, N, K, D, w / items, w % items);
-  __syncthreads();
-  for (int k = threadIdx.x; k < N * D; k += blockDim.x) g.obs[(size_t)b * N * D + k] = s.obs[k];
-  for (int k = threadIdx.x; k < N * K; k += blockDim.x) g.nearing[(size_t)b * N * K + k] = s.near[k];
+  for (int k = threadIdx.x; k < t.slots * D; k += blockDim.x) g.obs[t.a0 * D + k] = s.obs[k];
+  for (int k = threadIdx.x; k < t.slots * K; k += blockDim.x) g.nearing[t.a0 * K + k] = s.near[k];
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// the fused step kernel: grid = n_envs, block = 64 * WAVES
+// the fused step kernel: grid = ceil(n_envs / G), block = 64 * waves
 // VMAS >= 1.4 call order restated per env: world.step(); reward(a) for all a; observation(a) for all a; done()
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) sigmaenv_step_kernel(sigmaenv_config_t c, DevMap m, DevBufs g, const float* __restrict__ actions) {
+__global__ void __launch_bounds__(256) sigmaenv_step_kernel(sigmaenv_config_t c, DevMap m, DevBufs g, const float* __restrict__ actions, int G, int dbg_skip) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int N = c.n_agents, K = c.n_nearing;
-  const int D = 4 + 2 * NS + 11 * K;
-  const int b = blockIdx.x;
+  const Tile t(c, G);
+  const int N = t.N;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
-  Smem s(smem_raw, N, K, D);
-  const size_t bN = (size_t)b * N;
+  Smem s(smem_raw, G * N, N, t.K, t.D);
+#define TS(k) do { if (g.dbg_ts && tid == 0) g.dbg_ts[(size_t)blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+  TS(0);
 
-  // ---- A: dynamics + vertices (one thread per agent) -------------------------------------------------------------
-  for (int i = tid; i < N; i += blockDim.x) {
-    const size_t bi = bN + i;
+  // ---- A: dynamics + vertices (one lane per agent; slots <= 64 so this is wavefront 0) -------------------------------
+  if (tid < t.slots && !(dbg_skip & 16)) {
+    const int sl = tid;
+    const size_t gi = t.a0 + sl;
     float st[8], uc[2];
-    const float4* gs = reinterpret_cast<const float4*>(g.state + bi * 8);
+    const float4* gs = reinterpret_cast<const float4*>(g.state + gi * 8);
     float4 s0 = gs[0], s1 = gs[1];
     st[0] = s0.x; st[1] = s0.y; st[2] = s0.z; st[3] = s0.w; st[4] = s1.x; st[5] = s1.y; st[6] = s1.z; st[7] = s1.w;
-    float2 u = reinterpret_cast<const float2*>(actions)[bi];
+    float2 u = reinterpret_cast<const float2*>(actions)[gi];
     bicycle_step(c, st, u.x, u.y, uc);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) s.st[i * 8 + k] = st[k];
-    reinterpret_cast<float2*>(g.action)[bi] = make_float2(uc[0], uc[1]);
-    float4* go = reinterpret_cast<float4*>(g.state + bi * 8);
+    for (int k = 0; k < 8; ++k) s.st[sl * 8 + k] = st[k];
+    reinterpret_cast<float2*>(g.action)[gi] = make_float2(uc[0], uc[1]);
+    float4* go = reinterpret_cast<float4*>(g.state + gi * 8);
     go[0] = make_float4(st[0], st[1], st[2], st[3]);
     go[1] = make_float4(st[4], st[5], st[6], st[7]);
     // last step's vertices: agent 0's corner queries and the whole mtv matrix still see them, because update_distances
     // runs before update_vertices (world_state_rt_sim.py:439-448)
+    const float2* gv = reinterpret_cast<const float2*>(g.vertices + gi * 10);
 #pragma unroll
-    for (int k = 0; k < 10; ++k) s.vold[i * 10 + k] = g.vertices[bi * 10 + k];
+    for (int k = 0; k < 5; ++k) { float2 vv = gv[k]; s.vold[sl * 10 + 2 * k] = vv.x; s.vold[sl * 10 + 2 * k + 1] = vv.y; }
     float v[10];
     rect_vertices(c, st[0], st[1], st[2], v);
+    float2* gvo = reinterpret_cast<float2*>(g.vertices + gi * 10);
 #pragma unroll
-    for (int k = 0; k < 10; ++k) { s.vnew[i * 10 + k] = v[k]; g.vertices[bi * 10 + k] = v[k]; }
-    s.path[i] = g.path[bi * 4];
+    for (int k = 0; k < 5; ++k) { s.vnew[sl * 10 + 2 * k] = v[2 * k]; s.vnew[sl * 10 + 2 * k + 1] = v[2 * k + 1]; gvo[k] = make_float2(v[2 * k], v[2 * k + 1]); }
+    s.path[sl] = g.path[gi * 4];
     // last step's closest-point indices: the pruned scan derives its distance upper bounds from them
-    s.cp[i * 3 + 0] = g.closest[bi * 3 + 0]; s.cp[i * 3 + 1] = g.closest[bi * 3 + 1]; s.cp[i * 3 + 2] = g.closest[bi * 3 + 2];
+    s.cp[sl * 3 + 0] = g.closest[gi * 3 + 0]; s.cp[sl * 3 + 1] = g.closest[gi * 3 + 1]; s.cp[sl * 3 + 2] = g.closest[gi * 3 + 2];
+    if (m.nch > 0) scan_prepare<true>(m, s, sl, sl % N == 0);
   }
   __syncthreads();
+  TS(1);
 
-  // ---- B1: mutual distances + agent-agent collisions (one thread per ordered pair) -------------------------------
+  // ---- B1: mutual distances + agent-agent collisions (one lane per ordered pair) -------------------------------------
   const float diag = sqrtf(c.world_x_dim * c.world_x_dim + c.world_y_dim * c.world_y_dim);  // helper_scenario.py:1140-1143
-  for (int p = tid; p < N * N; p += blockDim.x) {
-    int i = p / N, j = p - i * N;
-    float d = (i == j) ? diag : pair_distance(c, s.st, s.vold, i, j);
+  for (int p = tid; p < t.slots * N; p += blockDim.x) {
+    if (dbg_skip & 1) break;  // profiling experiments only (results invalid)
+    int si = p / N, j = p - si * N;
+    int sj = (si / N) * N + j;
+    float d = (si == sj) ? diag : pair_distance(c, s.st, s.vold, si, sj);
     s.dist[p] = d;
-    g.dist_agents[bN * N + p] = d;
+    g.dist_agents[t.a0 * N + p] = d;
     uint8_t col = 0;
     if (c.distance_type == SIGMAENV_DIST_C2C) {
-      if (i != j) col = interx_rect_rect(s.vnew + (i < j ? i : j) * 10, s.vnew + (i < j ? j : i) * 10) ? 1 : 0;  // world_state_rt_sim.py:382-393
+      // world_state_rt_sim.py:382-393; rectangles whose circumcircles are disjoint cannot produce a proper edge crossing
+      // (DESIGN.md "Pruned scan"), so the 16 edge tests are skipped for them
+      if (si != sj && !(d > 2.0f * m.rect_radius + 1e-4f))
+        col = interx_rect_rect(s.vnew + (si < sj ? si : sj) * 10, s.vnew + (si < sj ? sj : si) * 10) ? 1 : 0;
     } else {
       col = (d == 0.0f) ? 1 : 0;  // :394-396
     }
     s.col[p] = col;
-    g.col_agents[bN * N + p] = col;
+    g.col_agents[t.a0 * N + p] = col;
   }
 
-  // ---- B2: distance queries + boundary collisions (one wavefront per agent) --------------------------------------
-  for (int i = wave; i < N; i += n_waves) {
-    const float* si = s.st + i * 8;
-    const float* qv = (i == 0) ? (s.vold) : (s.vnew + i * 10);  // agent 0 queries its corners at last step's vertices
-    AgentScan r;
-    agent_scan_any<true>(m, c, s.path[i], lane, si[0], si[1], qv, s.vnew + i * 10, s.cp + i * 3, r);
-    int path = s.path[i];
-    bool entry = false, exit_ = false;
-    if (!m.is_loop[path]) {  // world_state_rt_sim.py:413-424
-      const float* lb = m.left + (size_t)path * m.P * 2;
-      const float* rb = m.right + (size_t)path * m.P * 2;
-      int nl = m.n_left[path], nr = m.n_right[path];
-      entry = interx_rect_seg(s.vnew + i * 10, lb[0], lb[1], rb[0], rb[1]);
-      exit_ = interx_rect_seg(s.vnew + i * 10, lb[2 * (nl - 1)], lb[2 * (nl - 1) + 1], rb[2 * (nr - 1)], rb[2 * (nr - 1) + 1]);
-    }
-    if (lane == 0) {
-      s.dref[i] = r.d_ref;
-      float mb = INFINITY;
+  TS(2);
+  // ---- B2: distance queries + boundary collisions (two agents per wavefront; full-scan fallback one agent per wavefront) ----
+  if (dbg_skip & 2) {
+  } else if (m.nch > 0) {
+    for (int pr = wave; 2 * pr < t.slots; pr += n_waves) pair_scan<true>(m, c, s, 2 * pr, (2 * pr + 1 < t.slots) ? 3 : 1, lane, true, N);
+  } else {
+    for (int sl = wave; sl < t.slots; sl += n_waves) {
+      const int i = sl % N;
+      const float* si = s.st + sl * 8;
+      const float* qv = (i == 0) ? (s.vold + sl * 10) : (s.vnew + sl * 10);  // agent 0 queries its corners at last step's vertices
+      AgentScan r;
+      agent_scan_full<true>(m, c, s.path[sl], lane, si[0], si[1], qv, s.vnew + sl * 10, r);
+      if (lane == 0) {
+        s.dref[sl] = r.d_ref;
 #pragma unroll
-      for (int q = 0; q < 5; ++q) { s.dleft[i * 5 + q] = r.dl[q]; s.dright[i * 5 + q] = r.dr[q]; }
-#pragma unroll
-      for (int q = 0; q < 5; ++q) mb = fminf(mb, r.dl[q]);
-#pragma unroll
-      for (int q = 0; q < 5; ++q) mb = fminf(mb, r.dr[q]);
-      s.dbound[i] = mb;
-      s.cp[i * 3 + 0] = r.cp_ref; s.cp[i * 3 + 1] = r.cp_l; s.cp[i * 3 + 2] = r.cp_r;
-      s.flags[i * 4 + 0] = r.hit ? 1 : 0; s.flags[i * 4 + 1] = entry ? 1 : 0; s.flags[i * 4 + 2] = exit_ ? 1 : 0;
+        for (int q = 0; q < 5; ++q) { s.dleft[sl * 5 + q] = r.dl[q]; s.dright[sl * 5 + q] = r.dr[q]; }
+        s.cp[sl * 3 + 0] = r.cp_ref; s.cp[sl * 3 + 1] = r.cp_l; s.cp[sl * 3 + 2] = r.cp_r;
+        s.flags[sl * 4 + 0] = r.hit ? 1 : 0;
+      }
     }
   }
   __syncthreads();
+  TS(3);
 
-  // ---- C: reward, short-term path, bookkeeping (one thread per agent) ---------------------------------------------
-  const size_t BN = (size_t)c.n_envs * N;
-  for (int i = tid; i < N; i += blockDim.x) {
-    const size_t bi = bN + i;
-    const float* si = s.st + i * 8;
-    float2 pp = reinterpret_cast<const float2*>(g.prev_pos)[bi];
-    float w[3];
-    w[0] = __uint_as_float(W_REF_BITS[0]); w[1] = __uint_as_float(W_REF_BITS[1]); w[2] = __uint_as_float(W_REF_BITS[2]);
-    float mvx = si[0] - pp.x, mvy = si[1] - pp.y;
-    float acc = 0.0f;
+  // ---- C: reward, short-term path, per-env done()/counters via ballots (wavefront 0, one lane per agent) --------------
+  if (wave == 0 && !(dbg_skip & 4)) {
+    const bool act = tid < t.slots;
+    const int sl = act ? tid : 0;
+    const int e = sl / N, i = sl - e * N;
+    const size_t gi = t.a0 + sl;
+    const size_t BN = (size_t)c.n_envs * N;
+    int col_a = 0, col_l = 0, goal = 0, entry = 0;
+    if (act) {
+      const float* si = s.st + sl * 8;
+      float2 pp = reinterpret_cast<const float2*>(g.prev_pos)[gi];
+      float w[3];
+      w[0] = __uint_as_float(W_REF_BITS[0]); w[1] = __uint_as_float(W_REF_BITS[1]); w[2] = __uint_as_float(W_REF_BITS[2]);
+      float mvx = si[0] - pp.x, mvy = si[1] - pp.y;                  // road_traffic.py:972-974
+      float acc = 0.0f;
+      const float2* gst = reinterpret_cast<const float2*>(g.short_term + gi * NS * 2);
 #pragma unroll
-    for (int k = 0; k < NS; ++k) {  // the short-term path of the PREVIOUS step is still in HBM (road_traffic.py:976-984)
-      float rx = g.short_term[bi * NS * 2 + 2 * k] - pp.x, ry = g.short_term[bi * NS * 2 + 2 * k + 1] - pp.y;
-      float mp = mvx * rx + mvy * ry;
-      acc = acc + mp * w[k];
-    }
-    float denom = (float)((double)c.max_speed * (double)c.dt);
-    float rew = 0.0f;
-    rew += acc / denom * c.reward_progress;
-    int goal = s.flags[i * 4 + 2];
-    float reward_goal = (float)goal * c.reward_reach_goal;
-    int col_a = 0;
-    for (int j = 0; j < N; ++j) col_a |= s.col[i * N + j];
-    s.flags[i * 4 + 3] = col_a;
-    float pca = (float)col_a * c.penalty_collide_with_agents;
-    int col_l = s.flags[i * 4 + 0];
-    float pcl = (float)col_l * c.penalty_collide_with_boundaries;
-    float pen_lane = decreasing_lin(s.dbound[i], c.threshold_near_boundary_low, c.threshold_near_boundary_high) * c.penalty_near_boundary;
-    bool has_near = false;
-    float near_other = 0.0f;
-    if (c.is_testing_mode) {
-      rew += reward_goal; rew += pca; rew += pcl;
-    } else {
-      if (c.rew_flags & SIGMAENV_REW_EXACT_SPARSE) { rew += pca; rew += pcl; }
-      if (c.rew_flags & SIGMAENV_REW_TTC) {
-        float p = ttc_penalty(c, s.st, N, i);
-        near_other = p; has_near = true;
-        rew += p; rew += pen_lane; rew += pca; rew += pcl;
-        if (c.rew_flags & SIGMAENV_REW_HAS_SPARSE) { rew += pca; rew += pcl; }
+      for (int k = 0; k < NS; ++k) {  // the short-term path of the PREVIOUS step is still in HBM (:976-984)
+        float2 sp = gst[k];
+        float rx = sp.x - pp.x, ry = sp.y - pp.y;
+        float mp = mvx * rx + mvy * ry;
+        acc = acc + mp * w[k];
       }
-      if (c.rew_flags & SIGMAENV_REW_DISTANCE) {
-        float ssum = 0.0f;
-        for (int j = 0; j < N; ++j) ssum += decreasing_lin(s.dist[i * N + j], c.threshold_near_other_agents_low, c.threshold_near_other_agents_high);
-        float p = ssum * c.penalty_near_other_agents;
-        near_other = p; has_near = true;
-        rew += p; rew += pen_lane;
-        if (c.rew_flags & SIGMAENV_REW_HAS_SPARSE) { rew += pca; rew += pcl; }
+      float denom = (float)((double)c.max_speed * (double)c.dt);
+      float rew = 0.0f;
+      rew += acc / denom * c.reward_progress;                        // :986-991
+      {  // entry / exit segments of non-loop paths (world_state_rt_sim.py:413-424) and the boundary minimum (world_state_rt.py:648-656)
+        const int pth = s.path[sl];
+        if (!m.is_loop[pth]) {
+          const float* lb = m.left + (size_t)pth * m.P * 2;
+          const float* rb = m.right + (size_t)pth * m.P * 2;
+          const int nl = m.n_left[pth], nr = m.n_right[pth];
+          entry = interx_rect_seg(s.vnew + sl * 10, lb[0], lb[1], rb[0], rb[1]) ? 1 : 0;
+          goal = interx_rect_seg(s.vnew + sl * 10, lb[2 * (nl - 1)], lb[2 * (nl - 1) + 1], rb[2 * (nr - 1)], rb[2 * (nr - 1) + 1]) ? 1 : 0;
+        }
+        float mbnd = INFINITY;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) mbnd = fminf(mbnd, s.dleft[sl * 5 + q]);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) mbnd = fminf(mbnd, s.dright[sl * 5 + q]);
+        s.dbound[sl] = mbnd;
       }
-    }
-    float r = clampf(rew, -1.0f, 1.0f);
-    g.reward[bi] = r;
-    // RewardInfo.reset() at the top of every reward() zeroes all agents' entries except three fields
-    // (helper_scenario.py:128-138): only the last agent's values of the other fields survive the loop.
-    bool last = (i == N - 1);
-    g.reward_info[1 * BN + bi] = last ? reward_goal : 0.0f;
-    g.reward_info[7 * BN + bi] = last ? pca : 0.0f;
-    g.reward_info[8 * BN + bi] = last ? pcl : 0.0f;
-    g.reward_info[11 * BN + bi] = last ? r : 0.0f;
-    if (has_near) g.reward_info[4 * BN + bi] = near_other;
-    // update_state_after_rewarding: new short-term path (world_state_rt_sim.py:450-454)
-    int path = s.path[i];
-    float sp[NS * 2];
-    short_term_path(m.center + (size_t)path * m.P * 2, m.n_center[path], m.is_loop[path] != 0, s.cp[i * 3], sp);
+      float reward_goal = (float)goal * c.reward_reach_goal;
+      for (int j = 0; j < N; ++j) col_a |= s.col[sl * N + j];        // :1008-1013
+      float pca = (float)col_a * c.penalty_collide_with_agents;
+      col_l = s.flags[sl * 4 + 0];
+      float pcl = (float)col_l * c.penalty_collide_with_boundaries;  // :1021-1026
+      float pen_lane = decreasing_lin(s.dbound[sl], c.threshold_near_boundary_low, c.threshold_near_boundary_high) * c.penalty_near_boundary;
+      bool has_near = false;
+      float near_other = 0.0f;
+      if (c.is_testing_mode) {                                       // :1050-1055
+        rew += reward_goal; rew += pca; rew += pcl;
+      } else {
+        if (c.rew_flags & SIGMAENV_REW_EXACT_SPARSE) { rew += pca; rew += pcl; }
+        if (c.rew_flags & SIGMAENV_REW_TTC) {                        // :1064-1084
+          float p = ttc_penalty(c, s.st + e * N * 8, N, i);
+          near_other = p; has_near = true;
+          rew += p; rew += pen_lane; rew += pca; rew += pcl;
+          if (c.rew_flags & SIGMAENV_REW_HAS_SPARSE) { rew += pca; rew += pcl; }
+        }
+        if (c.rew_flags & SIGMAENV_REW_DISTANCE) {                   // :1086-1110
+          float ssum = 0.0f;
+          for (int j = 0; j < N; ++j) ssum += decreasing_lin(s.dist[sl * N + j], c.threshold_near_other_agents_low, c.threshold_near_other_agents_high);
+          float p = ssum * c.penalty_near_other_agents;
+          near_other = p; has_near = true;
+          rew += p; rew += pen_lane;
+          if (c.rew_flags & SIGMAENV_REW_HAS_SPARSE) { rew += pca; rew += pcl; }
+        }
+      }
+      float r = clampf(rew, -1.0f, 1.0f);                            // :1249
+      g.reward[gi] = r;
+      // RewardInfo.reset() at the top of every reward() zeroes all agents' entries except three fields
+      // (helper_scenario.py:128-138): only the last agent's values of the other fields survive the loop.
+      bool last = (i == N - 1);
+      g.reward_info[1 * BN + gi] = last ? reward_goal : 0.0f;
+      g.reward_info[7 * BN + gi] = last ? pca : 0.0f;
+      g.reward_info[8 * BN + gi] = last ? pcl : 0.0f;
+      g.reward_info[11 * BN + gi] = last ? r : 0.0f;
+      if (has_near) g.reward_info[4 * BN + gi] = near_other;
+      // update_state_after_rewarding: new short-term path (world_state_rt_sim.py:450-454)
+      int path = s.path[sl];
+      float sp[NS * 2];
+      short_term_path(m.center + (size_t)path * m.P * 2, m.n_center[path], m.is_loop[path] != 0, s.cp[sl * 3], sp);
+      float2* gso = reinterpret_cast<float2*>(g.short_term + gi * NS * 2);
 #pragma unroll
-    for (int k = 0; k < NS * 2; ++k) { s.shrt[i * NS * 2 + k] = sp[k]; g.short_term[bi * NS * 2 + k] = sp[k]; }
-    reinterpret_cast<float2*>(g.prev_pos)[bi] = make_float2(si[0], si[1]);  // state_buffer.add, road_traffic.py:1226-1240
-    // distances / indices / flags of this agent
-    g.dist_ref[bi] = s.dref[i];
+      for (int k = 0; k < NS; ++k) { s.shrt[sl * NS * 2 + 2 * k] = sp[2 * k]; s.shrt[sl * NS * 2 + 2 * k + 1] = sp[2 * k + 1]; gso[k] = make_float2(sp[2 * k], sp[2 * k + 1]); }
+      reinterpret_cast<float2*>(g.prev_pos)[gi] = make_float2(si[0], si[1]);  // state_buffer.add, road_traffic.py:1226-1240
+      g.dist_ref[gi] = s.dref[sl];
 #pragma unroll
-    for (int q = 0; q < 5; ++q) { g.dist_left[bi * 5 + q] = s.dleft[i * 5 + q]; g.dist_right[bi * 5 + q] = s.dright[i * 5 + q]; }
-    g.dist_bound[bi] = s.dbound[i];
-    g.closest[bi * 3 + 0] = s.cp[i * 3 + 0]; g.closest[bi * 3 + 1] = s.cp[i * 3 + 1]; g.closest[bi * 3 + 2] = s.cp[i * 3 + 2];
-  }
-  __syncthreads();
-
-  // ---- E: timer, counters, done(), reset requests (road_traffic.py:954-962,998-1002,1030-1035,1368-1487) --------
-  if (tid == 0) {
-    int step = g.timer[b * 4] + 1;
-    int tries = 0, succ = 0, col_a = 0, col_l = 0;
-    for (int i = 0; i < N; ++i) {
-      int ca = s.flags[i * 4 + 3], cl = s.flags[i * 4 + 0], goal = s.flags[i * 4 + 2];
-      succ += goal;
-      tries += (ca | cl | goal) ? 1 : 0;
-      col_a |= ca; col_l |= cl;
+      for (int q = 0; q < 5; ++q) { g.dist_left[gi * 5 + q] = s.dleft[sl * 5 + q]; g.dist_right[gi * 5 + q] = s.dright[sl * 5 + q]; }
+      g.dist_bound[gi] = s.dbound[sl];
+      g.closest[gi * 3 + 0] = s.cp[sl * 3 + 0]; g.closest[gi * 3 + 1] = s.cp[sl * 3 + 1]; g.closest[gi * 3 + 2] = s.cp[sl * 3 + 2];
     }
-    g.timer[b * 4] = step;
-    g.timer[b * 4 + 1] += tries;
-    g.timer[b * 4 + 2] += succ;
-    int max_reached = (step == c.max_steps - 1);
-    int done = c.is_testing_mode ? max_reached : (max_reached | col_a | col_l);
-    g.done[b] = (uint8_t)done;
-    for (int i = 0; i < N; ++i) {
+    // timer, counters, done(), reset requests (road_traffic.py:954-962,998-1002,1030-1035,1368-1487): per-env reductions by ballot
+    const unsigned long long env_mask = ((N >= 64) ? ~0ull : ((1ull << N) - 1ull)) << (e * N);
+    const unsigned long long b_ca = __ballot(act && col_a), b_cl = __ballot(act && col_l), b_goal = __ballot(act && goal);
+    const unsigned long long b_any = __ballot(act && (col_a | col_l | goal));
+    if (act) {
+      const int b = t.env0 + e;
+      const int step = g.timer[b * 4] + 1;
+      const int max_reached = (step == c.max_steps - 1);
+      const int any_ca = (b_ca & env_mask) != 0ull, any_cl = (b_cl & env_mask) != 0ull;
+      const int done = c.is_testing_mode ? max_reached : (max_reached | any_ca | any_cl);
       int rq = 0;
-      if (c.is_testing_mode) rq = s.flags[i * 4 + 3] | s.flags[i * 4 + 0] | s.flags[i * 4 + 1] | s.flags[i * 4 + 2];
-      else if (c.has_entry_exit) rq = s.flags[i * 4 + 1] | s.flags[i * 4 + 2];
-      uchar4 f;
-      f.x = (uint8_t)s.flags[i * 4 + 0]; f.y = (uint8_t)s.flags[i * 4 + 1]; f.z = (uint8_t)s.flags[i * 4 + 2];
-      f.w = (uint8_t)((rq && !done) ? 1 : 0);
-      reinterpret_cast<uchar4*>(g.col_flags)[bN + i] = f;
+      if (c.is_testing_mode) rq = col_a | col_l | entry | goal;
+      else if (c.has_entry_exit) rq = entry | goal;
+      reinterpret_cast<uchar4*>(g.col_flags)[gi] = make_uchar4((uint8_t)col_l, (uint8_t)entry, (uint8_t)goal, (uint8_t)((rq && !done) ? 1 : 0));
+      if (i == 0) {
+        g.timer[b * 4] = step;
+        g.timer[b * 4 + 1] += __popcll(b_any & env_mask);
+        g.timer[b * 4 + 2] += __popcll(b_goal & env_mask);
+        g.done[b] = (uint8_t)done;
+      }
     }
   }
+  __syncthreads();
+  TS(4);
 
-  // ---- D: observations --------------------------------------------------------------------------------------------
-  observe_env(c, s, g, b, N, K, D);
+  // ---- D: observations ---------------------------------------------------------------------------------------------
+  if (!(dbg_skip & 8)) observe_tile(c, s, g, t);
+  TS(5);
+#undef TS
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// observation only (observation() called again after resets): grid = n_envs
+// observation only (observation() called again after resets)
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ inline void load_env_for_observation(const Smem& s, const DevBufs& g, int b, int N) {
-  const size_t bN = (size_t)b * N;
-  for (int k = threadIdx.x; k < N * 8; k += blockDim.x) s.st[k] = g.state[bN * 8 + k];
-  for (int k = threadIdx.x; k < N * 10; k += blockDim.x) s.vnew[k] = g.vertices[bN * 10 + k];
-  for (int k = threadIdx.x; k < N * NS * 2; k += blockDim.x) s.shrt[k] = g.short_term[bN * NS * 2 + k];
-  for (int k = threadIdx.x; k < N; k += blockDim.x) s.dref[k] = g.dist_ref[bN + k];
-  for (int k = threadIdx.x; k < N * 5; k += blockDim.x) { s.dleft[k] = g.dist_left[bN * 5 + k]; s.dright[k] = g.dist_right[bN * 5 + k]; }
-  for (int k = threadIdx.x; k < N * N; k += blockDim.x) s.dist[k] = g.dist_agents[bN * N + k];
+__device__ inline void load_tile_for_observation(const Smem& s, const DevBufs& g, const Tile& t) {
+  const int N = t.N;
+  for (int k = threadIdx.x; k < t.slots * 8; k += blockDim.x) s.st[k] = g.state[t.a0 * 8 + k];
+  for (int k = threadIdx.x; k < t.slots * 10; k += blockDim.x) s.vnew[k] = g.vertices[t.a0 * 10 + k];
+  for (int k = threadIdx.x; k < t.slots * NS * 2; k += blockDim.x) s.shrt[k] = g.short_term[t.a0 * NS * 2 + k];
+  for (int k = threadIdx.x; k < t.slots; k += blockDim.x) s.dref[k] = g.dist_ref[t.a0 + k];
+  for (int k = threadIdx.x; k < t.slots * 5; k += blockDim.x) { s.dleft[k] = g.dist_left[t.a0 * 5 + k]; s.dright[k] = g.dist_right[t.a0 * 5 + k]; }
+  for (int k = threadIdx.x; k < t.slots * N; k += blockDim.x) s.dist[k] = g.dist_agents[t.a0 * N + k];
   __syncthreads();
 }
 
-__global__ void __launch_bounds__(1024) sigmaenv_observe_kernel(sigmaenv_config_t c, DevBufs g) {
+__global__ void __launch_bounds__(256) sigmaenv_observe_kernel(sigmaenv_config_t c, DevBufs g, int G) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int N = c.n_agents, K = c.n_nearing, D = 4 + 2 * NS + 11 * K;
-  Smem s(smem_raw, N, K, D);
-  load_env_for_observation(s, g, blockIdx.x, N);
-  observe_env(c, s, g, blockIdx.x, N, K, D);
+  const Tile t(c, G);
+  Smem s(smem_raw, G * t.N, t.N, t.K, t.D);
+  load_tile_for_observation(s, g, t);
+  observe_tile(c, s, g, t);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// reset: (1) scatter host-chosen entries, (2) optional device-side sampling, (3) rebuild derived state of marked envs
+// reset: (1) scatter host-chosen entries, (2) rebuild the derived state of marked agents / envs
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void sigmaenv_reset_scatter_kernel(DevBufs g, int N, int n, const int32_t* env_idx, const int32_t* agent_idx, const int32_t* path_ids,
                                               const float* state8, int full_env) {
@@ -639,146 +700,233 @@ __global__ void sigmaenv_reset_scatter_kernel(DevBufs g, int N, int n, const int
 }
 
 // derived state of every marked agent (reset_init_distances_and_short_term_ref_path, world_state_rt.py:422-529) and the
-// per-env tail (road_traffic.py:902-923); with_obs: also a fresh observation of the env.  Expects s.st / s.path / s.vnew of
-// the env in LDS.  All threads of the block participate.
-__device__ inline void reset_derive_body(const sigmaenv_config_t& c, const DevMap& m, const DevBufs& g, const Smem& s, int b, unsigned long long mask,
-                                         int full, int with_obs) {
-  const int N = c.n_agents, K = c.n_nearing, D = 4 + 2 * NS + 11 * K;
+// per-env tail (road_traffic.py:902-923) for the envs of the tile whose bit is set in env_bits; with_obs: also a fresh
+// observation of the whole tile.  Expects s.st / s.path / s.vnew / s.cp (scan guesses) of the tile in LDS; agent_mask[e] is the
+// per-env agent bit mask, full[e] the full-env flag.  All threads of the block participate.
+__device__ inline void reset_derive_body(const sigmaenv_config_t& c, const DevMap& m, const DevBufs& g, const Smem& s, const Tile& t,
+                                         const unsigned long long* agent_mask, const int* full, int with_obs) {
+  const int N = t.N;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
-  const size_t bN = (size_t)b * N;
-  for (int i = tid; i < N; i += blockDim.x) {
-    if ((mask >> i) & 1ull) {
+  for (int sl = tid; sl < t.slots; sl += blockDim.x) {
+    int e = sl / N, i = sl - e * N;
+    if ((agent_mask[e] >> i) & 1ull) {
       float v[10];
-      rect_vertices(c, s.st[i * 8], s.st[i * 8 + 1], s.st[i * 8 + 2], v);
+      rect_vertices(c, s.st[sl * 8], s.st[sl * 8 + 1], s.st[sl * 8 + 2], v);
 #pragma unroll
-      for (int k = 0; k < 10; ++k) { s.vnew[i * 10 + k] = v[k]; g.vertices[(bN + i) * 10 + k] = v[k]; }
+      for (int k = 0; k < 10; ++k) { s.vnew[sl * 10 + k] = v[k]; g.vertices[(t.a0 + sl) * 10 + k] = v[k]; }
+      if (m.nch > 0) scan_prepare<false>(m, s, sl, false);
     }
   }
   __syncthreads();
-  for (int i = wave; i < N; i += n_waves) {
-    if (!((mask >> i) & 1ull)) continue;
-    AgentScan r;
-    agent_scan_any<false>(m, c, s.path[i], lane, s.st[i * 8], s.st[i * 8 + 1], s.vnew + i * 10, s.vnew + i * 10, s.cp + i * 3, r);
-    if (lane == 0) {
-      const size_t bi = bN + i;
-      float mb = INFINITY;
-      g.dist_ref[bi] = r.d_ref;
+  if (m.nch > 0) {
+    for (int pr = wave; 2 * pr < t.slots; pr += n_waves) {
+      int sa = 2 * pr, sb = 2 * pr + 1;
+      bool ma = (agent_mask[sa / N] >> (sa % N)) & 1ull;
+      bool mb = (sb < t.slots) && ((agent_mask[sb / N] >> (sb % N)) & 1ull);
+      if (!(ma || mb)) continue;
+      pair_scan<false>(m, c, s, sa, (ma ? 1 : 0) | (mb ? 2 : 0), lane, false, N);
+    }
+  } else {
+    for (int sl = wave; sl < t.slots; sl += n_waves) {
+      int e = sl / N, i = sl - e * N;
+      if (!((agent_mask[e] >> i) & 1ull)) continue;
+      AgentScan r;
+      agent_scan_full<false>(m, c, s.path[sl], lane, s.st[sl * 8], s.st[sl * 8 + 1], s.vnew + sl * 10, s.vnew + sl * 10, r);
+      if (lane == 0) {
+        s.dref[sl] = r.d_ref;
 #pragma unroll
-      for (int q = 0; q < 5; ++q) { g.dist_left[bi * 5 + q] = r.dl[q]; g.dist_right[bi * 5 + q] = r.dr[q]; }
-#pragma unroll
-      for (int q = 0; q < 5; ++q) mb = fminf(mb, r.dl[q]);
-#pragma unroll
-      for (int q = 0; q < 5; ++q) mb = fminf(mb, r.dr[q]);
-      g.dist_bound[bi] = mb;
-      g.closest[bi * 3 + 0] = r.cp_ref; g.closest[bi * 3 + 1] = r.cp_l; g.closest[bi * 3 + 2] = r.cp_r;
-      int path = s.path[i];
-      float sp[NS * 2];
-      short_term_path(m.center + (size_t)path * m.P * 2, m.n_center[path], m.is_loop[path] != 0, r.cp_ref, sp);
-#pragma unroll
-      for (int k = 0; k < NS * 2; ++k) g.short_term[bi * NS * 2 + k] = sp[k];
+        for (int q = 0; q < 5; ++q) { s.dleft[sl * 5 + q] = r.dl[q]; s.dright[sl * 5 + q] = r.dr[q]; }
+        s.cp[sl * 3 + 0] = r.cp_ref; s.cp[sl * 3 + 1] = r.cp_l; s.cp[sl * 3 + 2] = r.cp_r;
+      }
     }
   }
-  // tail: mutual distances, collisions cleared, prev_pos := pos, timer
+  __syncthreads();
+  for (int sl = tid; sl < t.slots; sl += blockDim.x) {  // only the marked agents' derived state is replaced
+    int e = sl / N, i = sl - e * N;
+    if (!((agent_mask[e] >> i) & 1ull)) continue;
+    const size_t gi = t.a0 + sl;
+    float mbnd = INFINITY;
+    g.dist_ref[gi] = s.dref[sl];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) { g.dist_left[gi * 5 + q] = s.dleft[sl * 5 + q]; g.dist_right[gi * 5 + q] = s.dright[sl * 5 + q]; }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) mbnd = fminf(mbnd, s.dleft[sl * 5 + q]);
+#pragma unroll
+    for (int q = 0; q < 5; ++q) mbnd = fminf(mbnd, s.dright[sl * 5 + q]);
+    g.dist_bound[gi] = mbnd;
+    g.closest[gi * 3 + 0] = s.cp[sl * 3 + 0]; g.closest[gi * 3 + 1] = s.cp[sl * 3 + 1]; g.closest[gi * 3 + 2] = s.cp[sl * 3 + 2];
+    int path = s.path[sl];
+    float sp[NS * 2];
+    short_term_path(m.center + (size_t)path * m.P * 2, m.n_center[path], m.is_loop[path] != 0, s.cp[sl * 3], sp);
+#pragma unroll
+    for (int k = 0; k < NS * 2; ++k) g.short_term[gi * NS * 2 + k] = sp[k];
+  }
+  // tail of every touched env: mutual distances, collisions cleared, prev_pos := pos, timer
   const float diag = sqrtf(c.world_x_dim * c.world_x_dim + c.world_y_dim * c.world_y_dim);
-  for (int p = tid; p < N * N; p += blockDim.x) {
-    int i = p / N, j = p - i * N;
-    float d = (i == j) ? diag : pair_distance(c, s.st, s.vnew, i, j);
-    g.dist_agents[bN * N + p] = d;
-    g.col_agents[bN * N + p] = 0;
+  for (int p = tid; p < t.slots * N; p += blockDim.x) {
+    int si = p / N, j = p - si * N;
+    int e = si / N;
+    if (agent_mask[e] == 0ull) continue;
+    int sj = e * N + j;
+    float d = (si == sj) ? diag : pair_distance(c, s.st, s.vnew, si, sj);
+    g.dist_agents[t.a0 * N + p] = d;
+    g.col_agents[t.a0 * N + p] = 0;
   }
-  for (int i = tid; i < N; i += blockDim.x) {
-    reinterpret_cast<uchar4*>(g.col_flags)[bN + i] = make_uchar4(0, 0, 0, 0);
-    reinterpret_cast<float2*>(g.prev_pos)[bN + i] = make_float2(s.st[i * 8], s.st[i * 8 + 1]);
-    if (full) reinterpret_cast<float2*>(g.action)[bN + i] = make_float2(0.f, 0.f);
-  }
-  if (tid == 0) {
-    if (full) { g.timer[b * 4] = 0; g.timer[b * 4 + 3] += 1; g.done[b] = 0; }
-    g.reset_mask[b] = 0ull;
-    g.reset_full[b] = 0;
+  for (int sl = tid; sl < t.slots; sl += blockDim.x) {
+    int e = sl / N, i = sl - e * N;
+    if (agent_mask[e] == 0ull) continue;
+    const size_t gi = t.a0 + sl;
+    reinterpret_cast<uchar4*>(g.col_flags)[gi] = make_uchar4(0, 0, 0, 0);
+    reinterpret_cast<float2*>(g.prev_pos)[gi] = make_float2(s.st[sl * 8], s.st[sl * 8 + 1]);
+    if (full[e]) reinterpret_cast<float2*>(g.action)[gi] = make_float2(0.f, 0.f);
+    if (i == 0) {
+      int b = t.env0 + e;
+      if (full[e]) { g.timer[b * 4] = 0; g.timer[b * 4 + 3] += 1; g.done[b] = 0; }
+      g.reset_mask[b] = 0ull;
+      g.reset_full[b] = 0;
+    }
   }
   if (with_obs) {
     __threadfence_block();
     __syncthreads();
-    load_env_for_observation(s, g, b, N);
-    observe_env(c, s, g, b, N, K, D);
+    load_tile_for_observation(s, g, t);
+    observe_tile(c, s, g, t);
   }
 }
 
-// host-driven resets: grid = n_envs, only blocks whose env has marked agents do work
-__global__ void __launch_bounds__(1024) sigmaenv_reset_derive_kernel(sigmaenv_config_t c, DevMap m, DevBufs g, int with_obs) {
+#define MAX_G 64
+
+// host-driven resets: only tiles with marked agents do work
+__global__ void __launch_bounds__(256) sigmaenv_reset_derive_kernel(sigmaenv_config_t c, DevMap m, DevBufs g, int with_obs, int G) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int b = blockIdx.x;
-  const unsigned long long mask = g.reset_mask[b];
-  if (mask == 0ull) return;  // uniform per block
-  const int N = c.n_agents, K = c.n_nearing, D = 4 + 2 * NS + 11 * K;
-  const int full = g.reset_full[b];
-  Smem s(smem_raw, N, K, D);
-  const size_t bN = (size_t)b * N;
-  for (int k = threadIdx.x; k < N * 8; k += blockDim.x) s.st[k] = g.state[bN * 8 + k];
-  for (int k = threadIdx.x; k < N * 10; k += blockDim.x) s.vnew[k] = g.vertices[bN * 10 + k];
-  for (int k = threadIdx.x; k < N; k += blockDim.x) {
-    s.path[k] = g.path[(bN + k) * 4];
-    int pt = g.path[(bN + k) * 4 + 3];  // the agent was placed at (or near) this centre-line point: guess for the pruned scan
+  const Tile t(c, G);
+  const int N = t.N;
+  // all LDS lives in the one dynamic region (keeps its base 16-byte aligned): [Smem | masks | full flags | any]
+  unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(smem_raw + ((Smem::bytes(G * N, N, t.K, t.D) + 15) & ~(size_t)15));
+  int* s_full = reinterpret_cast<int*>(s_mask + MAX_G);
+  int* s_any = s_full + MAX_G;
+  if (threadIdx.x == 0) *s_any = 0;
+  __syncthreads();
+  if (threadIdx.x < t.nenv) {
+    unsigned long long mk = g.reset_mask[t.env0 + threadIdx.x];
+    s_mask[threadIdx.x] = mk;
+    s_full[threadIdx.x] = g.reset_full[t.env0 + threadIdx.x];
+    if (mk) *s_any = 1;
+  }
+  __syncthreads();
+  if (!*s_any) return;
+  Smem s(smem_raw, G * N, N, t.K, t.D);
+  for (int k = threadIdx.x; k < t.slots * 8; k += blockDim.x) s.st[k] = g.state[t.a0 * 8 + k];
+  for (int k = threadIdx.x; k < t.slots * 10; k += blockDim.x) s.vnew[k] = g.vertices[t.a0 * 10 + k];
+  for (int k = threadIdx.x; k < t.slots; k += blockDim.x) {
+    s.path[k] = g.path[(t.a0 + k) * 4];
+    int pt = g.path[(t.a0 + k) * 4 + 3];  // the agent was placed at (or near) this centre-line point: guess for the pruned scan
     s.cp[k * 3 + 0] = pt; s.cp[k * 3 + 1] = pt; s.cp[k * 3 + 2] = pt;
   }
   __syncthreads();
-  reset_derive_body(c, m, g, s, b, mask, full, with_obs);
+  reset_derive_body(c, m, g, s, t, s_mask, s_full, with_obs);
 }
 
-// Device-side reset of finished envs (grid = n_envs, blocks of unfinished envs exit at once).  Wavefront 0 runs the rejection
-// sampler of world_state_rt_sim.py:215-311 (non-testing mode) from a counter-based RNG: the 64 lanes evaluate tries 0..63 of one
-// agent at once and the FIRST feasible try wins, which is exactly the sequential loop's result for the same draws (bounded to
-// 64 tries; the reference loops without bound).  Then the deterministic reset as in sigmaenv_reset(full_env=1).
-__global__ void __launch_bounds__(1024) sigmaenv_auto_reset_kernel(sigmaenv_config_t c, DevMap m, DevBufs g, uint64_t seed, uint64_t counter,
-                                                                   int path_first, int path_count) {
+// Device-side reset of finished envs (tiles without a finished env exit at once).  One wavefront per finished env runs the
+// rejection sampler of world_state_rt_sim.py:215-311 (non-testing mode) from a counter-based RNG: the 64 lanes evaluate tries
+// 0..63 of one agent at once and the FIRST feasible try wins, which is exactly the sequential loop's result for the same draws
+// (bounded to 64 tries; the reference loops without bound).  Then the deterministic reset as in sigmaenv_reset(full_env=1).
+__global__ void __launch_bounds__(256) sigmaenv_auto_reset_kernel(sigmaenv_config_t c, DevMap m, DevBufs g, uint64_t seed, uint64_t counter,
+                                                                  int path_first, int path_count, int G) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int b = blockIdx.x;
-  if (!g.done[b]) return;  // uniform per block
-  const int N = c.n_agents, K = c.n_nearing, D = 4 + 2 * NS + 11 * K;
-  Smem s(smem_raw, N, K, D);
-  const size_t bN = (size_t)b * N;
-  const int tid = threadIdx.x;
-  if (tid < 64) {
-    const int t = tid;  // try index of this lane
-    const float min_d = sqrtf((float)((double)c.length * (double)c.length + (double)c.width * (double)c.width)) * 1.5f;  // road_traffic.py:679-684
-    const float min_d_sq = min_d * min_d;
+  const Tile t(c, G);
+  const int N = t.N;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
+  unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(smem_raw + ((Smem::bytes(G * N, N, t.K, t.D) + 15) & ~(size_t)15));
+  int* s_full = reinterpret_cast<int*>(s_mask + MAX_G);
+  int* s_any = s_full + MAX_G;
+  if (tid == 0) *s_any = 0;
+  __syncthreads();
+  if (tid < t.nenv) {
+    int dn = g.done[t.env0 + tid];
+    s_mask[tid] = dn ? ((N >= 64) ? ~0ull : ((1ull << N) - 1ull)) : 0ull;
+    s_full[tid] = dn;
+    if (dn) *s_any = 1;
+  }
+  __syncthreads();
+  if (!*s_any) return;
+  Smem s(smem_raw, G * N, N, t.K, t.D);
+  // untouched envs of the tile keep their state (needed for the tile-wide observation)
+  for (int k = tid; k < t.slots * 8; k += blockDim.x) s.st[k] = g.state[t.a0 * 8 + k];
+  for (int k = tid; k < t.slots * 10; k += blockDim.x) s.vnew[k] = g.vertices[t.a0 * 10 + k];
+  for (int k = tid; k < t.slots; k += blockDim.x) s.path[k] = g.path[(t.a0 + k) * 4];
+  __syncthreads();
+  const float min_d = sqrtf((float)((double)c.length * (double)c.length + (double)c.width * (double)c.width)) * 1.5f;  // road_traffic.py:679-684
+  const float min_d_sq = min_d * min_d;
+  // candidate (path, point) of try `tr` for agent `i` of env `b` -- the draw layout shared with the oracle
+  auto candidate = [&](int b, int i, int tr, int& path, int& pt, float& px, float& py) {
+    path = path_first + (int)__umulhi(rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, 2u * tr), (uint32_t)path_count);
+    int n = m.n_center[path];
+    int end = n / 2;
+    if (end < 4) end = 4;
+    pt = 3 + (int)__umulhi(rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, 2u * tr + 1u), (uint32_t)(end - 3));
+    px = m.center[((size_t)path * m.P + pt) * 2];
+    py = m.center[((size_t)path * m.P + pt) * 2 + 1];
+  };
+  const int TR = 64 / N > 0 ? 64 / N : 1;  // tries per agent evaluated up front (all agents at once, loads in flight together)
+  for (int e = wave; e < t.nenv; e += n_waves) {
+    if (!s_full[e]) continue;
+    const int b = t.env0 + e;
+    const int ca = lane / TR, ctr = lane - ca * TR;  // this lane's (agent, try)
+    const bool has_c = ca < N;
+    int cpath = 0, cpt = 3;
+    float cx = 0.f, cy = 0.f;
+    if (has_c) candidate(b, ca, ctr, cpath, cpt, cx, cy);
+    bool cok = has_c;  // still feasible w.r.t. every agent accepted so far
     for (int i = 0; i < N; ++i) {
-      int path = path_first + (int)(rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, 2u * t) % (uint32_t)path_count);
-      int n = m.n_center[path];
-      int end = n / 2;
-      if (end < 4) end = 4;
-      int pt = 3 + (int)(rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, 2u * t + 1u) % (uint32_t)(end - 3));
-      float px = m.center[((size_t)path * m.P + pt) * 2];
-      float py = m.center[((size_t)path * m.P + pt) * 2 + 1];
-      bool ok = true;
-      for (int j = 0; j < i; ++j) {  // accepted agents 0..i-1 are in LDS (written by the winning lane below)
-        float dx = px - s.st[j * 8], dy = py - s.st[j * 8 + 1];
-        float d2 = dx * dx + dy * dy;
-        if (!(d2 >= min_d_sq)) ok = false;
+      const int sl = e * N + i;
+      unsigned long long feas = __ballot(cok && ca == i);
+      int path, pt;
+      float px, py;
+      if (feas) {  // first feasible among the precomputed tries (they are tries 0..TR-1 in lane order)
+        int wl = __ffsll((long long)feas) - 1;
+        path = __shfl(cpath, wl, 64); pt = __shfl(cpt, wl, 64); px = __shfl(cx, wl, 64); py = __shfl(cy, wl, 64);
+      } else {     // rare: tries TR..63 of this agent, all lanes at once; none feasible -> the last try (as the bounded loop would)
+        int p2, q2;
+        float x2, y2;
+        candidate(b, i, lane, p2, q2, x2, y2);
+        bool ok = lane >= TR;
+        for (int j = 0; j < i; ++j) {
+          float dx = x2 - s.st[(e * N + j) * 8], dy = y2 - s.st[(e * N + j) * 8 + 1];
+          float d2 = dx * dx + dy * dy;
+          if (!(d2 >= min_d_sq)) ok = false;
+        }
+        unsigned long long f2 = __ballot(ok);
+        int wl = f2 ? (__ffsll((long long)f2) - 1) : (AUTO_RESET_MAX_TRIES - 1);
+        path = __shfl(p2, wl, 64); pt = __shfl(q2, wl, 64); px = __shfl(x2, wl, 64); py = __shfl(y2, wl, 64);
       }
-      unsigned long long feas = __ballot(ok);
-      int win = feas ? (__ffsll((long long)feas) - 1) : (AUTO_RESET_MAX_TRIES - 1);
-      if (t == win) {
-        float u = (float)(rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, 1000u) >> 8) * (1.0f / 16777216.0f);
-        int yi = pt < m.yaw_stride ? pt : m.yaw_stride - 1;
-        float rot = m.yaw[(size_t)path * m.yaw_stride + yi];
-        float speed = u * c.max_speed;
-        float st[8] = {px, py, rot, speed, 0.0f, speed * cr_cos(0.0f + rot), speed * cr_sin(0.0f + rot), 0.0f};
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { s.st[i * 8 + k] = st[k]; g.state[(bN + i) * 8 + k] = st[k]; }
-        s.path[i] = path;
-        s.cp[i * 3 + 0] = pt; s.cp[i * 3 + 1] = pt; s.cp[i * 3 + 2] = pt;
-        g.path[(bN + i) * 4 + 0] = path; g.path[(bN + i) * 4 + 1] = 0; g.path[(bN + i) * 4 + 2] = path - path_first; g.path[(bN + i) * 4 + 3] = pt;
-      }
+      if (lane == 0) { s.st[sl * 8] = px; s.st[sl * 8 + 1] = py; s.path[sl] = path; s.cp[sl * 3] = pt; }
+      // later agents must keep the minimum distance to this one (world_state_rt_sim.py:296-309)
+      float dx = cx - px, dy = cy - py;
+      float d2 = dx * dx + dy * dy;
+      if (ca > i && !(d2 >= min_d_sq)) cok = false;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    if (lane < N) {  // finalise the accepted starts, one lane per agent (world_state_rt_sim.py:189-213)
+      const int i = lane, sl = e * N + i;
+      const size_t gi = t.a0 + sl;
+      const int path = s.path[sl], pt = s.cp[sl * 3];
+      float u = (float)(rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, 1000u) >> 8) * (1.0f / 16777216.0f);
+      int yi = pt < m.yaw_stride ? pt : m.yaw_stride - 1;
+      float rot = m.yaw[(size_t)path * m.yaw_stride + yi];
+      float speed = u * c.max_speed;
+      float st[8] = {s.st[sl * 8], s.st[sl * 8 + 1], rot, speed, 0.0f, speed * cr_cos(0.0f + rot), speed * cr_sin(0.0f + rot), 0.0f};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { s.st[sl * 8 + k] = st[k]; g.state[gi * 8 + k] = st[k]; }
+      s.cp[sl * 3 + 1] = pt; s.cp[sl * 3 + 2] = pt;
+      g.path[gi * 4 + 0] = path; g.path[gi * 4 + 1] = 0; g.path[gi * 4 + 2] = path - path_first; g.path[gi * 4 + 3] = pt;
+    }
   }
   __threadfence_block();
   __syncthreads();
-  const unsigned long long mask = (N >= 64) ? ~0ull : ((1ull << N) - 1ull);
-  reset_derive_body(c, m, g, s, b, mask, 1, 1);
+  reset_derive_body(c, m, g, s, t, s_mask, s_full, 1);
 }
 
 // =====================================================================================================================
@@ -794,6 +942,9 @@ struct sigmaenv {
   std::vector<void*> allocs;
   size_t smem_bytes = 0;
   int block = 256;
+  int G = 1;      // environments per workgroup (G * N <= 64 agent slots)
+  int dbg_skip = 0;  // SIGMAENV_DEBUG_SKIP: phase-ablation bit mask for profiling experiments (results invalid when non-zero)
+  int grid = 1;
   void* bufs[SIGMAENV_BUF_COUNT] = {nullptr};
   size_t buf_bytes[SIGMAENV_BUF_COUNT] = {0};
   // reset staging
@@ -839,14 +990,14 @@ extern "C" void sigmaenv_destroy(sigmaenv_t* h) {
   delete h;
 }
 
-static int pick_block(int N, int B, int n_cu) {
-  // one wavefront per agent where that still leaves enough workgroups to fill the chip, else fewer waves looping over agents
-  int waves = N;
-  if (waves > 16) waves = 16;
-  while (waves > 4 && (long long)B * waves > (long long)n_cu * 32 * 4) waves >>= 1;
-  if (waves < 1) waves = 1;
-  // at least N threads are not required (loops stride by blockDim), but phase B1 likes >= 64
-  return waves * 64;
+// Environments per workgroup: a wavefront's worth of agents (G * N <= 64) so that the per-agent phases fill all 64 lanes,
+// but never so many that the grid drops below ~4 workgroups per CU (small batches keep G small instead).
+static int pick_envs_per_group(int N, int B, int n_cu) {
+  int G = 64 / N;
+  if (G < 1) G = 1;
+  if (G > MAX_G) G = MAX_G;
+  while (G > 1 && (B + G - 1) / G < 4 * n_cu) G >>= 1;
+  return G;
 }
 
 extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_t* map, int device_id, void* hip_stream, sigmaenv_t** out) {
@@ -929,7 +1080,7 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
   H2D(d_loop, map->is_loop, (size_t)np);
   // pruning table: bounding boxes of runs of SIGMAENV_CHUNK consecutive real segments (points 8c .. min(8c+8, n-1))
   int nch = (P - 1 + SIGMAENV_CHUNK - 1) / SIGMAENV_CHUNK;
-  bool prune = nch <= 32;  // the candidate masks are 32-bit; longer polylines fall back to the full scan
+  bool prune = nch <= 64;  // the candidate masks are 64-bit; longer polylines fall back to the full scan
   if (const char* e = getenv("SIGMAENV_PRUNE")) prune = prune && atoi(e) != 0;
   float4* d_box = nullptr;
   std::vector<float4> hb;  // must outlive the asynchronous upload below
@@ -951,7 +1102,9 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
     ALLOC(d_box, hb.size() * sizeof(float4));
     H2D(d_box, hb.data(), hb.size() * sizeof(float4));
   }
-  h->map = DevMap{d_c, d_l, d_r, d_y, d_nc, d_nl, d_nr, d_loop, P, np, S, d_box, prune ? nch : 0};
+  const float lh = (float)((double)cfg->length / 2.0), wh = (float)((double)cfg->width / 2.0);
+  const float rect_radius = sqrtf(lh * lh + wh * wh) * 1.00001f + 1e-5f;
+  h->map = DevMap{d_c, d_l, d_r, d_y, d_nc, d_nl, d_nr, d_loop, P, np, S, d_box, prune ? nch : 0, rect_radius};
   const size_t BN = (size_t)B * N;
   DevBufs& g = h->buf;
   struct Spec { int id; void** p; size_t bytes; };
@@ -974,17 +1127,28 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
   }
   ALLOC(g.reset_mask, (size_t)B * 8);
   ALLOC(g.reset_full, (size_t)B);
+  g.dbg_ts = nullptr;
+  if (const char* e = getenv("SIGMAENV_TIMESTAMPS")) {
+    if (atoi(e) != 0) { ALLOC(g.dbg_ts, (size_t)B * 8 * sizeof(unsigned long long)); }
+  }
 #undef ALLOC
 #undef H2D
   hipDeviceProp_t prop;
   int n_cu = 256;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) n_cu = prop.multiProcessorCount;
-  h->block = pick_block(N, B, n_cu);
+  h->G = pick_envs_per_group(N, B, n_cu);
+  if (const char* e = getenv("SIGMAENV_G")) {
+    int v = atoi(e);
+    if (v >= 1 && v * N <= 64) h->G = v;
+  }
+  h->block = 256;
   if (const char* e = getenv("SIGMAENV_BLOCK")) {
     int v = atoi(e);
-    if (v >= 64 && v <= 1024 && v % 64 == 0) h->block = v;
+    if (v >= 64 && v <= 256 && v % 64 == 0) h->block = v;
   }
-  h->smem_bytes = Smem::bytes(N, K, h->D);
+  if (const char* e = getenv("SIGMAENV_DEBUG_SKIP")) h->dbg_skip = atoi(e);
+  h->grid = (B + h->G - 1) / h->G;
+  h->smem_bytes = ((Smem::bytes(h->G * N, N, K, h->D) + 15) & ~(size_t)15) + MAX_G * 8 + MAX_G * 4 + 16;
   if (h->smem_bytes > 64 * 1024) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem_bytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_observe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem_bytes);
@@ -997,7 +1161,8 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
 }
 
 static int launch_derive(sigmaenv* h, int with_obs) {
-  hipLaunchKernelGGL(sigmaenv_reset_derive_kernel, dim3(h->B), dim3(h->block), h->smem_bytes, h->stream, h->cfg, h->map, h->buf, with_obs);
+  // resets touch few envs: one env per workgroup (G = 1) keeps the untouched ones out of the way
+  hipLaunchKernelGGL(sigmaenv_reset_derive_kernel, dim3(h->B), dim3(h->block), h->smem_bytes, h->stream, h->cfg, h->map, h->buf, with_obs, 1);
   HIPCHK(h, hipGetLastError());
   return SIGMAENV_OK;
 }
@@ -1057,7 +1222,7 @@ extern "C" int sigmaenv_step(sigmaenv_t* h, const float* actions) {
     h->ev_used.push_back(slot);
     HIPCHK(h, hipEventRecord(h->ev_pool[slot].first, h->stream));
   }
-  hipLaunchKernelGGL(sigmaenv_step_kernel, dim3(h->B), dim3(h->block), h->smem_bytes, h->stream, h->cfg, h->map, h->buf, actions);
+  hipLaunchKernelGGL(sigmaenv_step_kernel, dim3(h->grid), dim3(h->block), h->smem_bytes, h->stream, h->cfg, h->map, h->buf, actions, h->G, h->dbg_skip);
   HIPCHK(h, hipGetLastError());
   if (slot >= 0) HIPCHK(h, hipEventRecord(h->ev_pool[slot].second, h->stream));
   return SIGMAENV_OK;
@@ -1065,7 +1230,7 @@ extern "C" int sigmaenv_step(sigmaenv_t* h, const float* actions) {
 
 extern "C" int sigmaenv_observe(sigmaenv_t* h) {
   if (!h) return SIGMAENV_EINVAL;
-  hipLaunchKernelGGL(sigmaenv_observe_kernel, dim3(h->B), dim3(h->block), h->smem_bytes, h->stream, h->cfg, h->buf);
+  hipLaunchKernelGGL(sigmaenv_observe_kernel, dim3(h->grid), dim3(h->block), h->smem_bytes, h->stream, h->cfg, h->buf, h->G);
   HIPCHK(h, hipGetLastError());
   return SIGMAENV_OK;
 }
@@ -1073,7 +1238,7 @@ extern "C" int sigmaenv_observe(sigmaenv_t* h) {
 extern "C" int sigmaenv_auto_reset(sigmaenv_t* h, uint64_t seed, uint64_t counter, int32_t path_first, int32_t path_count) {
   if (!h || path_first < 0 || path_count < 1 || path_first + path_count > h->n_paths) return SIGMAENV_EINVAL;
   hipLaunchKernelGGL(sigmaenv_auto_reset_kernel, dim3(h->B), dim3(h->block), h->smem_bytes, h->stream, h->cfg, h->map, h->buf, seed, counter,
-                     (int)path_first, (int)path_count);
+                     (int)path_first, (int)path_count, 1);
   HIPCHK(h, hipGetLastError());
   return SIGMAENV_OK;
 }
@@ -1089,6 +1254,17 @@ extern "C" int sigmaenv_sync(sigmaenv_t* h) {
   if (!h) return SIGMAENV_EINVAL;
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return SIGMAENV_OK;
+}
+
+// Diagnostics: copies the per-workgroup phase timestamps of the LAST step launch to `out` ([n_groups][8] u64); returns the number of
+// workgroups, 0 when SIGMAENV_TIMESTAMPS was not set at create.
+extern "C" int sigmaenv_debug_timestamps(sigmaenv_t* h, unsigned long long* out, int32_t max_groups) {
+  if (!h || !out) return SIGMAENV_EINVAL;
+  if (!h->buf.dbg_ts) return 0;
+  int n = h->grid < max_groups ? h->grid : max_groups;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(out, h->buf.dbg_ts, (size_t)n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return n;
 }
 
 // Enables HIP-event bracketing of every subsequent step launch (first call) and reports/clears the collected launches.

@@ -33,8 +33,9 @@ struct DevMap {
   // pruning table: axis-aligned boxes of runs of CHUNK consecutive real segments, [n_paths][3 (centre,left,right)][nch]
   const float4* chunk_box;  // (min_x, min_y, max_x, max_y)
   int32_t nch;              // boxes per polyline (stride); 0 disables pruning (brute-force scan)
+  float rect_radius;        // upper bound of |vertex - centre| of a vehicle rectangle (half diagonal + slack)
 };
-#define SIGMAENV_CHUNK 8
+#define SIGMAENV_CHUNK 4
 
 struct DevBufs {
   float *state, *prev_pos, *vertices, *short_term, *dist_ref, *dist_left, *dist_right, *dist_bound, *dist_agents;
@@ -43,6 +44,7 @@ struct DevBufs {
   uint8_t *col_agents, *col_flags, *done;
   unsigned long long* reset_mask;  // [B] bit i: agent i needs its derived state rebuilt
   uint8_t* reset_full;             // [B] full-env reset pending
+  unsigned long long* dbg_ts;      // optional [grid][8] shader-clock timestamps at the phase boundaries (SIGMAENV_TIMESTAMPS=1)
 };
 
 // ---- scalar helpers ------------------------------------------------------------------------------------------------
@@ -123,6 +125,17 @@ __device__ __forceinline__ float point_segment(float px, float py, float sx, flo
   float t = clampf(proj, 0.0f, 1.0f);
   float cx = sx + lx * t, cy = sy + ly * t;
   return norm2(cx - px, cy - py);
+}
+
+// squared form: torch.norm == sqrt(fma(ey,ey,ex*ex)); sqrt is monotone and correctly rounded, so min_k sqrt(s_k) == sqrt(min_k s_k)
+// bit-for-bit, which lets the corner queries (value only, no index) defer the sqrt to after the reduction.
+__device__ __forceinline__ float point_segment_sq(float px, float py, float sx, float sy, float lx, float ly, float len2) {
+  float vx = px - sx, vy = py - sy;
+  float proj = (vx * lx + vy * ly) / len2;
+  float t = clampf(proj, 0.0f, 1.0f);
+  float cx = sx + lx * t, cy = sy + ly * t;
+  float ex = cx - px, ey = cy - py;
+  return fmaf(ey, ey, ex * ex);
 }
 
 // one rectangle edge against one polyline segment, helper_scenario.py:1165-1196
@@ -263,17 +276,48 @@ __device__ __forceinline__ void wave_argmin(float& d, int& k) {
   }
 }
 
-// counter-based RNG (specification shared with the oracle): splitmix64 finaliser over (seed, counter, env, agent, draw)
+// DPP lane permutations inside rows of 16 lanes (no LDS crossbar): quad_perm[1,0,3,2], quad_perm[2,3,0,1], row_half_mirror,
+// row_mirror.  Applying a commutative/associative combine over these four patterns leaves the full 16-lane result in every lane.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+__device__ __forceinline__ float row16_min(float v) {
+  v = fminf(v, dpp_f<0xB1>(v));
+  v = fminf(v, dpp_f<0x4E>(v));
+  v = fminf(v, dpp_f<0x141>(v));
+  v = fminf(v, dpp_f<0x140>(v));
+  return v;
+}
+#define SIGMA_ARGMIN_STEP(CTRL)                                   \
+  {                                                               \
+    float od = dpp_f<CTRL>(d);                                    \
+    int ok = dpp_i<CTRL>(k);                                      \
+    if (od < d || (od == d && ok < k)) { d = od; k = ok; }        \
+  }
+// lexicographic (distance, index) minimum over each row of 16 lanes
+__device__ __forceinline__ void row16_argmin(float& d, int& k) {
+  SIGMA_ARGMIN_STEP(0xB1)
+  SIGMA_ARGMIN_STEP(0x4E)
+  SIGMA_ARGMIN_STEP(0x141)
+  SIGMA_ARGMIN_STEP(0x140)
+}
+
+// counter-based RNG (specification shared with the oracle): 32-bit multiplicative mix + murmur3 finalisers over (seed, counter, env, agent, draw)
 __device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint64_t counter, uint32_t env, uint32_t agent, uint32_t draw) {
-  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (counter + 1);
-  z ^= ((uint64_t)env << 32) | ((uint64_t)agent << 16) | (uint64_t)draw;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (uint32_t)(z >> 32);
+  uint32_t h = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9E3779B9u);
+  h ^= ((uint32_t)counter + 0x7F4A7C15u) * 0x85EBCA6Bu;
+  h ^= (env + 0x165667B1u) * 0xC2B2AE35u;
+  h ^= (agent + 0x27D4EB2Fu) * 0x9E3779B1u;
+  h ^= (draw + 0x61C88647u) * 0x85EBCA77u;
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;   /* murmur3 fmix32, twice */
+  h += 0x9E3779B9u;
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
 }
 
 }  // namespace sigmadev
