@@ -1,0 +1,447 @@
+"""Host-side mirror of the reference's VMAS plugin surface, backed by the fused HIP step.
+
+Same names, argument meaning and error behaviour as the reference for THIS path, so that ``sigmarl/mappo_cavs.py`` can
+consume it as a drop-in (``scenario = ScenarioRoadTraffic(); scenario.parameters = parameters; VmasEnv(scenario=scenario, ...)``):
+
+  ScenarioRoadTraffic      <- sigmarl/scenarios/road_traffic.py:72   (make_world :104, reset_world_at :816, reward :925,
+                                                                       observation :1334, done :1368, info :1489)
+  WorldCustom              <- sigmarl/helper_training.py:791          (step :797 -> ONE fused launch: sigmaenv_step)
+  Vehicle / VehicleState   <- sigmarl/helper_common.py:290-430        (tensors are zero-copy views of the device state buffer)
+
+VMAS drives a scenario as ``world.step()`` then ``reward(a)`` for all agents, ``observation(a)`` for all agents, ``info(a)``,
+``done()`` (sigmarl's ``if agent_index == 0`` guards rely on that order).  Here ``world.step()`` runs the whole fused kernel
+(dynamics -> distances/collisions -> rewards -> observations -> done flags); the callbacks only hand out views of the results
+and ``done()`` performs the host-driven per-agent resets the reference performs there (RNG stays in torch, as in the reference).
+
+vmas itself is optional: when it is importable the classes derive from its base classes (so ``VmasEnv`` accepts them); in this
+build image it is absent and light stand-ins are used.  A CUDA/HIP device is mandatory -- there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import math
+import time
+from types import SimpleNamespace
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import capi
+from .env import SigmaEnv
+from .maps import load_map
+from .params import Parameters, make_config
+
+try:  # pragma: no cover - vmas is not installed in the build image
+    from vmas.simulator.scenario import BaseScenario as _VmasBaseScenario
+except Exception:  # noqa: BLE001
+    _VmasBaseScenario = None
+
+
+class _BaseScenarioStandIn:
+    """The slice of ``vmas.simulator.scenario.BaseScenario`` that VMAS' Environment calls."""
+
+    def __init__(self):
+        self._world = None
+
+    @property
+    def world(self):
+        return self._world
+
+    def env_make_world(self, batch_dim, device, **kwargs):
+        self._world = self.make_world(batch_dim, device, **kwargs)
+        return self._world
+
+    def env_reset_world_at(self, env_index):
+        self.world.reset(env_index)
+        self.reset_world_at(env_index)
+
+    def pre_step(self):
+        return
+
+    def post_step(self):
+        return
+
+    def env_process_action(self, agent):
+        return
+
+    def extra_render(self, env_index: int = 0):
+        return []
+
+
+BaseScenario = _VmasBaseScenario or _BaseScenarioStandIn
+
+AGENTS = capi.AGENTS
+
+
+class Box:
+    def __init__(self, length: float, width: float):
+        self.length, self.width = length, width
+
+
+class KinematicBicycleModel:
+    """Constants holder mirroring ``sigmarl/dynamics.py:11-60``; the integration itself runs inside the fused kernel."""
+
+    def __init__(self, **kw):
+        self.l_f, self.l_r = kw.get("l_f", AGENTS["l_f"]), kw.get("l_r", AGENTS["l_r"])
+        self.l_wb = self.l_f + self.l_r
+        for k in ("max_speed", "min_speed", "max_steering", "min_steering", "max_acc", "min_acc", "max_steering_rate", "min_steering_rate"):
+            setattr(self, k, kw.get(k, AGENTS[k]))
+        self.device = kw.get("device", "cuda")
+
+    @property
+    def needed_action_size(self) -> int:
+        return 2
+
+
+class _Action:
+    def __init__(self):
+        self.u = None  # None before the first step (road_traffic.py:1505, observation_provider_rt.py:948)
+
+
+class VehicleState:
+    """pos/rot/vel + speed/steering/sideslip_angle (helper_common.py:290-379) as views of ``SIGMAENV_BUF_STATE[:, i]``."""
+
+    def __init__(self, state_row: torch.Tensor):
+        self._s = state_row  # [B, 8] strided view: x, y, psi, speed, steering, vx, vy, sideslip
+
+    pos = property(lambda self: self._s[:, 0:2])
+    rot = property(lambda self: self._s[:, 2:3])
+    speed = property(lambda self: self._s[:, 3:4])
+    steering = property(lambda self: self._s[:, 4:5])
+    vel = property(lambda self: self._s[:, 5:7])
+    sideslip_angle = property(lambda self: self._s[:, 7:8])
+
+
+class Vehicle:
+    """``Vehicle(Agent)`` of helper_common.py:382-430.  Direct state writes do NOT refresh the derived tensors; go through
+    ``ScenarioRoadTraffic.reset_world_at`` / ``SigmaEnv.reset`` for that."""
+
+    def __init__(self, name, state_row, shape, u_range, max_speed, dynamics, color=None):
+        self.name = name
+        self.shape = shape
+        self.color = color
+        self.collide = False
+        self.render_action = False
+        self.u_range = u_range
+        self.u_multiplier = [1, 1]
+        self.max_speed = max_speed
+        self.dynamics = dynamics
+        self._state = VehicleState(state_row)
+        self._action = _Action()
+        self.batch_dim = state_row.shape[0]
+        self.device = state_row.device
+
+    @property
+    def state(self):
+        return self._state
+
+    @property
+    def action(self):
+        return self._action
+
+    def _set(self, view, value, batch_index):
+        value = torch.as_tensor(value, dtype=torch.float32, device=view.device)
+        if batch_index is None:
+            view.copy_(value.expand_as(view) if value.ndim < view.ndim or value.shape[0] != view.shape[0] else value)
+        else:
+            view[batch_index] = value
+
+    def set_pos(self, pos, batch_index=None):
+        self._set(self.state.pos, pos, batch_index)
+
+    def set_rot(self, rot, batch_index=None):
+        self._set(self.state.rot, rot, batch_index)
+
+    def set_vel(self, vel, batch_index=None):
+        self._set(self.state.vel, vel, batch_index)
+
+    def set_speed(self, speed, batch_index=None):
+        self._set(self.state.speed, speed, batch_index)
+
+    def set_steering(self, steering, batch_index=None):
+        self._set(self.state.steering, steering, batch_index)
+
+    def set_sideslip_angle(self, sideslip_angle, batch_index=None):
+        self._set(self.state.sideslip_angle, sideslip_angle, batch_index)
+
+
+class WorldCustom:
+    """``WorldCustom(World)`` of helper_training.py:791-861: ``step()`` is ONE fused HIP launch over agents x envs."""
+
+    def __init__(self, env: SigmaEnv, dt: float, x_semidim, y_semidim):
+        self._env = env
+        self.batch_dim = env.B
+        self.device = env.device
+        self.dt = dt
+        self.x_semidim, self.y_semidim = x_semidim, y_semidim
+        self._agents = []
+        self.parameters = None
+        self._actions = torch.zeros((env.B, env.N, 2), dtype=torch.float32, device=env.device)
+        self._scenario = None
+
+    @property
+    def agents(self):
+        return self._agents
+
+    @property
+    def entities(self):
+        return self._agents
+
+    @property
+    def policy_agents(self):
+        return self._agents
+
+    def add_agent(self, agent):
+        self._agents.append(agent)
+
+    def reset(self, env_index):
+        """VMAS zeroes the entity states here; the full reset (incl. that) happens in ``reset_world_at``."""
+        return
+
+    def step(self):
+        for i, a in enumerate(self._agents):
+            if a.action.u is None:
+                raise ValueError("agent.action.u is None: VMAS sets the actions before world.step()")
+            self._actions[:, i].copy_(a.action.u)
+        self._env.step(self._actions)
+        clamped = self._env.buffer(capi.BUF_ACTION)
+        for i, a in enumerate(self._agents):  # WorldCustom.step clamps entity.action.u in place (helper_training.py:807-818)
+            a.action.u = clamped[:, i]
+        if self._scenario is not None:
+            self._scenario._obs_dirty = False
+
+
+class ScenarioRoadTraffic(BaseScenario):
+    """Drop-in for ``sigmarl.scenarios.road_traffic.ScenarioRoadTraffic`` (callbacks :104-1635; rendering is out of scope)."""
+
+    def make_world(self, batch_dim: int, device, **kwargs):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("sigmarl_amd.ScenarioRoadTraffic runs on an MI355X only (device='cuda:<i>'); there is no CPU fallback")
+        if not hasattr(self, "parameters") or self.parameters is None:
+            self.parameters = Parameters(
+                n_agents=kwargs.pop("n_agents", 4), scenario_type=kwargs.get("scenario_type", "cpm_entire"),
+                dt=kwargs.pop("dt", 0.05), is_obs_noise=kwargs.pop("is_obs_noise", True), is_apply_mask=kwargs.pop("is_apply_mask", False),
+                is_use_mtv_distance=kwargs.pop("is_use_mtv_distance", False), is_testing_mode=kwargs.pop("is_testing_mode", False),
+            )
+        p = self.parameters
+        if "n_agents" in kwargs:  # VmasEnv(..., n_agents=...) forwards it (mappo_cavs.py:170-177)
+            p.n_agents = int(kwargs.pop("n_agents"))
+        make_world_scenario_type = kwargs.pop("scenario_type", "cpm_entire")  # the reference's normaliser quirk, see params.make_config
+        self.map = load_map(p.scenario_type)
+        if abs(float(p.lane_width) - self.map.parser_lane_width) > 1e-12 and "cpm" not in p.scenario_type:
+            raise NotImplementedError(
+                f"map table of {p.scenario_type!r} was parsed with lane_width={self.map.parser_lane_width}; Parameters.lane_width={p.lane_width} needs the map compiler (SURVEY.md 8f-2)")
+        self._noise = bool(p.is_obs_noise)
+        cfg = make_config(p, self.map, batch_dim, make_world_scenario_type)
+        self.env = SigmaEnv(cfg=cfg, map_table=self.map, device=device)
+        self.n_agents = p.n_agents
+        self.agent_width, self.agent_length = AGENTS["width"], AGENTS["length"]
+        self.max_speed = AGENTS["max_speed"]
+        self.max_steering = torch.tensor(AGENTS["max_steering"], device=device, dtype=torch.float32)
+        self.world_x_dim, self.world_y_dim = self.map.world_x_dim, self.map.world_y_dim
+        self.i_iter = 0
+        env = self.env
+        world = WorldCustom(env, p.dt, torch.tensor(self.world_x_dim, device=device), torch.tensor(self.world_y_dim, device=device))
+        world.parameters = p
+        world._scenario = self
+        state = env.buffer(capi.BUF_STATE)
+        for i in range(self.n_agents):
+            world.add_agent(Vehicle(
+                name=f"agent_{i}", state_row=state[:, i], shape=Box(AGENTS["length"], AGENTS["width"]),
+                u_range=[self.max_speed, self.max_steering], max_speed=self.max_speed, dynamics=KinematicBicycleModel(device=device)))
+        self._world = world
+        self._build_views()
+        self._obs_dirty = True
+        self.stored_observations = [None] * self.n_agents
+        self._lanelet_table = torch.zeros((self.map.n_paths, max(1, self.map.n_lanelets_all)), dtype=torch.int32, device=device)
+        ids = torch.as_tensor(self.map.lanelet_ids)
+        self._lanelet_table[:, : ids.shape[1]] = ids.to(device)
+        return world
+
+    # ---- views mirroring the attribute tree consumers read (helper_training.py:596-642, cbf_qp.py:1286-1395) --------------
+    def _build_views(self):
+        e, B, N, dev = self.env, self.env.B, self.env.N, self.env.device
+        cl = e.buffer(capi.BUF_CLOSEST)
+        pth = e.buffer(capi.BUF_PATH)
+        cf = e.buffer(capi.BUF_COL_FLAGS)
+        distances = SimpleNamespace(
+            type="mtv" if self.parameters.is_use_mtv_distance else "c2c", agents=e.buffer(capi.BUF_DIST_AGENTS),
+            left_boundaries=e.buffer(capi.BUF_DIST_LEFT), right_boundaries=e.buffer(capi.BUF_DIST_RIGHT),
+            boundaries=e.buffer(capi.BUF_DIST_BOUND), ref_paths=e.buffer(capi.BUF_DIST_REF),
+            closest_point_on_ref_path=cl[..., 0], closest_point_on_left_b=cl[..., 1], closest_point_on_right_b=cl[..., 2])
+        collisions = SimpleNamespace(
+            with_agents=e.buffer(capi.BUF_COL_AGENTS), with_lanelets=cf[..., 0], with_entry_segments=cf[..., 1], with_exit_segments=cf[..., 2])
+        ref_paths = SimpleNamespace(short_term=e.buffer(capi.BUF_SHORT_TERM), scenario_id=pth[..., 1], path_id=pth[..., 2], point_id=pth[..., 3])
+        act = e.buffer(capi.BUF_ACTION)
+        self.world_state = SimpleNamespace(
+            distances=distances, collisions=collisions, ref_paths_agent_related=ref_paths, vertices=e.buffer(capi.BUF_VERTICES), world=self._world,
+            nominal_action_vel=act[..., 0], nominal_action_steer=act[..., 1], applied_action_vel=act[..., 0], applied_action_steer=act[..., 1])
+        self.observation_provider = SimpleNamespace(observations=SimpleNamespace(nearing_agents_indices=e.buffer(capi.BUF_NEARING)))
+        ri = e.buffer(capi.BUF_REWARD_INFO)
+        self.reward_info = SimpleNamespace(**{name: ri[k] for k, name in enumerate(capi.REWARD_INFO_FIELDS)})
+        tm = e.buffer(capi.BUF_TIMER)
+        self.timer = SimpleNamespace(step=tm[:, 0], start=time.time(), end=0)
+        self.num_task_tries, self.task_success_times = tm[:, 1], tm[:, 2]
+        lw3 = float(self.env.cfg.lane_width) * 3
+        self.normalizers = SimpleNamespace(
+            pos=torch.tensor([self.agent_length * 10] * 2, device=dev), pos_world=torch.tensor([self.world_x_dim, self.world_y_dim], device=dev, dtype=torch.float32),
+            v=torch.tensor(self.max_speed, device=dev), rot=torch.tensor(2 * math.pi, device=dev), steering=self.max_steering,
+            distance_lanelet=torch.tensor(lw3, device=dev), distance_ref=torch.tensor(lw3, device=dev), distance_agent=torch.tensor(self.agent_length * 10, device=dev))
+        self.constants = SimpleNamespace(
+            empty_action_vel=torch.zeros((B, N), device=dev), empty_action_steering=torch.zeros((B, N), device=dev),
+            reset_agent_min_distance=torch.tensor(self.agent_length ** 2 + self.agent_width ** 2, dtype=torch.float32).sqrt() * 1.5)
+
+    # ---- reset (road_traffic.py:816-923; sampling restated from world_state_rt_sim.py:143-358, RNG = torch's global generator) --
+    def _scenario_lists(self, env_index, agent_index):
+        p = self.parameters
+        if p.scenario_type != "cpm_mixed":
+            return 0
+        if agent_index is not None:
+            return int(self.env.buffer(capi.BUF_PATH)[env_index, agent_index, 1].item())
+        probs = torch.tensor(p.cpm_scenario_probabilities, dtype=torch.float32)
+        return int(torch.multinomial(probs, 1, replacement=True).item()) + 1
+
+    def _sample_start(self, positions: np.ndarray, agent_index: int, list_id: int, single: bool):
+        """One agent's (path_id, point_id): the rejection loop of world_state_rt_sim.py:215-311 (draw order preserved)."""
+        mp, p = self.map, self.parameters
+        first, count = mp.list_first[list_id], mp.list_count[list_id]
+        min_d2 = float(self.constants.reset_agent_min_distance) ** 2
+        random_count, end_point_idx = 0, 3
+        while True:
+            random_count += 1
+            path_id = int(torch.randint(0, count, (1,)).item())
+            gp = first + path_id
+            num_points = int(mp.n_center[gp])
+            if p.is_testing_mode:
+                end_point_idx += random_count
+            else:
+                end_point_idx = int(num_points / 2)
+            end_point_idx = min(end_point_idx, int(num_points / 2))
+            point_id = int(torch.randint(3, end_point_idx, (1,)).item())
+            pos = mp.center[gp, point_id]
+            positions[agent_index] = pos
+            if not single and agent_index == 0:
+                return gp, path_id, point_id
+            others = positions[: agent_index + 1] if not single else positions
+            d2 = ((positions[agent_index] - others) ** 2).sum(-1).astype(np.float32)
+            d2[agent_index] = d2.max() + 1
+            if d2.min() >= min_d2:
+                return gp, path_id, point_id
+
+    def reset_world_at(self, env_index: Optional[int] = None, agent_index: Optional[int] = None):
+        p, env, mp, N = self.parameters, self.env, self.map, self.n_agents
+        if agent_index is not None:
+            assert env_index is not None
+            agent_index = int(agent_index)
+        if env_index is None:
+            if p.predefined_ref_path_idx is None:
+                if p.scenario_type == "cpm_mixed":
+                    for e in range(env.B):
+                        self.reset_world_at(e)
+                    return
+                # vectorised initial reset: the device-side sampler (same rule, counter-based RNG instead of torch's generator)
+                env.buffer(capi.BUF_DONE).fill_(1)
+                env.auto_reset(seed=int(getattr(p, "random_seed", 0)))
+                self._obs_dirty = False
+                return
+            envs = range(env.B)
+        else:
+            envs = [int(env_index)]
+        env_idx, agent_idx, ids, st8 = [], [], [], []
+        state_host = env.buffer(capi.BUF_STATE).cpu().numpy() if agent_index is not None else None
+        for e in envs:
+            list_id = self._scenario_lists(e, agent_index)
+            positions = np.zeros((N, 2), np.float32) if agent_index is None else state_host[e, :, 0:2].copy()
+            for i in (range(N) if agent_index is None else [agent_index]):
+                if agent_index is None and p.predefined_ref_path_idx is not None:  # deterministic start (world_state_rt_sim.py:99-126)
+                    path_id = int(p.predefined_ref_path_idx[i])
+                    gp = mp.list_first[list_id] + path_id
+                    x, y, rot = [float(v) for v in p.init_state[i][0:3]]
+                    point_id, speed = 0, 0.0
+                else:
+                    gp, path_id, point_id = self._sample_start(positions, i, list_id, agent_index is not None)
+                    x, y = [float(v) for v in mp.center[gp, point_id]]
+                    rot = float(mp.yaw[gp, min(point_id, int(mp.n_yaw[gp]) - 1)])
+                    speed = float(torch.rand(1, dtype=torch.float32).item() * self.max_speed)
+                rot32, sp32 = np.float32(rot), np.float32(speed)
+                vx = np.float32(sp32 * np.float32(math.cos(float(rot32))))
+                vy = np.float32(sp32 * np.float32(math.sin(float(rot32))))
+                env_idx.append(e); agent_idx.append(i)
+                ids.append((gp, list_id, path_id, point_id))
+                st8.append((x, y, rot32, sp32, 0.0, vx, vy, 0.0))
+        env.reset(env_idx, agent_idx, np.asarray(ids, np.int32), np.asarray(st8, np.float32), full_env=agent_index is None)
+        self._obs_dirty = True
+
+    # ---- callbacks -------------------------------------------------------------------------------------------------
+    def _index(self, agent) -> int:
+        return self.world.agents.index(agent)
+
+    def reward(self, agent):
+        """[B] fp32, already computed by the fused step (road_traffic.py:925-1253)."""
+        return self.env.reward[:, self._index(agent)]
+
+    def observation(self, agent):
+        """[B, obs_dim] fp32 (road_traffic.py:1334-1366); uniform noise as observation_provider_rt.py:613-618 when enabled."""
+        i = self._index(agent)
+        if i == 0 and self._obs_dirty:
+            self.env.observe()
+            self._obs_dirty = False
+        obs = self.env.obs[:, i]
+        if self._noise:
+            obs = obs + float(self.parameters.obs_noise_level) * torch.rand_like(obs)
+        self.stored_observations[i] = obs
+        return obs
+
+    def done(self):
+        """[B] bool (road_traffic.py:1368-1487) + the per-agent resets the reference performs here (:1435-1447, :1456-1473)."""
+        is_done = self.env.done.to(torch.bool)
+        if self.parameters.is_testing_mode or self.parameters.scenario_type != "cpm_entire":
+            req = self.env.buffer(capi.BUF_COL_FLAGS)[..., 3]
+            if bool(req.any()):
+                idx = torch.nonzero(req).cpu().tolist()
+                for e, a in idx:
+                    self.reset_world_at(env_index=e, agent_index=a)
+        return is_done
+
+    def info(self, agent) -> Dict[str, torch.Tensor]:
+        """The 27 + 12 entries of road_traffic.py:1489-1635."""
+        i = self._index(agent)
+        ws, nz, B = self.world_state, self.normalizers, self.env.B
+        st = agent.state
+        two_pi = 2 * math.pi
+        rot = st.rot % two_pi
+        rot = torch.where(rot > math.pi, rot - two_pi, rot)  # angle_eliminate_two_pi, helper_scenario.py:1276-1289
+        empty = agent.action.u is None
+        act_v = self.constants.empty_action_vel[:, i] if empty else agent.action.u[:, 0]
+        act_s = self.constants.empty_action_steering[:, i] if empty else agent.action.u[:, 1]
+        short = ws.ref_paths_agent_related.short_term[:, i]
+        dl = ws.distances.left_boundaries[:, i].min(dim=-1)[0]
+        dr = ws.distances.right_boundaries[:, i].min(dim=-1)[0]
+        gp = self.env.buffer(capi.BUF_PATH)[:, i, 0].long()
+        info = {
+            "pos": st.pos, "pos_nom": st.pos / nz.pos_world, "rot": rot, "rot_nom": rot / nz.rot,
+            "vel": st.vel, "vel_nom": st.vel / nz.v,
+            "act_vel": act_v, "act_vel_nom": act_v if empty else act_v / nz.v,
+            "act_steer": act_s, "act_steer_nom": act_s if empty else act_s / nz.steering,
+            "ref": short.reshape(B, -1), "ref_nom": (short / nz.pos_world).reshape(B, -1),
+            "distance_ref": ws.distances.ref_paths[:, i], "distance_ref_nom": ws.distances.ref_paths[:, i] / nz.distance_ref,
+            "distance_left_b": dl, "distance_left_b_nom": dl / nz.distance_lanelet,
+            "distance_right_b": dr, "distance_right_b_nom": dr / nz.distance_lanelet,
+            "is_collision_with_agents": ws.collisions.with_agents[:, i].to(torch.bool).any(dim=-1),
+            "is_collision_with_lanelets": ws.collisions.with_lanelets[:, i].to(torch.bool),
+            "is_reach_goal": ws.collisions.with_exit_segments[:, i].to(torch.bool),
+            "ref_lanelet_ids": self._lanelet_table[gp], "path_id": ws.ref_paths_agent_related.path_id[:, i],
+            "applied_action_vel": ws.applied_action_vel[:, i], "applied_action_steer": ws.applied_action_steer[:, i],
+            "nominal_action_vel": ws.nominal_action_vel[:, i], "nominal_action_steer": ws.nominal_action_steer[:, i],
+        }
+        for name in capi.REWARD_INFO_FIELDS:
+            info[name] = getattr(self.reward_info, name)[:, i]
+        return info
+
+
+def make_scenario(parameters: Parameters) -> ScenarioRoadTraffic:
+    """``scenario = ScenarioRoadTraffic(); scenario.parameters = parameters`` as mappo_cavs.py:168-169 does."""
+    sc = ScenarioRoadTraffic()
+    sc.parameters = parameters
+    return sc

@@ -1,0 +1,151 @@
+"""The VMAS-surface mirror (sigmarl_amd.scenario) driven in the VMAS call order on an MI355X."""
+import numpy as np
+import pytest
+
+import traj_replay as tr
+from sigmarl_amd import capi
+from sigmarl_amd.params import Parameters
+
+pytestmark = pytest.mark.gpu
+
+INFO_KEYS = [
+    "pos", "pos_nom", "rot", "rot_nom", "vel", "vel_nom", "act_vel", "act_vel_nom", "act_steer", "act_steer_nom", "ref", "ref_nom",
+    "distance_ref", "distance_ref_nom", "distance_left_b", "distance_left_b_nom", "distance_right_b", "distance_right_b_nom",
+    "is_collision_with_agents", "is_collision_with_lanelets", "is_reach_goal", "ref_lanelet_ids", "path_id", "applied_action_vel",
+    "applied_action_steer", "nominal_action_vel", "nominal_action_steer",
+] + list(capi.REWARD_INFO_FIELDS)
+
+
+def _vmas_step(sc, actions):
+    """What vmas.Environment.step does with a scenario (>= 1.4 order)."""
+    import torch
+
+    world = sc.world
+    for i, a in enumerate(world.agents):
+        u = actions[:, i].clone()
+        rng = torch.tensor([float(a.u_range[0]), float(a.u_range[1])], device=u.device)
+        a.action.u = u.clamp(-rng, rng)
+    sc.pre_step()
+    world.step()
+    sc.post_step()
+    rew = [sc.reward(a).clone() for a in world.agents]
+    obs = [sc.observation(a).clone() for a in world.agents]
+    info = [{k: v.clone() for k, v in sc.info(a).items()} for a in world.agents]
+    done = sc.done().clone()
+    return obs, rew, done, info
+
+
+def test_surface_shapes_and_info_keys():
+    import torch
+    from sigmarl_amd.scenario import make_scenario
+
+    B, N = 32, 16
+    p = Parameters(n_agents=N, scenario_type="cpm_entire", is_use_mtv_distance=False, is_apply_mask=False, is_obs_noise=False, num_vmas_envs=B)
+    sc = make_scenario(p)
+    world = sc.env_make_world(B, "cuda:0", n_agents=N)
+    assert world.batch_dim == B and len(world.agents) == N and world.parameters is p
+    sc.env_reset_world_at(None)
+    a0 = world.agents[0]
+    assert a0.action.u is None
+    obs0 = sc.observation(a0)
+    assert obs0.shape == (B, 32) and obs0.dtype == torch.float32
+    info0 = sc.info(a0)  # callable before the first step (road_traffic.py:1505)
+    assert list(info0.keys()) == INFO_KEYS and len(INFO_KEYS) == 39
+    assert a0.state.pos.shape == (B, 2) and a0.state.rot.shape == (B, 1) and a0.state.speed.shape == (B, 1)
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    for _ in range(5):
+        act = torch.rand((B, N, 2), generator=gen, device="cuda") * torch.tensor([1.3, 1.4], device="cuda") - torch.tensor([0.1, 0.7], device="cuda")
+        obs, rew, done, info = _vmas_step(sc, act)
+        assert done.dtype == torch.bool and done.shape == (B,)
+        assert rew[3].shape == (B,) and obs[3].shape == (B, 32)
+        assert info[3]["ref_lanelet_ids"].shape == (B, 104) and info[3]["ref"].shape == (B, 6)
+        # WorldCustom.step clamps the action in place (helper_training.py:807-818)
+        assert float(a0.action.u[:, 0].abs().max()) <= 1.0 + 1e-6
+        assert torch.equal(info[3]["act_vel"], world.agents[3].action.u[:, 0])
+        for e in torch.nonzero(done).flatten().tolist():  # what TorchRL's step_and_maybe_reset does
+            sc.env_reset_world_at(e)
+    st = sc.env.state
+    assert torch.isfinite(st).all()
+    # the views really alias the device buffers
+    assert world.agents[5].state.pos.data_ptr() == st[:, 5, 0:2].data_ptr()
+    sc.env.close()
+
+
+def test_scenario_matches_plain_env_on_golden_prefix():
+    """Golden initial state injected through the scenario's env; stepping through the VMAS surface reproduces the reference."""
+    import torch
+    from sigmarl_amd.scenario import make_scenario
+
+    z, meta = tr.load_fixture("cpm16_c2c_noreset")
+    p = tr.params_from_meta(meta)
+    sc = make_scenario(p)
+    sc.env_make_world(meta["B"], "cuda:0", n_agents=meta["n_agents"])
+    from sigmarl_amd.env import NumpyAdapter
+
+    tr.apply_initial_reset(NumpyAdapter(sc.env), z, sc.map)
+    for t in range(12):
+        act = torch.as_tensor(z["act"][t]).cuda()
+        obs, rew, done, info = _vmas_step(sc, act)
+        assert np.abs(torch.stack(rew, 1).cpu().numpy() - z["post_reward"][t]).max() <= 1e-5
+        assert np.abs(torch.stack(obs, 1).cpu().numpy() - z["post_obs"][t]).max() <= 1e-5
+        assert np.array_equal(done.cpu().numpy(), z["done"][t])
+        rot = torch.stack([i["rot"] for i in info], 1).squeeze(-1).cpu().numpy()
+        assert np.abs(rot - z["post_info_rot"][t]).max() <= 1e-5
+        dl = torch.stack([i["distance_left_b"] for i in info], 1).cpu().numpy()
+        assert np.abs(dl - z["post_info_distance_left_b"][t]).max() <= 1e-5
+        tot = torch.stack([i["rew_total"] for i in info], 1).cpu().numpy()
+        assert np.abs(tot - z["post_info_rew_total"][t]).max() <= 1e-5  # RewardInfo.reset quirk: only the last agent's entry survives
+    sc.env.close()
+
+
+@pytest.mark.parametrize("scen,N,testing", [("intersection_1", 4, False), ("on_ramp_1", 4, False), ("cpm_entire", 4, True)])
+def test_host_driven_agent_resets(scen, N, testing):
+    """Non-loop maps / testing mode: done() performs the per-agent resets (torch RNG) the reference performs there.
+    Agents are injected just before the end of their path (non-loop maps) or straight at a lane boundary (testing mode) so that
+    the reset requests fire within a few steps."""
+    import torch
+    from sigmarl_amd.scenario import make_scenario
+
+    torch.manual_seed(0)
+    B = 4
+    p = Parameters(n_agents=N, scenario_type=scen, is_use_mtv_distance=False, is_apply_mask=False, is_obs_noise=False, is_testing_mode=testing,
+                   dt=0.1, max_steps=1000)
+    sc = make_scenario(p)
+    world = sc.env_make_world(B, "cuda:0", n_agents=N)
+    sc.env_reset_world_at(None)
+    mp = sc.map
+    ids, st = [], []
+    for b in range(B):
+        for i in range(N):
+            gp = mp.list_first[0] + (i % mp.list_count[0])
+            n = int(mp.n_center[gp])
+            k = (n - 4) if not testing else 10 + 12 * i
+            x, y = mp.center[gp, k]
+            yaw = float(mp.yaw[gp, min(k, int(mp.n_yaw[gp]) - 1)]) + (0.9 if testing else 0.0)
+            ids.append((gp, 0, gp - mp.list_first[0], k))
+            st.append((x, y, yaw, 0.8, 0.0, 0.8 * np.cos(yaw), 0.8 * np.sin(yaw), 0.0))
+    sc.env.reset(np.repeat(np.arange(B), N), np.tile(np.arange(N), B), np.asarray(ids, np.int32), np.asarray(st, np.float32), True)
+    sc._obs_dirty = True
+    calls = []
+    orig = sc.reset_world_at
+
+    def counting(env_index=None, agent_index=None):
+        if agent_index is not None:
+            calls.append((int(env_index), int(agent_index)))
+        return orig(env_index=env_index, agent_index=agent_index)
+
+    sc.reset_world_at = counting
+    obs = [sc.observation(a) for a in world.agents]
+    act = torch.zeros((B, N, 2), device="cuda")
+    act[..., 0] = 1.0
+    for t in range(12):
+        obs, rew, done, info = _vmas_step(sc, act)
+        for e in torch.nonzero(done).flatten().tolist():
+            sc.env_reset_world_at(e)
+        obs = [sc.observation(a) for a in world.agents]
+        assert torch.isfinite(torch.stack(obs, 1)).all()
+    assert len(calls) > 0, "no per-agent reset was exercised"
+    assert torch.isfinite(sc.env.state).all()
+    # every reset (and every step) leaves prev_pos == pos (state_buffer semantics, road_traffic.py:902-923,1226-1240)
+    assert torch.equal(sc.env.buffer(capi.BUF_PREV_POS), sc.env.state[..., 0:2])
+    sc.env.close()
