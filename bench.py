@@ -49,7 +49,7 @@ def cpu_baseline(params_kw, n_envs, target_seconds):
     rng = np.random.default_rng(0)
     N = cfg.n_agents
     acts = [np.stack([rng.uniform(0, 1, (n_envs, N)), rng.uniform(-0.25, 0.25, (n_envs, N))], axis=-1).astype(np.float32) for _ in range(8)]
-    env.step(acts[0])  # warm-up
+    env.step(acts[0])  # warm-up (also spins the OpenMP team up)
     env.auto_reset(0, 1, pf, pc)
     t0 = time.perf_counter()
     k = 0
@@ -178,7 +178,7 @@ def main():
     }
     if rank == 0:
         if args.cpu_seconds > 0 and world == 1:
-            out["cpu_baseline"] = cpu_baseline(params_kw, 256, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(params_kw, B, args.cpu_seconds)
         print(json.dumps(out))
     env.close()
     if world > 1:
