@@ -32,8 +32,10 @@ __device__ __constant__ uint32_t W_REF_BITS[3] = {0x3F0E38E3u, 0x3EAAAAABu, 0x3D
 // ---------------------------------------------------------------------------------------------------------------------
 // LDS carve-up for one workgroup: S = G*N agent slots (slot = env_local * N + agent)
 // ---------------------------------------------------------------------------------------------------------------------
+#define DIST_STRIDE(N) ((N) + 1)   /* odd float stride: lane-per-row column walks are bank-conflict free */
+#define COL_STRIDE(N) ((N) + 4)    /* byte stride whose word stride ((N+4)/4) is odd for N = 16 */
 struct Smem {
-  float *st, *vold, *vnew, *shrt, *dref, *dleft, *dright, *dbound, *dist, *obs, *thr;
+  float *st, *vold, *vnew, *shrt, *dref, *dleft, *dright, *dbound, *dist, *obs, *thr, *cs;
   int *path, *cp, *near, *flags, *npts;
   uint8_t* col;
   __device__ Smem(char* base, int S, int N, int K, int D) {
@@ -46,9 +48,10 @@ struct Smem {
     dleft = f; f += S * 5;
     dright = f; f += S * 5;
     dbound = f; f += S;
-    dist = f; f += S * N;
+    dist = f; f += S * DIST_STRIDE(N);
     obs = f; f += S * D;
     thr = f; f += S * 3;   // pruning thresholds of the centre / left / right scan
+    cs = f; f += S * 2;    // cos / sin of the yaw (shared by the vertices and the ego-view transforms)
     int* i = reinterpret_cast<int*>(f);
     path = i; i += S;
     cp = i; i += S * 3;
@@ -58,9 +61,9 @@ struct Smem {
     col = reinterpret_cast<uint8_t*>(i);
   }
   __host__ __device__ static size_t bytes(int S, int N, int K, int D) {
-    size_t f = (size_t)S * 8 + S * 10 * 2 + S * NS * 2 + S + S * 5 * 2 + S + (size_t)S * N + (size_t)S * D + S * 3;
+    size_t f = (size_t)S * 8 + S * 10 * 2 + S * NS * 2 + S + S * 5 * 2 + S + (size_t)S * DIST_STRIDE(N) + (size_t)S * D + S * 3 + S * 2;
     size_t i = (size_t)S + S * 3 + S * (K > 0 ? K : 1) + S * 4 + S * 3;
-    return (f + i) * 4 + (size_t)S * N + 16;
+    return (f + i) * 4 + (size_t)S * COL_STRIDE(N) + 16;
   }
 };
 
@@ -390,8 +393,11 @@ __device__ inline void observe_tile(const sigmaenv_config_t& c, const Smem& s, c
   const float n_pos = (float)((double)c.length * 10.0);   // normalizers.pos, road_traffic.py:588-592
   const float n_v = c.max_speed;                            // :596
   const float n_dl = (float)((double)c.lane_width * 3.0);   // :599-601 (distance_lanelet also normalises the agent distances)
-  for (int sl = threadIdx.x; sl < t.slots; sl += blockDim.x) topk_nearest(s.dist + sl * N, N, K, s.near + sl * K);
+  for (int sl = threadIdx.x; sl < t.slots; sl += blockDim.x) topk_nearest(s.dist + sl * DIST_STRIDE(N), N, K, s.near + sl * K);
   __syncthreads();
+  // The reference goes through atan2 / cos / sin (helper_scenario.py:1261-1271); the same rotation is applied here with the
+  // agent's cos(psi), sin(psi) (already needed for the vertices): rel = R(-psi_i) (p_j - p_i).  Identical up to ~1e-7, well inside
+  // the 1e-5 bar; no mask or index depends on it.  The oracle keeps the reference's formulation.
   const int T1 = NS + 4 * K;
   for (int w = threadIdx.x; w < t.slots * T1; w += blockDim.x) {
     int sl = w / T1, q = w - sl * T1;
@@ -408,27 +414,26 @@ __device__ inline void observe_tile(const sigmaenv_config_t& c, const Smem& s, c
       tx = s.vnew[sj * 10 + 2 * v]; ty = s.vnew[sj * 10 + 2 * v + 1];
       pos = 4 + 2 * NS + 11 * k + 2 * v;
     }
-    float ox, oy;
-    ego_transform(si[0], si[1], si[2], tx, ty, ox, oy);
-    s.obs[sl * D + pos] = ox / n_pos;
-    s.obs[sl * D + pos + 1] = oy / n_pos;
+    float dx = tx - si[0], dy = ty - si[1];
+    float ci = s.cs[sl * 2], sn = s.cs[sl * 2 + 1];
+    s.obs[sl * D + pos] = (dx * ci + dy * sn) / n_pos;
+    s.obs[sl * D + pos + 1] = (dy * ci - dx * sn) / n_pos;
   }
   const int T2 = K + 1;
   for (int w = threadIdx.x; w < t.slots * T2; w += blockDim.x) {
     int sl = w / T2, q = w - sl * T2;
     int ebase = (sl / N) * N;
-    const float* si = s.st + sl * 8;
     int sj = (q == 0) ? sl : (ebase + s.near[sl * K + (q - 1)]);
     const float* sjp = s.st + sj * 8;
-    float rr = angle_eliminate_two_pi(sjp[2] - si[2]);    // :439
     float va = norm2(sjp[5], sjp[6]);                      // :444
-    float vx = (va * cr_cos(rr)) / n_v, vy = (va * cr_sin(rr)) / n_v;  // :447-449, :503
+    float ci = s.cs[sl * 2], si_ = s.cs[sl * 2 + 1], cj = s.cs[sj * 2], sj_ = s.cs[sj * 2 + 1];
+    float cr = cj * ci + sj_ * si_, sr = sj_ * ci - cj * si_;   // cos / sin of (psi_j - psi_i) (:439, :447-449)
     if (q == 0) {
-      s.obs[sl * D] = vx;  // [own] only the longitudinal component is observed (:864-868, :885-887)
+      s.obs[sl * D] = va / n_v;  // [own] only the longitudinal component is observed; cos(0) = 1 (:864-868, :885-887)
     } else {
       int base = 4 + 2 * NS + 11 * (q - 1);
-      s.obs[sl * D + base + 8] = vx;
-      s.obs[sl * D + base + 9] = vy;
+      s.obs[sl * D + base + 8] = (va * cr) / n_v;
+      s.obs[sl * D + base + 9] = (va * sr) / n_v;
     }
   }
   for (int sl = threadIdx.x; sl < t.slots; sl += blockDim.x) {
@@ -438,7 +443,7 @@ __device__ inline void observe_tile(const sigmaenv_config_t& c, const Smem& s, c
     s.obs[sl * D + 1 + 2 * NS] = s.dref[sl] / n_dl;        // :376-378, :898-904
     s.obs[sl * D + 2 + 2 * NS] = ml / n_dl;                // :379-382
     s.obs[sl * D + 3 + 2 * NS] = mr / n_dl;                // :383-386
-    for (int k = 0; k < K; ++k) s.obs[sl * D + 4 + 2 * NS + 11 * k + 10] = s.dist[sl * N + s.near[sl * K + k]] / n_dl;  // :373-375
+    for (int k = 0; k < K; ++k) s.obs[sl * D + 4 + 2 * NS + 11 * k + 10] = s.dist[sl * DIST_STRIDE(N) + s.near[sl * K + k]] / n_dl;  // :373-375
   }
   __syncthreads();
   for (int k = threadIdx.x; k < t.slots * D; k += blockDim.x) g.obs[t.a0 * D + k] = s.obs[k];
@@ -480,7 +485,7 @@ __global__ void __launch_bounds__(256) sigmaenv_step_kernel(sigmaenv_config_t c,
 #pragma unroll
     for (int k = 0; k < 5; ++k) { float2 vv = gv[k]; s.vold[sl * 10 + 2 * k] = vv.x; s.vold[sl * 10 + 2 * k + 1] = vv.y; }
     float v[10];
-    rect_vertices(c, st[0], st[1], st[2], v);
+    rect_vertices(c, st[0], st[1], st[2], v, &s.cs[sl * 2]);
     float2* gvo = reinterpret_cast<float2*>(g.vertices + gi * 10);
 #pragma unroll
     for (int k = 0; k < 5; ++k) { s.vnew[sl * 10 + 2 * k] = v[2 * k]; s.vnew[sl * 10 + 2 * k + 1] = v[2 * k + 1]; gvo[k] = make_float2(v[2 * k], v[2 * k + 1]); }
@@ -499,7 +504,7 @@ __global__ void __launch_bounds__(256) sigmaenv_step_kernel(sigmaenv_config_t c,
     int si = p / N, j = p - si * N;
     int sj = (si / N) * N + j;
     float d = (si == sj) ? diag : pair_distance(c, s.st, s.vold, si, sj);
-    s.dist[p] = d;
+    s.dist[si * DIST_STRIDE(N) + j] = d;
     g.dist_agents[t.a0 * N + p] = d;
     uint8_t col = 0;
     if (c.distance_type == SIGMAENV_DIST_C2C) {
@@ -510,7 +515,7 @@ __global__ void __launch_bounds__(256) sigmaenv_step_kernel(sigmaenv_config_t c,
     } else {
       col = (d == 0.0f) ? 1 : 0;  // :394-396
     }
-    s.col[p] = col;
+    s.col[si * COL_STRIDE(N) + j] = col;
     g.col_agents[t.a0 * N + p] = col;
   }
 
@@ -581,7 +586,7 @@ __global__ void __launch_bounds__(256) sigmaenv_step_kernel(sigmaenv_config_t c,
         s.dbound[sl] = mbnd;
       }
       float reward_goal = (float)goal * c.reward_reach_goal;
-      for (int j = 0; j < N; ++j) col_a |= s.col[sl * N + j];        // :1008-1013
+      for (int j = 0; j < N; ++j) col_a |= s.col[sl * COL_STRIDE(N) + j];        // :1008-1013
       float pca = (float)col_a * c.penalty_collide_with_agents;
       col_l = s.flags[sl * 4 + 0];
       float pcl = (float)col_l * c.penalty_collide_with_boundaries;  // :1021-1026
@@ -600,7 +605,7 @@ __global__ void __launch_bounds__(256) sigmaenv_step_kernel(sigmaenv_config_t c,
         }
         if (c.rew_flags & SIGMAENV_REW_DISTANCE) {                   // :1086-1110
           float ssum = 0.0f;
-          for (int j = 0; j < N; ++j) ssum += decreasing_lin(s.dist[sl * N + j], c.threshold_near_other_agents_low, c.threshold_near_other_agents_high);
+          for (int j = 0; j < N; ++j) ssum += decreasing_lin(s.dist[sl * DIST_STRIDE(N) + j], c.threshold_near_other_agents_low, c.threshold_near_other_agents_high);
           float p = ssum * c.penalty_near_other_agents;
           near_other = p; has_near = true;
           rew += p; rew += pen_lane;
@@ -672,7 +677,12 @@ __device__ inline void load_tile_for_observation(const Smem& s, const DevBufs& g
   for (int k = threadIdx.x; k < t.slots * NS * 2; k += blockDim.x) s.shrt[k] = g.short_term[t.a0 * NS * 2 + k];
   for (int k = threadIdx.x; k < t.slots; k += blockDim.x) s.dref[k] = g.dist_ref[t.a0 + k];
   for (int k = threadIdx.x; k < t.slots * 5; k += blockDim.x) { s.dleft[k] = g.dist_left[t.a0 * 5 + k]; s.dright[k] = g.dist_right[t.a0 * 5 + k]; }
-  for (int k = threadIdx.x; k < t.slots * N; k += blockDim.x) s.dist[k] = g.dist_agents[t.a0 * N + k];
+  for (int k = threadIdx.x; k < t.slots * N; k += blockDim.x) s.dist[(k / N) * DIST_STRIDE(N) + (k % N)] = g.dist_agents[t.a0 * N + k];
+  for (int k = threadIdx.x; k < t.slots; k += blockDim.x) {
+    float psi = g.state[(t.a0 + k) * 8 + 2];
+    s.cs[k * 2] = cr_cos(psi);
+    s.cs[k * 2 + 1] = cr_sin(psi);
+  }
   __syncthreads();
 }
 
@@ -711,7 +721,7 @@ __device__ inline void reset_derive_body(const sigmaenv_config_t& c, const DevMa
     int e = sl / N, i = sl - e * N;
     if ((agent_mask[e] >> i) & 1ull) {
       float v[10];
-      rect_vertices(c, s.st[sl * 8], s.st[sl * 8 + 1], s.st[sl * 8 + 2], v);
+      rect_vertices(c, s.st[sl * 8], s.st[sl * 8 + 1], s.st[sl * 8 + 2], v, &s.cs[sl * 2]);
 #pragma unroll
       for (int k = 0; k < 10; ++k) { s.vnew[sl * 10 + k] = v[k]; g.vertices[(t.a0 + sl) * 10 + k] = v[k]; }
       if (m.nch > 0) scan_prepare<false>(m, s, sl, false);
@@ -759,7 +769,7 @@ __device__ inline void reset_derive_body(const sigmaenv_config_t& c, const DevMa
     float sp[NS * 2];
     short_term_path(m.center + (size_t)path * m.P * 2, m.n_center[path], m.is_loop[path] != 0, s.cp[sl * 3], sp);
 #pragma unroll
-    for (int k = 0; k < NS * 2; ++k) g.short_term[gi * NS * 2 + k] = sp[k];
+    for (int k = 0; k < NS * 2; ++k) { g.short_term[gi * NS * 2 + k] = sp[k]; s.shrt[sl * NS * 2 + k] = sp[k]; }
   }
   // tail of every touched env: mutual distances, collisions cleared, prev_pos := pos, timer
   const float diag = sqrtf(c.world_x_dim * c.world_x_dim + c.world_y_dim * c.world_y_dim);
@@ -769,6 +779,7 @@ __device__ inline void reset_derive_body(const sigmaenv_config_t& c, const DevMa
     if (agent_mask[e] == 0ull) continue;
     int sj = e * N + j;
     float d = (si == sj) ? diag : pair_distance(c, s.st, s.vnew, si, sj);
+    s.dist[si * DIST_STRIDE(N) + j] = d;
     g.dist_agents[t.a0 * N + p] = d;
     g.col_agents[t.a0 * N + p] = 0;
   }
@@ -789,7 +800,8 @@ __device__ inline void reset_derive_body(const sigmaenv_config_t& c, const DevMa
   if (with_obs) {
     __threadfence_block();
     __syncthreads();
-    load_tile_for_observation(s, g, t);
+    // with every agent of the tile marked (device-side full-env reset) all inputs of the observation are already in LDS
+    if (with_obs != 2) load_tile_for_observation(s, g, t);
     observe_tile(c, s, g, t);
   }
 }
@@ -797,7 +809,7 @@ __device__ inline void reset_derive_body(const sigmaenv_config_t& c, const DevMa
 #define MAX_G 64
 
 // host-driven resets: only tiles with marked agents do work
-__global__ void __launch_bounds__(256) sigmaenv_reset_derive_kernel(sigmaenv_config_t c, DevMap m, DevBufs g, int with_obs, int G) {
+__global__ void __launch_bounds__(512) sigmaenv_reset_derive_kernel(sigmaenv_config_t c, DevMap m, DevBufs g, int with_obs, int G) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const Tile t(c, G);
   const int N = t.N;
@@ -831,7 +843,7 @@ __global__ void __launch_bounds__(256) sigmaenv_reset_derive_kernel(sigmaenv_con
 // rejection sampler of world_state_rt_sim.py:215-311 (non-testing mode) from a counter-based RNG: the 64 lanes evaluate tries
 // 0..63 of one agent at once and the FIRST feasible try wins, which is exactly the sequential loop's result for the same draws
 // (bounded to 64 tries; the reference loops without bound).  Then the deterministic reset as in sigmaenv_reset(full_env=1).
-__global__ void __launch_bounds__(256) sigmaenv_auto_reset_kernel(sigmaenv_config_t c, DevMap m, DevBufs g, uint64_t seed, uint64_t counter,
+__global__ void __launch_bounds__(512) sigmaenv_auto_reset_kernel(sigmaenv_config_t c, DevMap m, DevBufs g, uint64_t seed, uint64_t counter,
                                                                   int path_first, int path_count, int G) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const Tile t(c, G);
@@ -926,7 +938,7 @@ __global__ void __launch_bounds__(256) sigmaenv_auto_reset_kernel(sigmaenv_confi
   }
   __threadfence_block();
   __syncthreads();
-  reset_derive_body(c, m, g, s, t, s_mask, s_full, 1);
+  reset_derive_body(c, m, g, s, t, s_mask, s_full, (G == 1) ? 2 : 1);
 }
 
 // =====================================================================================================================
@@ -942,6 +954,7 @@ struct sigmaenv {
   std::vector<void*> allocs;
   size_t smem_bytes = 0;
   int block = 256;
+  int reset_block = 256;
   int G = 1;      // environments per workgroup (G * N <= 64 agent slots)
   int dbg_skip = 0;  // SIGMAENV_DEBUG_SKIP: phase-ablation bit mask for profiling experiments (results invalid when non-zero)
   int grid = 1;
@@ -1148,6 +1161,11 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
   }
   if (const char* e = getenv("SIGMAENV_DEBUG_SKIP")) h->dbg_skip = atoi(e);
   h->grid = (B + h->G - 1) / h->G;
+  h->reset_block = 256;  // measured at 16 x 4096: 512-thread reset workgroups are slower (more early-exit launch cost, lower occupancy)
+  if (const char* e = getenv("SIGMAENV_RESET_BLOCK")) {
+    int v = atoi(e);
+    if (v >= 64 && v <= 512 && v % 64 == 0) h->reset_block = v;
+  }
   h->smem_bytes = ((Smem::bytes(h->G * N, N, K, h->D) + 15) & ~(size_t)15) + MAX_G * 8 + MAX_G * 4 + 16;
   if (h->smem_bytes > 64 * 1024) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem_bytes);
@@ -1162,7 +1180,7 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
 
 static int launch_derive(sigmaenv* h, int with_obs) {
   // resets touch few envs: one env per workgroup (G = 1) keeps the untouched ones out of the way
-  hipLaunchKernelGGL(sigmaenv_reset_derive_kernel, dim3(h->B), dim3(h->block), h->smem_bytes, h->stream, h->cfg, h->map, h->buf, with_obs, 1);
+  hipLaunchKernelGGL(sigmaenv_reset_derive_kernel, dim3(h->B), dim3(h->reset_block), h->smem_bytes, h->stream, h->cfg, h->map, h->buf, with_obs, 1);
   HIPCHK(h, hipGetLastError());
   return SIGMAENV_OK;
 }
@@ -1237,7 +1255,7 @@ extern "C" int sigmaenv_observe(sigmaenv_t* h) {
 
 extern "C" int sigmaenv_auto_reset(sigmaenv_t* h, uint64_t seed, uint64_t counter, int32_t path_first, int32_t path_count) {
   if (!h || path_first < 0 || path_count < 1 || path_first + path_count > h->n_paths) return SIGMAENV_EINVAL;
-  hipLaunchKernelGGL(sigmaenv_auto_reset_kernel, dim3(h->B), dim3(h->block), h->smem_bytes, h->stream, h->cfg, h->map, h->buf, seed, counter,
+  hipLaunchKernelGGL(sigmaenv_auto_reset_kernel, dim3(h->B), dim3(h->reset_block), h->smem_bytes, h->stream, h->cfg, h->map, h->buf, seed, counter,
                      (int)path_first, (int)path_count, 1);
   HIPCHK(h, hipGetLastError());
   return SIGMAENV_OK;

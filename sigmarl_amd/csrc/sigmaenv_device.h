@@ -53,6 +53,12 @@ __device__ __forceinline__ float cr_cos(float x) { return (float)cos((double)x);
 __device__ __forceinline__ float cr_tan(float x) { return (float)tan((double)x); }
 __device__ __forceinline__ float cr_atan(float x) { return (float)atan((double)x); }
 __device__ __forceinline__ float cr_atan2(float y, float x) { return (float)atan2((double)y, (double)x); }
+__device__ __forceinline__ void cr_sincos(float x, float& s, float& c) {
+  double ds, dc;
+  sincos((double)x, &ds, &dc);
+  s = (float)ds;
+  c = (float)dc;
+}
 __device__ __forceinline__ float norm2(float x, float y) { return sqrtf(fmaf(y, y, x * x)); }
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 __device__ __forceinline__ float remainder_pos(float a, float b) {  // torch.remainder, b > 0
@@ -86,8 +92,10 @@ __device__ inline void bicycle_step(const sigmaenv_config_t& c, float s[8], floa
   float k_beta = (float)((double)c.l_r / ((double)c.l_f + (double)c.l_r));
   float tan_d = cr_tan(delta);
   float beta = cr_atan(k_beta * tan_d);
-  float dx0 = v * cr_cos(psi + beta);
-  float dx1 = v * cr_sin(psi + beta);
+  float s0, c0;
+  cr_sincos(psi + beta, s0, c0);
+  float dx0 = v * c0;
+  float dx1 = v * s0;
   float dx2 = (v / l_wb) * tan_d * cr_cos(beta);
   float dt = c.dt;
   x = x + dt * dx0;
@@ -99,15 +107,19 @@ __device__ inline void bicycle_step(const sigmaenv_config_t& c, float s[8], floa
   float beta1 = cr_atan(k_beta * cr_tan(delta));
   float course = psi + beta1;
   s[0] = x; s[1] = y; s[2] = psi; s[3] = v; s[4] = delta;
-  s[5] = v * cr_cos(course);
-  s[6] = v * cr_sin(course);
+  float s1, c1;
+  cr_sincos(course, s1, c1);
+  s[5] = v * c1;
+  s[6] = v * s1;
   s[7] = beta1;
 }
 
 // ---- K2: get_rectangle_vertices (helper_scenario.py:695-826) ------------------------------------------------------
-__device__ inline void rect_vertices(const sigmaenv_config_t& c, float px, float py, float psi, float* v /*5x2*/) {
+__device__ inline void rect_vertices(const sigmaenv_config_t& c, float px, float py, float psi, float* v /*5x2*/, float* cs_out = nullptr) {
   float lh = (float)((double)c.length / 2.0), wh = (float)((double)c.width / 2.0);
-  float cs = cr_cos(psi), sn = cr_sin(psi);
+  float cs, sn;
+  cr_sincos(psi, sn, cs);
+  if (cs_out) { cs_out[0] = cs; cs_out[1] = sn; }
   float nsn = -sn;
   const float bx[5] = {lh, lh, -lh, -lh, lh};
   const float by[5] = {wh, -wh, -wh, wh, wh};
