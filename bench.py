@@ -6,8 +6,8 @@ Contract (see the round prompt): ``python bench.py --gpus N --steps K --warmup W
 barrier + torch.cuda.synchronize() on both sides, MAX over ranks, rank 0 prints ONE JSON line.
 
 A "step" is one pass of the hot path over one batch of synthetic input: the fused HIP step over agents x envs, the
-device-side reset of the envs that finished (the reference's step_and_maybe_reset), and -- for N > 1 -- the asynchronous
-gather of the rollout slab to the learner rank.  Inputs (actions) are resident in HBM before the timed region starts.
+device-side reset of the envs that finished (the reference's step_and_maybe_reset), and -- for N > 1 -- the rollout-buffer
+exchange (the step kernel records each step's slab, one asynchronous RCCL gather per chunk of steps to the learner rank).  Inputs (actions) are resident in HBM before the timed region starts.
 Weak scaling: every GPU steps BASELINE config 2 (16 agents x 4096 envs); N = 8 is config 3 (32768 envs).
 """
 from __future__ import annotations
@@ -84,7 +84,13 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 disables it)")
     ap.add_argument("--no-reset", action="store_true", help="diagnostic: leave finished envs un-reset")
     ap.add_argument("--no-gather", action="store_true", help="diagnostic: skip the rollout-slab gather for N > 1")
+    ap.add_argument("--chunk-steps", type=int, default=32, help="steps per rollout chunk gathered to the learner rank (N > 1)")
+    ap.add_argument("--force-dist", action="store_true", help="diagnostic: init RCCL and run the gather even with one rank")
     args = ap.parse_args()
+
+    # the contract is ONE JSON line on stdout: libraries (RCCL prints a version banner) get stderr instead
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -92,8 +98,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if args.gpus != world and rank == 0 and world > 1:
@@ -104,7 +114,7 @@ def main():
     from sigmarl_amd import capi
     from sigmarl_amd.env import SigmaEnv
     from sigmarl_amd.params import Parameters
-    from sigmarl_amd.shard import RolloutGather
+    from sigmarl_amd.shard import RolloutExchange
 
     B, N = args.envs_per_gpu, args.agents
     params_kw = dict(n_agents=N, scenario_type="cpm_entire", dt=0.05, is_use_mtv_distance=(args.distance == "mtv"), rew_method="distance",
@@ -117,14 +127,36 @@ def main():
     acts = torch.empty((n_act, B, N, 2), dtype=torch.float32, device=device)
     acts[..., 0] = torch.rand((n_act, B, N), generator=gen, device=device)                 # v_cmd ~ U[0, 1]
     acts[..., 1] = torch.rand((n_act, B, N), generator=gen, device=device) * 0.5 - 0.25    # delta_cmd ~ U[-0.25, 0.25] rad
-    gather = RolloutGather(B, N, env.D, device) if (world > 1 and not args.no_gather) else None
+    gather = None
+    gather_note = "n/a (single GPU)"
+    if use_dist and not args.no_gather:
+        try:  # the rollout exchange must never take the benchmark down: fall back to "no gather" and say so in the JSON line
+            gather = RolloutExchange(B, N, env.D, args.chunk_steps, device, force_collective=args.force_dist)
+            env.set_slab(gather.slot())
+            env.step(acts[0])
+            gather.advance()
+            gather.flush()
+            gather.wait_all()
+            torch.cuda.synchronize()
+            env.auto_reset(seed=seed, counter=0, path_first=env.map.list_first[0], path_count=env.map.list_count[0])
+            gather_note = (f"step kernel records (obs, reward, done) into a [{args.chunk_steps}, B, {N * (env.D + 1) + 1}] chunk buffer; "
+                           "one async gather per chunk to rank 0, double buffered")
+        except Exception as exc:  # noqa: BLE001
+            gather = None
+            env.set_slab(None)
+            gather_note = f"disabled: {type(exc).__name__}: {exc}"
+            print(f"[bench] rollout exchange disabled: {exc}", file=sys.stderr)
+    elif use_dist:
+        gather_note = "disabled by --no-gather"
     pf, pc = env.map.list_first[0], env.map.list_count[0]
     counter = [1]
 
     def one_step(t):
+        if gather is not None:
+            env.set_slab(gather.slot())
         env.step(acts[t % n_act])
         if gather is not None:
-            gather.submit(env.obs, env.reward, env.done)
+            gather.advance()
         if not args.no_reset:
             env.auto_reset(seed=seed, counter=counter[0], path_first=pf, path_count=pc)
             counter[0] += 1
@@ -132,24 +164,26 @@ def main():
     for t in range(args.warmup):
         one_step(t)
     if gather is not None:
+        gather.flush()
         gather.wait_all()
     env.step_time_ms()  # arms the HIP-event bracketing of the step launches (on the env's stream)
     resets_before = int(env.buffer(capi.BUF_TIMER)[:, 3].sum().item())  # episodes_reset counters
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for t in range(args.steps):
         one_step(args.warmup + t)
     if gather is not None:
+        gather.flush()
         gather.wait_all()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     el = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
 
@@ -159,6 +193,14 @@ def main():
     value = total_agent_steps / elapsed
     bytes_per = algorithmic_bytes_per_agent_step(N)
     achieved = (bytes_per * N * B) / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None
+    traffic = None
+    try:  # HBM bytes per launch from the separate rocprofv3 --pmc passes (tools/pmc_passes.sh), corrected as the MI355X guide says
+        with open(os.path.join(ROOT, "profiles", "traffic_latest.json")) as f:
+            tr = json.load(f)
+        if tr.get("n_agents") == N and tr.get("envs_per_gpu") == B and tr.get("distance") == args.distance:
+            traffic = tr["hbm_bytes_per_launch"]
+    except Exception:  # noqa: BLE001
+        pass
     out = {
         "metric": "env-steps/sec (agents x envs x steps), CPM scenario, 16 agents",
         "value": value, "unit": "agent-env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -168,21 +210,24 @@ def main():
             "workload": f"cpm_entire map, {N} agents x {B} envs per GPU ({B * world} envs total), {args.distance} distance, rew_method=distance, "
                         f"dt=0.05, obs_dim={env.D}, fused step + device-side reset of finished envs" + (" + rollout-slab gather" if gather else ""),
             "n_agents": N, "envs_per_gpu": B, "envs_total": B * world, "distance": args.distance,
-            "resets_per_step_per_gpu": dones / max(1, args.steps), "block_threads": None,
+            "resets_per_step_per_gpu": dones / max(1, args.steps), "rollout_gather": gather_note,
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": (achieved / 8000.0) if achieved else None,
-            "traffic": None, "kernel": "sigmaenv_step_kernel", "kernel_avg_ms": kernel_ms, "kernel_launches": n_launch,
+            "traffic": traffic, "kernel": "sigmaenv_step_kernel", "kernel_avg_ms": kernel_ms, "kernel_launches": n_launch,
             "algorithmic_bytes_per_agent_env_step": bytes_per,
         },
     }
-    if rank == 0:
-        if args.cpu_seconds > 0 and world == 1:
-            out["cpu_baseline"] = cpu_baseline(params_kw, B, args.cpu_seconds)
-        print(json.dumps(out))
+    if rank == 0 and args.cpu_seconds > 0 and world == 1:
+        out["cpu_baseline"] = cpu_baseline(params_kw, B, args.cpu_seconds)
     env.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    if rank == 0:
+        os.write(1, (json.dumps(out) + "\n").encode())
+    os.dup2(2, 1)  # RCCL prints its version banner at exit: keep it off stdout as well
 
 
 if __name__ == "__main__":

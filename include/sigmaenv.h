@@ -165,6 +165,12 @@ int sigmaenv_auto_reset(sigmaenv_t* h, uint64_t seed, uint64_t counter, int32_t 
 
 int sigmaenv_get(sigmaenv_t* h, sigmaenv_buf_t which, void** dev_ptr, size_t* bytes);
 
+/* Rollout slab (wire format of the learner-boundary exchange): when dev_ptr != NULL every following sigmaenv_step also writes
+ * one contiguous fp32 row per env, [N*D observation | N reward | 1 done], to dev_ptr ([B, N*(D+1)+1]).  The caller rotates the
+ * pointer through its rollout buffer; NULL disables the record.  Replaces the per-step tensordict stacking of
+ * SyncDataCollectorCustom.rollout (sigmarl/helper_training.py:687-788) for (observation, reward, done). */
+int sigmaenv_set_slab(sigmaenv_t* h, void* dev_ptr);
+
 /* Blocks until everything enqueued on the handle's stream has finished. */
 int sigmaenv_sync(sigmaenv_t* h);
 

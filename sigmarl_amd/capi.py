@@ -103,7 +103,10 @@ _SIGS = {
     "get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "sync": (C.c_int, [C.c_void_p]),
 }
-_PRODUCT_ONLY = {"step_time_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)])}
+_PRODUCT_ONLY = {
+    "step_time_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    "set_slab": (C.c_int, [C.c_void_p, C.c_void_p]),
+}
 
 
 class Library:

@@ -35,7 +35,7 @@ __device__ __constant__ uint32_t W_REF_BITS[3] = {0x3F0E38E3u, 0x3EAAAAABu, 0x3D
 #define DIST_STRIDE(N) ((N) + 1)   /* odd float stride: lane-per-row column walks are bank-conflict free */
 #define COL_STRIDE(N) ((N) + 4)    /* byte stride whose word stride ((N+4)/4) is odd for N = 16 */
 struct Smem {
-  float *st, *vold, *vnew, *shrt, *dref, *dleft, *dright, *dbound, *dist, *obs, *thr, *cs;
+  float *st, *vold, *vnew, *shrt, *dref, *dleft, *dright, *dbound, *dist, *obs, *thr, *cs, *rew;
   int *path, *cp, *near, *flags, *npts;
   uint8_t* col;
   __device__ Smem(char* base, int S, int N, int K, int D) {
@@ -52,6 +52,7 @@ struct Smem {
     obs = f; f += S * D;
     thr = f; f += S * 3;   // pruning thresholds of the centre / left / right scan
     cs = f; f += S * 2;    // cos / sin of the yaw (shared by the vertices and the ego-view transforms)
+    rew = f; f += S * 2;   // reward per slot, then done flag per env (rollout slab record)
     int* i = reinterpret_cast<int*>(f);
     path = i; i += S;
     cp = i; i += S * 3;
@@ -61,7 +62,7 @@ struct Smem {
     col = reinterpret_cast<uint8_t*>(i);
   }
   __host__ __device__ static size_t bytes(int S, int N, int K, int D) {
-    size_t f = (size_t)S * 8 + S * 10 * 2 + S * NS * 2 + S + S * 5 * 2 + S + (size_t)S * DIST_STRIDE(N) + (size_t)S * D + S * 3 + S * 2;
+    size_t f = (size_t)S * 8 + S * 10 * 2 + S * NS * 2 + S + S * 5 * 2 + S + (size_t)S * DIST_STRIDE(N) + (size_t)S * D + S * 3 + S * 2 + S * 2;
     size_t i = (size_t)S + S * 3 + S * (K > 0 ? K : 1) + S * 4 + S * 3;
     return (f + i) * 4 + (size_t)S * COL_STRIDE(N) + 16;
   }
@@ -614,6 +615,7 @@ __global__ void __launch_bounds__(256) sigmaenv_step_kernel(sigmaenv_config_t c,
       }
       float r = clampf(rew, -1.0f, 1.0f);                            // :1249
       g.reward[gi] = r;
+      s.rew[sl] = r;
       // RewardInfo.reset() at the top of every reward() zeroes all agents' entries except three fields
       // (helper_scenario.py:128-138): only the last agent's values of the other fields survive the loop.
       bool last = (i == N - 1);
@@ -655,6 +657,7 @@ __global__ void __launch_bounds__(256) sigmaenv_step_kernel(sigmaenv_config_t c,
         g.timer[b * 4 + 1] += __popcll(b_any & env_mask);
         g.timer[b * 4 + 2] += __popcll(b_goal & env_mask);
         g.done[b] = (uint8_t)done;
+        s.rew[G * N + e] = done ? 1.0f : 0.0f;
       }
     }
   }
@@ -663,6 +666,14 @@ __global__ void __launch_bounds__(256) sigmaenv_step_kernel(sigmaenv_config_t c,
 
   // ---- D: observations ---------------------------------------------------------------------------------------------
   if (!(dbg_skip & 8)) observe_tile(c, s, g, t);
+  if (g.slab) {  // rollout record of this step (observation AFTER the step, reward, done), one contiguous row per env
+    const int ND = N * t.D, W = ND + N + 1;
+    for (int k = tid; k < t.nenv * W; k += blockDim.x) {
+      int e = k / W, r = k - e * W;
+      float v = (r < ND) ? s.obs[e * ND + r] : ((r < ND + N) ? s.rew[e * N + (r - ND)] : s.rew[G * N + e]);
+      g.slab[(size_t)(t.env0 + e) * W + r] = v;
+    }
+  }
   TS(5);
 #undef TS
 }
@@ -1140,6 +1151,7 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
   }
   ALLOC(g.reset_mask, (size_t)B * 8);
   ALLOC(g.reset_full, (size_t)B);
+  g.slab = nullptr;
   g.dbg_ts = nullptr;
   if (const char* e = getenv("SIGMAENV_TIMESTAMPS")) {
     if (atoi(e) != 0) { ALLOC(g.dbg_ts, (size_t)B * 8 * sizeof(unsigned long long)); }
@@ -1271,6 +1283,14 @@ extern "C" int sigmaenv_get(sigmaenv_t* h, sigmaenv_buf_t which, void** dev_ptr,
 extern "C" int sigmaenv_sync(sigmaenv_t* h) {
   if (!h) return SIGMAENV_EINVAL;
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  return SIGMAENV_OK;
+}
+
+// Rollout slab: when set, every subsequent step also writes one contiguous fp32 row per env, [N*D observation | N reward | done],
+// to dev_ptr ([B, N*(D+1)+1]); the caller rotates the pointer through its rollout buffer.  NULL disables it.
+extern "C" int sigmaenv_set_slab(sigmaenv_t* h, void* dev_ptr) {
+  if (!h) return SIGMAENV_EINVAL;
+  h->buf.slab = reinterpret_cast<float*>(dev_ptr);
   return SIGMAENV_OK;
 }
 

@@ -44,6 +44,7 @@ struct DevBufs {
   uint8_t *col_agents, *col_flags, *done;
   unsigned long long* reset_mask;  // [B] bit i: agent i needs its derived state rebuilt
   uint8_t* reset_full;             // [B] full-env reset pending
+  float* slab;                     // optional rollout record of this step: [B][N*D obs | N reward | 1 done] fp32 (sigmaenv_set_slab)
   unsigned long long* dbg_ts;      // optional [grid][8] shader-clock timestamps at the phase boundaries (SIGMAENV_TIMESTAMPS=1)
 };
 

@@ -188,6 +188,15 @@ class SigmaEnv:
             path_first, path_count = self.map.list_first[0], self.map.list_count[0]
         self._chk(self.lib.auto_reset(self.h, int(seed), int(counter), int(path_first), int(path_count)), "auto_reset")
 
+    def set_slab(self, slab: torch.Tensor | None):
+        """Route the per-step rollout record ([B, N*(D+1)+1] fp32: obs | reward | done) into ``slab`` (None disables it)."""
+        if slab is None:
+            self._chk(self.lib.set_slab(self.h, None), "set_slab")
+            return
+        if not (slab.is_cuda and slab.dtype == torch.float32 and slab.is_contiguous() and tuple(slab.shape) == (self.B, self.N * (self.D + 1) + 1)):
+            raise ValueError(f"slab must be a contiguous float32 CUDA tensor of shape {(self.B, self.N * (self.D + 1) + 1)}")
+        self._chk(self.lib.set_slab(self.h, C.c_void_p(slab.data_ptr())), "set_slab")
+
     def sync(self):
         self._chk(self.lib.sync(self.h), "sync")
 

@@ -1,10 +1,12 @@
-"""Env-shard partitioning across the GPUs of one node and the rollout-slab exchange.
+"""Env-shard partitioning across the GPUs of one node and the rollout-buffer exchange.
 
 Environments are independent units (no cross-env read anywhere in the step), so the data path
 shards with NO collective: rank r owns a contiguous env range and its own ``SigmaEnv``.  The only exchange is the
-learner-boundary concat of the per-step rollout slab (observation, reward, done) -- one gather to the learner rank
-(RCCL over xGMI when the backend is "nccl"; gloo in the CPU tests).  It is issued asynchronously on the communication
-stream so that it overlaps the next fused step.
+learner-boundary concat of the rollout buffer (observation, reward, done of every step): the fused step kernel writes each
+step's slab row-wise into a ``[T, B, W]`` chunk buffer (``sigmaenv_set_slab``), and once per chunk ONE asynchronous gather
+ships it to the learner rank (RCCL over xGMI when the backend is "nccl"; gloo in the CPU tests) while the next chunk is
+being stepped into the second buffer.  One large message per link instead of a small one per step: xGMI is point-to-point, the
+7 peers of the learner send over 7 distinct links.
 """
 from __future__ import annotations
 
@@ -21,12 +23,15 @@ def shard_range(total_envs: int, rank: int, world_size: int):
     return begin, begin + base + (1 if rank < rem else 0)
 
 
+def slab_width(n_agents: int, obs_dim: int) -> int:
+    return n_agents * (obs_dim + 1) + 1
+
+
 def pack_slab(obs: torch.Tensor, reward: torch.Tensor, done: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
-    """[B,N,D] obs, [B,N] reward, [B] done(u8) -> one contiguous fp32 slab [B, N*(D+1)+1] (wire format of the exchange)."""
+    """[B,N,D] obs, [B,N] reward, [B] done -> fp32 slab [B, N*(D+1)+1]: the wire format the step kernel writes natively."""
     B, N, D = obs.shape
-    width = N * (D + 1) + 1
     if out is None:
-        out = torch.empty((B, width), dtype=torch.float32, device=obs.device)
+        out = torch.empty((B, slab_width(N, D)), dtype=torch.float32, device=obs.device)
     out[:, : N * D].copy_(obs.reshape(B, N * D))
     out[:, N * D: N * D + N].copy_(reward)
     out[:, -1].copy_(done.to(torch.float32))
@@ -34,41 +39,58 @@ def pack_slab(obs: torch.Tensor, reward: torch.Tensor, done: torch.Tensor, out: 
 
 
 def unpack_slab(slab: torch.Tensor, N: int, D: int):
-    B = slab.shape[0]
-    obs = slab[:, : N * D].reshape(B, N, D)
-    reward = slab[:, N * D: N * D + N]
-    done = slab[:, -1] > 0.5
+    """[..., N*(D+1)+1] -> obs [..., N, D], reward [..., N], done [...] (bool)."""
+    lead = slab.shape[:-1]
+    obs = slab[..., : N * D].reshape(*lead, N, D)
+    reward = slab[..., N * D: N * D + N]
+    done = slab[..., -1] > 0.5
     return obs, reward, done
 
 
-class RolloutGather:
-    """Double-buffered asynchronous gather of the per-step slab to ``dst`` (the learner rank)."""
+class RolloutExchange:
+    """Double-buffered rollout chunks ``[T, B, W]`` + one asynchronous gather per chunk to ``dst`` (the learner rank)."""
 
-    def __init__(self, local_envs: int, n_agents: int, obs_dim: int, device, dst: int = 0, group=None):
+    def __init__(self, local_envs: int, n_agents: int, obs_dim: int, chunk_steps: int, device, dst: int = 0, group=None,
+                 force_collective: bool = False):
         self.group = group
+        self.force = bool(force_collective)  # issue the collective even with one rank (exercises the RCCL path on a 1-GPU box)
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.collective = self.world > 1 or self.force
         self.dst = dst
-        self.N, self.D = n_agents, obs_dim
-        width = n_agents * (obs_dim + 1) + 1
-        self.send = [torch.empty((local_envs, width), dtype=torch.float32, device=device) for _ in range(2)]
+        self.N, self.D, self.T = n_agents, obs_dim, int(chunk_steps)
+        shape = (self.T, local_envs, slab_width(n_agents, obs_dim))
+        self.chunks = [torch.empty(shape, dtype=torch.float32, device=device) for _ in range(2)]
         self.recv = None
-        if self.rank == dst and self.world > 1:
-            self.recv = [[torch.empty((local_envs, width), dtype=torch.float32, device=device) for _ in range(self.world)] for _ in range(2)]
+        if self.rank == dst and self.collective:
+            self.recv = [[torch.empty(shape, dtype=torch.float32, device=device) for _ in range(self.world)] for _ in range(2)]
         self.pending = [None, None]
-        self.k = 0
+        self.cur, self.t = 0, 0
+        self.completed = []  # indices of chunk buffers whose gather has been issued, in order
 
-    def submit(self, obs, reward, done):
-        """Packs the slab of this step and starts its gather; returns immediately (the previous use of the buffer is waited for)."""
-        k = self.k & 1
-        if self.pending[k] is not None:
-            self.pending[k].wait()
-            self.pending[k] = None
-        slab = pack_slab(obs, reward, done, self.send[k])
-        if self.world > 1:
-            self.pending[k] = dist.gather(slab, self.recv[k] if self.rank == self.dst else None, dst=self.dst, group=self.group, async_op=True)
-        self.k += 1
-        return k
+    def slot(self) -> torch.Tensor:
+        """The ``[B, W]`` row block the NEXT step must be recorded into (pass it to ``SigmaEnv.set_slab``)."""
+        if self.t == 0 and self.pending[self.cur] is not None:  # the buffer is about to be overwritten: its gather must be done
+            self.pending[self.cur].wait()
+            self.pending[self.cur] = None
+        return self.chunks[self.cur][self.t]
+
+    def advance(self):
+        """Call after the step that filled ``slot()`` has been enqueued; ships the chunk when it is full."""
+        self.t += 1
+        if self.t == self.T:
+            self.flush()
+
+    def flush(self):
+        if self.t == 0:
+            return
+        k = self.cur
+        if self.collective:
+            self.pending[k] = dist.gather(self.chunks[k], self.recv[k] if self.rank == self.dst else None, dst=self.dst, group=self.group,
+                                          async_op=True)
+        self.completed.append(k)
+        self.cur ^= 1
+        self.t = 0
 
     def wait_all(self):
         for k in (0, 1):
@@ -77,7 +99,7 @@ class RolloutGather:
                 self.pending[k] = None
 
     def gathered(self, k):
-        """On the learner rank: list of per-rank slabs of buffer k (after ``wait_all``)."""
-        if self.world == 1:
-            return [self.send[k]]
+        """On the learner rank: per-rank chunk buffers ``[T, B_r, W]`` of buffer k (after ``wait_all``)."""
+        if not self.collective:
+            return [self.chunks[k]]
         return self.recv[k] if self.rank == self.dst else None

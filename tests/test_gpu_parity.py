@@ -214,3 +214,32 @@ def test_full_size_properties(N, B):
             assert np.abs(o1[t][w] - ora.get(w)).max() <= FTOL
         ora.auto_reset(9, t + 1, pf, pc)
     ora.close()
+
+
+def test_rollout_slab_is_written_by_the_step_kernel():
+    """sigmaenv_set_slab: the per-step record [obs | reward | done] equals the individual buffers (ragged tile: N=5, B=33)."""
+    import torch
+    from sigmarl_amd.shard import slab_width, unpack_slab
+
+    for N, B in ((16, 64), (5, 33)):
+        p = Parameters(n_agents=N, scenario_type="cpm_entire", is_use_mtv_distance=False, is_apply_mask=False, is_obs_noise=False)
+        mp = load_map("cpm_entire")
+        dev = _hip_env(make_config(p, mp, B), mp)
+        env = dev.env
+        env.reset_random(seed=2)
+        chunk = torch.full((3, B, slab_width(N, env.D)), float("nan"), device="cuda")
+        gen = torch.Generator(device="cuda").manual_seed(0)
+        for t in range(3):
+            env.set_slab(chunk[t])
+            act = torch.rand((B, N, 2), generator=gen, device="cuda") - torch.tensor([0.0, 0.5], device="cuda")
+            env.step(act)
+            env.sync()
+            obs, rew, done = unpack_slab(chunk[t], N, env.D)
+            assert torch.equal(obs, env.obs) and torch.equal(rew, env.reward) and torch.equal(done, env.done.bool())
+            env.auto_reset(seed=2)
+        env.set_slab(None)
+        before = chunk.clone()
+        env.step(act)
+        env.sync()
+        assert torch.equal(before, chunk)
+        dev.close()

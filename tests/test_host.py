@@ -150,7 +150,7 @@ import oracle_binding as ob
 from sigmarl_amd import capi
 from sigmarl_amd.maps import load_map
 from sigmarl_amd.params import Parameters, make_config
-from sigmarl_amd.shard import RolloutGather, shard_range, unpack_slab
+from sigmarl_amd.shard import RolloutExchange, pack_slab, shard_range, unpack_slab
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 TOTAL, N, T = 24, 4, 3
@@ -169,19 +169,30 @@ def make(lo, hi):
     return e
 env = make(b0, b1)
 full = make(0, TOTAL) if rank == 0 else None
-gather = RolloutGather(b1 - b0, N, env.D, "cpu", dst=0)
+CH = 2  # steps per chunk: T = 3 steps -> one full chunk + one partial chunk flushed at the end
+ex = RolloutExchange(b1 - b0, N, env.D, CH, "cpu", dst=0)
 rng = np.random.default_rng(0)
+ref = []
 for t in range(T):
     act = np.stack([rng.uniform(0, 1, (TOTAL, N)), rng.uniform(-0.2, 0.2, (TOTAL, N))], -1).astype(np.float32)
     env.step(act[b0:b1])
-    k = gather.submit(torch.from_numpy(env.get(capi.BUF_OBS)), torch.from_numpy(env.get(capi.BUF_REWARD)), torch.from_numpy(env.get(capi.BUF_DONE)))
-    gather.wait_all()
+    # (on the GPU the step kernel writes this row block itself: sigmaenv_set_slab)
+    pack_slab(torch.from_numpy(env.get(capi.BUF_OBS)), torch.from_numpy(env.get(capi.BUF_REWARD)), torch.from_numpy(env.get(capi.BUF_DONE)), out=ex.slot())
+    ex.advance()
     if rank == 0:
         full.step(act)
-        slabs = torch.cat(gather.gathered(k), 0)
-        obs, rew, done = unpack_slab(slabs, N, env.D)
-        assert np.array_equal(obs.numpy(), full.get(capi.BUF_OBS)) and np.array_equal(rew.numpy(), full.get(capi.BUF_REWARD))
-        assert np.array_equal(done.numpy(), full.get(capi.BUF_DONE).astype(bool))
+        ref.append((full.get(capi.BUF_OBS), full.get(capi.BUF_REWARD), full.get(capi.BUF_DONE).astype(bool)))
+ex.flush(); ex.wait_all()
+if rank == 0:
+    assert ex.completed == [0, 1]
+    t = 0
+    for k, n_steps in zip(ex.completed, (CH, T - CH)):
+        chunk = torch.cat(ex.gathered(k), 1)  # [CH, TOTAL, W]: ranks own contiguous env ranges
+        obs, rew, done = unpack_slab(chunk, N, env.D)
+        for q in range(n_steps):
+            assert np.array_equal(obs[q].numpy(), ref[t][0]) and np.array_equal(rew[q].numpy(), ref[t][1]) and np.array_equal(done[q].numpy(), ref[t][2])
+            t += 1
+    assert t == T
 dist.barrier()
 if rank == 0: print("SHARD_OK")
 dist.destroy_process_group()
