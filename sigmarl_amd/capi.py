@@ -142,7 +142,8 @@ def load_library(path: str | None = None) -> Library:
 
     if path is None:
         if _product_lib is None:
-            _product_lib = Library(DEFAULT_LIB, "sigmaenv_", _PRODUCT_ONLY)
+            # SIGMAENV_LIB: alternative build of the same HIP library (A/B experiments); still the HIP path, never a fallback
+            _product_lib = Library(os.environ.get("SIGMAENV_LIB", DEFAULT_LIB), "sigmaenv_", _PRODUCT_ONLY)
         return _product_lib
     return Library(path, "sigmaenv_", _PRODUCT_ONLY)
 

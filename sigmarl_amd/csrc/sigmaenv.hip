@@ -37,6 +37,7 @@ __device__ __constant__ uint32_t W_REF_BITS[3] = {0x3F0E38E3u, 0x3EAAAAABu, 0x3D
 struct Smem {
   float *st, *vold, *vnew, *shrt, *dref, *dleft, *dright, *dbound, *dist, *obs, *thr, *cs, *rew;
   int *path, *cp, *near, *flags, *npts;
+  unsigned long long* cmask;  // candidate-chunk masks of the centre / left / right scan, [S][3]
   uint8_t* col;
   __device__ Smem(char* base, int S, int N, int K, int D) {
     float* f = reinterpret_cast<float*>(base);
@@ -59,11 +60,13 @@ struct Smem {
     near = i; i += S * (K > 0 ? K : 1);
     flags = i; i += S * 4;
     npts = i; i += S * 3;  // point counts of the agent's centre line / left / right boundary
+    i += (S * 3) & 1;      // keep the 64-bit masks 8-byte aligned
+    cmask = reinterpret_cast<unsigned long long*>(i); i += S * 3 * 2;
     col = reinterpret_cast<uint8_t*>(i);
   }
   __host__ __device__ static size_t bytes(int S, int N, int K, int D) {
     size_t f = (size_t)S * 8 + S * 10 * 2 + S * NS * 2 + S + S * 5 * 2 + S + (size_t)S * DIST_STRIDE(N) + (size_t)S * D + S * 3 + S * 2 + S * 2;
-    size_t i = (size_t)S + S * 3 + S * (K > 0 ? K : 1) + S * 4 + S * 3;
+    size_t i = (size_t)S + S * 3 + S * (K > 0 ? K : 1) + S * 4 + S * 3 + 1 + (size_t)S * 3 * 2;
     return (f + i) * 4 + (size_t)S * COL_STRIDE(N) + 16;
   }
 };
@@ -205,14 +208,6 @@ __device__ __forceinline__ int nth_set_bit64(unsigned long long m, int c) {
   for (int t = 0; t < c; ++t) m &= (m - 1ull);
   return m ? (__ffsll((long long)m) - 1) : -1;
 }
-__device__ __forceinline__ bool chunk_hit(const float4* __restrict__ box, int idx, int nch, float px, float py, float T) {
-  if (idx >= nch) return false;
-  float4 b = box[idx];
-  float dx = fmaxf(fmaxf(b.x - px, px - b.z), 0.0f);
-  float dy = fmaxf(fmaxf(b.y - py, py - b.w), 0.0f);
-  return !((dx * dx + dy * dy) > T * T);  // a NaN threshold keeps every chunk
-}
-
 // per-agent inputs of the pruned scan, computed by ONE lane per agent (all agents of the tile in parallel, so the dependent
 // global loads overlap): point counts and the pruning thresholds T (see the exactness argument above).
 template <bool COLLIDE>
@@ -230,6 +225,42 @@ __device__ inline void scan_prepare(const DevMap& m, const Smem& s, int sl, bool
   s.thr[sl * 3 + 2] = fmaxf(guess_distance(m.right + (size_t)path * m.P * 2, nr, s.cp[sl * 3 + 2], cgx, cgy) + 2.0f * Rq, floor_b) + MARGIN;
 }
 
+// candidate-chunk masks: bit c of the (agent, polyline) mask is set iff the bounding box of chunk c is within the scan threshold
+// of the agent's centre.  Two levels so that the far part of the polyline costs one box per 8 chunks (32 segments): first the <= 8
+// group boxes, then the 8 chunk boxes of every group that is within the threshold (usually one or two).  One lane per
+// (agent, polyline); the loads of a level are independent and in flight together.
+__device__ __forceinline__ bool box_within(const float4 b, float px, float py, float T2) {
+  float dx = fmaxf(fmaxf(b.x - px, px - b.z), 0.0f);
+  float dy = fmaxf(fmaxf(b.y - py, py - b.w), 0.0f);
+  return !((dx * dx + dy * dy) > T2);  // a NaN threshold keeps every box
+}
+__device__ inline void scan_mask_task(const DevMap& m, const Smem& s, int task) {
+  const int sl = task / 3, pl = task - sl * 3;
+  const int path = s.path[sl];
+  const float px = s.st[sl * 8], py = s.st[sl * 8 + 1];
+  const float T = s.thr[sl * 3 + pl];
+  const float T2 = T * T;
+  const int nch = (s.npts[sl * 3 + pl] - 1 + SIGMAENV_CHUNK - 1) / SIGMAENV_CHUNK;
+  const float4* gbox = m.group_box + ((size_t)path * 3 + pl) * 8;
+  const float4* box = m.chunk_box + ((size_t)path * 3 + pl) * m.nch;
+  unsigned gm = 0u;
+#pragma unroll
+  for (int gidx = 0; gidx < 8; ++gidx) {
+    if (gidx * 8 < nch && box_within(gbox[gidx], px, py, T2)) gm |= 1u << gidx;
+  }
+  unsigned long long mk = 0ull;
+  while (gm) {
+    const int gidx = __ffs((int)gm) - 1;
+    gm &= gm - 1u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int cidx = gidx * 8 + k;
+      if (cidx < nch && box_within(box[cidx], px, py, T2)) mk |= 1ull << cidx;
+    }
+  }
+  s.cmask[task] = mk;
+}
+
 template <bool COLLIDE>
 __device__ inline void pair_scan(const DevMap& m, const sigmaenv_config_t& c, const Smem& s, int slotA, int valid_mask, int lane, bool stale_first, int N) {
   // valid_mask: bit 0 = scan agent slotA, bit 1 = scan agent slotA + 1 (an unselected half mirrors the selected one, results dropped)
@@ -245,21 +276,8 @@ __device__ inline void pair_scan(const DevMap& m, const sigmaenv_config_t& c, co
   const float2* pol2 = reinterpret_cast<const float2*>((side ? m.right : m.left) + (size_t)path * m.P * 2);
   const int n = s.npts[sl * 3], np = s.npts[sl * 3 + 1 + side];
   const float Tc = s.thr[sl * 3], Tb = s.thr[sl * 3 + 1 + side];
-  // ---- candidate chunk masks: each 16-lane group tests its own boundary, each half-wave its own centre line
-  unsigned long long mb = 0ull, mc = 0ull;
-  {
-    const float4* box = m.chunk_box + (size_t)path * 3 * m.nch;
-    const int nchb = (np - 1 + SIGMAENV_CHUNK - 1) / SIGMAENV_CHUNK, nchc = (n - 1 + SIGMAENV_CHUNK - 1) / SIGMAENV_CHUNK;
-    const float4* bb = box + (1 + side) * m.nch;
-    for (int base = 0; base < m.nch; base += 16) {
-      unsigned long long bal = __ballot(chunk_hit(bb, base + gl, nchb, cgx, cgy, Tb));
-      mb |= ((bal >> (grp * 16)) & 0xFFFFull) << base;
-    }
-    for (int base = 0; base < m.nch; base += 32) {
-      unsigned long long bal = __ballot(chunk_hit(box, base + hl, nchc, cgx, cgy, Tc));
-      mc |= ((bal >> (ag * 32)) & 0xFFFFFFFFull) << base;
-    }
-  }
+  // ---- candidate chunk masks (scan_mask_task, one lane per (agent, polyline), computed before the scan)
+  const unsigned long long mc = s.cmask[sl * 3], mb = s.cmask[sl * 3 + 1 + side];
   Edge e[4];
   if (COLLIDE) {
 #pragma unroll
@@ -455,7 +473,10 @@ __device__ inline void observe_tile(const sigmaenv_config_t& c, const Smem& s, c
 // the fused step kernel: grid = ceil(n_envs / G), block = 64 * waves
 // VMAS >= 1.4 call order restated per env: world.step(); reward(a) for all a; observation(a) for all a; done()
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) sigmaenv_step_kernel(sigmaenv_config_t c, DevMap m, DevBufs g, const float* __restrict__ actions, int G, int dbg_skip) {
+#ifndef STEP_MIN_WAVES
+#define STEP_MIN_WAVES 1
+#endif
+__global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigmaenv_config_t c, DevMap m, DevBufs g, const float* __restrict__ actions, int G, int dbg_skip) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const Tile t(c, G);
   const int N = t.N;
@@ -496,6 +517,9 @@ __global__ void __launch_bounds__(256) sigmaenv_step_kernel(sigmaenv_config_t c,
     if (m.nch > 0) scan_prepare<true>(m, s, sl, sl % N == 0);
   }
   __syncthreads();
+  if (m.nch > 0) {
+    for (int task = tid; task < t.slots * 3; task += blockDim.x) scan_mask_task(m, s, task);
+  }
   TS(1);
 
   // ---- B1: mutual distances + agent-agent collisions (one lane per ordered pair) -------------------------------------
@@ -520,6 +544,7 @@ __global__ void __launch_bounds__(256) sigmaenv_step_kernel(sigmaenv_config_t c,
     g.col_agents[t.a0 * N + p] = col;
   }
 
+  __syncthreads();  // the candidate masks (written by other lanes) must be visible to the scan
   TS(2);
   // ---- B2: distance queries + boundary collisions (two agents per wavefront; full-scan fallback one agent per wavefront) ----
   if (dbg_skip & 2) {
@@ -740,6 +765,11 @@ __device__ inline void reset_derive_body(const sigmaenv_config_t& c, const DevMa
   }
   __syncthreads();
   if (m.nch > 0) {
+    for (int task = tid; task < t.slots * 3; task += blockDim.x) {
+      int sl = task / 3;
+      if ((agent_mask[sl / N] >> (sl % N)) & 1ull) scan_mask_task(m, s, task);
+    }
+    __syncthreads();
     for (int pr = wave; 2 * pr < t.slots; pr += n_waves) {
       int sa = 2 * pr, sb = 2 * pr + 1;
       bool ma = (agent_mask[sa / N] >> (sa % N)) & 1ull;
@@ -1106,8 +1136,8 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
   int nch = (P - 1 + SIGMAENV_CHUNK - 1) / SIGMAENV_CHUNK;
   bool prune = nch <= 64;  // the candidate masks are 64-bit; longer polylines fall back to the full scan
   if (const char* e = getenv("SIGMAENV_PRUNE")) prune = prune && atoi(e) != 0;
-  float4* d_box = nullptr;
-  std::vector<float4> hb;  // must outlive the asynchronous upload below
+  float4 *d_box = nullptr, *d_gbox = nullptr;
+  std::vector<float4> hb, hg;  // must outlive the asynchronous uploads below
   if (prune) {
     hb.assign((size_t)np * 3 * nch, make_float4(1e30f, 1e30f, -1e30f, -1e30f));
     for (int p = 0; p < np; ++p) {
@@ -1125,10 +1155,21 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
     }
     ALLOC(d_box, hb.size() * sizeof(float4));
     H2D(d_box, hb.data(), hb.size() * sizeof(float4));
+    hg.assign((size_t)np * 3 * 8, make_float4(1e30f, 1e30f, -1e30f, -1e30f));
+    for (size_t pq = 0; pq < (size_t)np * 3; ++pq) {
+      for (int cidx = 0; cidx < nch; ++cidx) {
+        const float4& bx = hb[pq * nch + cidx];
+        if (bx.x > bx.z) continue;  // chunk without real segments
+        float4& gx = hg[pq * 8 + cidx / 8];
+        gx.x = bx.x < gx.x ? bx.x : gx.x; gx.y = bx.y < gx.y ? bx.y : gx.y; gx.z = bx.z > gx.z ? bx.z : gx.z; gx.w = bx.w > gx.w ? bx.w : gx.w;
+      }
+    }
+    ALLOC(d_gbox, hg.size() * sizeof(float4));
+    H2D(d_gbox, hg.data(), hg.size() * sizeof(float4));
   }
   const float lh = (float)((double)cfg->length / 2.0), wh = (float)((double)cfg->width / 2.0);
   const float rect_radius = sqrtf(lh * lh + wh * wh) * 1.00001f + 1e-5f;
-  h->map = DevMap{d_c, d_l, d_r, d_y, d_nc, d_nl, d_nr, d_loop, P, np, S, d_box, prune ? nch : 0, rect_radius};
+  h->map = DevMap{d_c, d_l, d_r, d_y, d_nc, d_nl, d_nr, d_loop, P, np, S, d_box, d_gbox, prune ? nch : 0, rect_radius};
   const size_t BN = (size_t)B * N;
   DevBufs& g = h->buf;
   struct Spec { int id; void** p; size_t bytes; };
@@ -1323,3 +1364,4 @@ extern "C" int sigmaenv_step_time_ms(sigmaenv_t* h, double* avg_ms, int32_t* n_l
   h->ev_used.clear();
   return SIGMAENV_OK;
 }
+

@@ -32,6 +32,7 @@ struct DevMap {
   int32_t P, n_paths, yaw_stride;
   // pruning table: axis-aligned boxes of runs of CHUNK consecutive real segments, [n_paths][3 (centre,left,right)][nch]
   const float4* chunk_box;  // (min_x, min_y, max_x, max_y)
+  const float4* group_box;  // union boxes of groups of 8 consecutive chunks, [n_paths][3][8]
   int32_t nch;              // boxes per polyline (stride); 0 disables pruning (brute-force scan)
   float rect_radius;        // upper bound of |vertex - centre| of a vehicle rectangle (half diagonal + slack)
 };
