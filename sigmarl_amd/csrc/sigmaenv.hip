@@ -208,39 +208,37 @@ __device__ __forceinline__ int nth_set_bit64(unsigned long long m, int c) {
   for (int t = 0; t < c; ++t) m &= (m - 1ull);
   return m ? (__ffsll((long long)m) - 1) : -1;
 }
-// per-agent inputs of the pruned scan, computed by ONE lane per agent (all agents of the tile in parallel, so the dependent
-// global loads overlap): point counts and the pruning thresholds T (see the exactness argument above).
-template <bool COLLIDE>
-__device__ inline void scan_prepare(const DevMap& m, const Smem& s, int sl, bool stale) {
-  const int path = s.path[sl];
-  const float cgx = s.st[sl * 8], cgy = s.st[sl * 8 + 1];
-  const int n = m.n_center[path], nl = m.n_left[path], nr = m.n_right[path];
-  s.npts[sl * 3 + 0] = n; s.npts[sl * 3 + 1] = nl; s.npts[sl * 3 + 2] = nr;
-  const float MARGIN = 1e-4f;
-  const float Rv = m.rect_radius;
-  const float Rq = stale ? query_radius(s.vold + sl * 10, cgx, cgy) : Rv;
-  const float floor_b = COLLIDE ? Rv : 0.0f;
-  s.thr[sl * 3 + 0] = guess_distance(m.center + (size_t)path * m.P * 2, n, s.cp[sl * 3 + 0], cgx, cgy) + MARGIN;
-  s.thr[sl * 3 + 1] = fmaxf(guess_distance(m.left + (size_t)path * m.P * 2, nl, s.cp[sl * 3 + 1], cgx, cgy) + 2.0f * Rq, floor_b) + MARGIN;
-  s.thr[sl * 3 + 2] = fmaxf(guess_distance(m.right + (size_t)path * m.P * 2, nr, s.cp[sl * 3 + 2], cgx, cgy) + 2.0f * Rq, floor_b) + MARGIN;
-}
-
 // candidate-chunk masks: bit c of the (agent, polyline) mask is set iff the bounding box of chunk c is within the scan threshold
 // of the agent's centre.  Two levels so that the far part of the polyline costs one box per 8 chunks (32 segments): first the <= 8
 // group boxes, then the 8 chunk boxes of every group that is within the threshold (usually one or two).  One lane per
-// (agent, polyline); the loads of a level are independent and in flight together.
+// (agent, polyline); the loads of a level are independent and in flight together.  The task also derives the threshold itself.
 __device__ __forceinline__ bool box_within(const float4 b, float px, float py, float T2) {
   float dx = fmaxf(fmaxf(b.x - px, px - b.z), 0.0f);
   float dy = fmaxf(fmaxf(b.y - py, py - b.w), 0.0f);
   return !((dx * dx + dy * dy) > T2);  // a NaN threshold keeps every box
 }
-__device__ inline void scan_mask_task(const DevMap& m, const Smem& s, int task) {
+template <bool COLLIDE>
+__device__ inline void scan_mask_task(const DevMap& m, const Smem& s, int task, bool stale_first, int N) {
+  // task = (agent slot, polyline): 0 centre line, 1 left boundary, 2 right boundary
   const int sl = task / 3, pl = task - sl * 3;
   const int path = s.path[sl];
   const float px = s.st[sl * 8], py = s.st[sl * 8 + 1];
-  const float T = s.thr[sl * 3 + pl];
+  const float* poly = (pl == 0 ? m.center : (pl == 1 ? m.left : m.right)) + (size_t)path * m.P * 2;
+  const int npt = (pl == 0 ? m.n_center : (pl == 1 ? m.n_left : m.n_right))[path];
+  s.npts[sl * 3 + pl] = npt;
+  // pruning threshold T (see the exactness argument above): distance to last step's closest segment, plus (boundaries) twice the
+  // radius of the query points around the centre -- exact for the agent whose corners are stale -- and at least the circumradius
+  // when the rectangle is also tested for collision
+  const float MARGIN = 1e-4f;
+  float T = guess_distance(poly, npt, s.cp[sl * 3 + pl], px, py);
+  if (pl != 0) {
+    const bool stale = stale_first && (sl % N == 0);
+    const float Rq = stale ? query_radius(s.vold + sl * 10, px, py) : m.rect_radius;
+    T = fmaxf(T + 2.0f * Rq, COLLIDE ? m.rect_radius : 0.0f);
+  }
+  T += MARGIN;
   const float T2 = T * T;
-  const int nch = (s.npts[sl * 3 + pl] - 1 + SIGMAENV_CHUNK - 1) / SIGMAENV_CHUNK;
+  const int nch = (npt - 1 + SIGMAENV_CHUNK - 1) / SIGMAENV_CHUNK;
   const float4* gbox = m.group_box + ((size_t)path * 3 + pl) * 8;
   const float4* box = m.chunk_box + ((size_t)path * 3 + pl) * m.nch;
   unsigned gm = 0u;
@@ -275,7 +273,6 @@ __device__ inline void pair_scan(const DevMap& m, const sigmaenv_config_t& c, co
   const float2* ctr2 = reinterpret_cast<const float2*>(m.center + (size_t)path * m.P * 2);
   const float2* pol2 = reinterpret_cast<const float2*>((side ? m.right : m.left) + (size_t)path * m.P * 2);
   const int n = s.npts[sl * 3], np = s.npts[sl * 3 + 1 + side];
-  const float Tc = s.thr[sl * 3], Tb = s.thr[sl * 3 + 1 + side];
   // ---- candidate chunk masks (scan_mask_task, one lane per (agent, polyline), computed before the scan)
   const unsigned long long mc = s.cmask[sl * 3], mb = s.cmask[sl * 3 + 1 + side];
   Edge e[4];
@@ -514,11 +511,10 @@ __global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigm
     s.path[sl] = g.path[gi * 4];
     // last step's closest-point indices: the pruned scan derives its distance upper bounds from them
     s.cp[sl * 3 + 0] = g.closest[gi * 3 + 0]; s.cp[sl * 3 + 1] = g.closest[gi * 3 + 1]; s.cp[sl * 3 + 2] = g.closest[gi * 3 + 2];
-    if (m.nch > 0) scan_prepare<true>(m, s, sl, sl % N == 0);
   }
   __syncthreads();
   if (m.nch > 0) {
-    for (int task = tid; task < t.slots * 3; task += blockDim.x) scan_mask_task(m, s, task);
+    for (int task = tid; task < t.slots * 3; task += blockDim.x) scan_mask_task<true>(m, s, task, true, N);
   }
   TS(1);
 
@@ -760,14 +756,13 @@ __device__ inline void reset_derive_body(const sigmaenv_config_t& c, const DevMa
       rect_vertices(c, s.st[sl * 8], s.st[sl * 8 + 1], s.st[sl * 8 + 2], v, &s.cs[sl * 2]);
 #pragma unroll
       for (int k = 0; k < 10; ++k) { s.vnew[sl * 10 + k] = v[k]; g.vertices[(t.a0 + sl) * 10 + k] = v[k]; }
-      if (m.nch > 0) scan_prepare<false>(m, s, sl, false);
     }
   }
   __syncthreads();
   if (m.nch > 0) {
     for (int task = tid; task < t.slots * 3; task += blockDim.x) {
       int sl = task / 3;
-      if ((agent_mask[sl / N] >> (sl % N)) & 1ull) scan_mask_task(m, s, task);
+      if ((agent_mask[sl / N] >> (sl % N)) & 1ull) scan_mask_task<false>(m, s, task, false, N);
     }
     __syncthreads();
     for (int pr = wave; 2 * pr < t.slots; pr += n_waves) {
@@ -1009,6 +1004,8 @@ struct sigmaenv {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   std::vector<int> ev_used;
   bool timing = false;
+  int timing_stride = 8;
+  unsigned long long launch_count = 0;
   std::string err;
 };
 
@@ -1213,6 +1210,7 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
     if (v >= 64 && v <= 256 && v % 64 == 0) h->block = v;
   }
   if (const char* e = getenv("SIGMAENV_DEBUG_SKIP")) h->dbg_skip = atoi(e);
+  if (const char* e = getenv("SIGMAENV_TIMING_STRIDE")) { int v = atoi(e); if (v >= 1) h->timing_stride = v; }
   h->grid = (B + h->G - 1) / h->G;
   h->reset_block = 256;  // measured at 16 x 4096: 512-thread reset workgroups are slower (more early-exit launch cost, lower occupancy)
   if (const char* e = getenv("SIGMAENV_RESET_BLOCK")) {
@@ -1282,7 +1280,9 @@ extern "C" int sigmaenv_reset(sigmaenv_t* h, int32_t n, const int32_t* env_idx, 
 extern "C" int sigmaenv_step(sigmaenv_t* h, const float* actions) {
   if (!h || !actions) return SIGMAENV_EINVAL;
   int slot = -1;
-  if (h->timing) {
+  // HIP-event bracketing of a SAMPLE of the launches (every timing_stride-th): every event pair costs a few microseconds of
+  // queue time, bracketing all launches would slow down the very region it measures
+  if (h->timing && (h->launch_count++ % h->timing_stride) == 0) {
     slot = (int)h->ev_used.size();
     if (slot >= (int)h->ev_pool.size()) {
       hipEvent_t a, b;
