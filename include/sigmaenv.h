@@ -158,9 +158,12 @@ int sigmaenv_step(sigmaenv_t* h, const float* actions);
 /* Recompute observations from the current state (observation() called again after resets). */
 int sigmaenv_observe(sigmaenv_t* h);
 
-/* Device-side reset of every env whose done flag is set: rejection sampling of collision-free starts
- * (bounded retries) on the paths [path_first, path_first + path_count) of the table, then the same deterministic
- * reset as sigmaenv_reset(full_env=1) and a fresh observation.  seed/counter select the counter-based random stream. */
+/* Device-side resets.  (1) Every env whose done flag is set: rejection sampling of collision-free starts (bounded retries) on the
+ * paths [path_first, path_first + path_count) of the table, then the same deterministic reset as sigmaenv_reset(full_env=1).
+ * (2) In every unfinished env, every agent with a pending reset request (SIGMAENV_BUF_COL_FLAGS[...,3]: left through an entry /
+ * exit segment, or collided in testing mode -- the per-agent resets ScenarioRoadTraffic.done performs, road_traffic.py:1435-1447,
+ * 1456-1473) is re-placed against all other agents, as sigmaenv_reset(full_env=0) would.  Touched envs get a fresh observation.
+ * seed/counter select the counter-based random stream. */
 int sigmaenv_auto_reset(sigmaenv_t* h, uint64_t seed, uint64_t counter, int32_t path_first, int32_t path_count);
 
 int sigmaenv_get(sigmaenv_t* h, sigmaenv_buf_t which, void** dev_ptr, size_t* bytes);

@@ -753,11 +753,63 @@ int sigmaenv_oracle_observe(oracle_t* o) {
   return SIGMAENV_OK;
 }
 
+/* per-agent resets of an unfinished env (road_traffic.py:1435-1447, :1456-1473): agents with a reset request in index order, each
+ * sampled against ALL other agents' current positions (is_reset_single_agent, world_state_rt_sim.py:287-309); tries 0..63 use the
+ * draws 2000 + 2t / 2001 + 2t, the speed draw 3000.  Then the single-agent reset of road_traffic.py:888-923 (derived state of the
+ * agent, env-wide mutual distances, all collision flags of the env cleared, prev_pos := pos) and a fresh observation. */
+static void auto_reset_agents(oracle_t* o, int b, uint64_t seed, uint64_t counter, int path_first, int path_count) {
+  int N = o->N;
+  const sigmaenv_config_t* c = &o->cfg;
+  float min_d = sqrtf((float)((double)c->length * (double)c->length + (double)c->width * (double)c->width)) * 1.5f;
+  float min_d_sq = min_d * min_d;
+  int any = 0;
+  uint64_t req = 0;
+  for (int i = 0; i < N; ++i) if (o->col_flags[((size_t)b * N + i) * 4 + 3]) { req |= 1ull << i; any = 1; }
+  if (!any) return;
+  for (int i = 0; i < N; ++i) {
+    if (!((req >> i) & 1)) continue;
+    size_t bi = (size_t)b * N + i;
+    float* s = o->state + bi * 8;
+    int path = path_first, pt = 3;
+    float px = 0.f, py = 0.f;
+    for (int t = 0; t < AUTO_RESET_MAX_TRIES; ++t) {
+      path = path_first + (int)(((uint64_t)rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, 2000u + 2u * t) * (uint64_t)(uint32_t)path_count) >> 32);
+      int n = o->n_center[path];
+      int end = n / 2;
+      if (end < 4) end = 4;
+      pt = 3 + (int)(((uint64_t)rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, 2001u + 2u * t) * (uint64_t)(uint32_t)(end - 3)) >> 32);
+      px = o->center[((size_t)path * o->P + pt) * 2]; py = o->center[((size_t)path * o->P + pt) * 2 + 1];
+      int ok = 1;
+      for (int j = 0; j < N; ++j) {
+        if (j == i) continue;
+        const float* sj = o->state + ((size_t)b * N + j) * 8;
+        float dx = px - sj[0], dy = py - sj[1];
+        float d2 = dx * dx + dy * dy;
+        if (!(d2 >= min_d_sq)) ok = 0;
+      }
+      if (ok) break;
+    }
+    float u = (float)(rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, 3000u) >> 8) * (1.0f / 16777216.0f);
+    int yi = pt < o->yaw_stride ? pt : o->yaw_stride - 1;
+    float rot = o->yaw[(size_t)path * o->yaw_stride + yi];
+    float speed = u * c->max_speed;
+    s[0] = px; s[1] = py; s[2] = rot; s[3] = speed; s[4] = 0.0f; s[7] = 0.0f;
+    s[5] = speed * cr_cos(0.0f + rot);
+    s[6] = speed * cr_sin(0.0f + rot);
+    o->path[bi * 4 + 0] = path; o->path[bi * 4 + 2] = path - path_first; o->path[bi * 4 + 3] = pt;
+  }
+  for (int i = 0; i < N; ++i) if ((req >> i) & 1) reset_agent_derived(o, b, i);
+  reset_env_tail(o, b, 0);
+  for (int i = 0; i < N; ++i) agent_observation(o, b, i);
+}
+
 int sigmaenv_oracle_auto_reset(oracle_t* o, uint64_t seed, uint64_t counter, int32_t path_first, int32_t path_count) {
   if (!o || path_first < 0 || path_count < 1 || path_first + path_count > o->n_paths) return SIGMAENV_EINVAL;
 #pragma omp parallel for schedule(static)
-  for (int b = 0; b < o->B; ++b)
+  for (int b = 0; b < o->B; ++b) {
     if (o->done[b]) auto_reset_env(o, b, seed, counter, path_first, path_count);
+    else auto_reset_agents(o, b, seed, counter, path_first, path_count);
+  }
   return SIGMAENV_OK;
 }
 

@@ -891,10 +891,14 @@ __global__ void __launch_bounds__(512) sigmaenv_auto_reset_kernel(sigmaenv_confi
   if (tid == 0) *s_any = 0;
   __syncthreads();
   if (tid < t.nenv) {
-    int dn = g.done[t.env0 + tid];
-    s_mask[tid] = dn ? ((N >= 64) ? ~0ull : ((1ull << N) - 1ull)) : 0ull;
+    const int dn = g.done[t.env0 + tid];
+    unsigned long long rq = 0ull;  // per-agent reset requests of an unfinished env (road_traffic.py:1435-1447, :1456-1473)
+    if (!dn && (c.is_testing_mode || c.has_entry_exit)) {  // no other configuration ever raises a request
+      for (int i = 0; i < N; ++i) rq |= (unsigned long long)(g.col_flags[((size_t)(t.env0 + tid) * N + i) * 4 + 3] != 0) << i;
+    }
+    s_mask[tid] = dn ? ((N >= 64) ? ~0ull : ((1ull << N) - 1ull)) : rq;
     s_full[tid] = dn;
-    if (dn) *s_any = 1;
+    if (dn || rq) *s_any = 1;
   }
   __syncthreads();
   if (!*s_any) return;
@@ -907,19 +911,60 @@ __global__ void __launch_bounds__(512) sigmaenv_auto_reset_kernel(sigmaenv_confi
   const float min_d = sqrtf((float)((double)c.length * (double)c.length + (double)c.width * (double)c.width)) * 1.5f;  // road_traffic.py:679-684
   const float min_d_sq = min_d * min_d;
   // candidate (path, point) of try `tr` for agent `i` of env `b` -- the draw layout shared with the oracle
-  auto candidate = [&](int b, int i, int tr, int& path, int& pt, float& px, float& py) {
-    path = path_first + (int)__umulhi(rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, 2u * tr), (uint32_t)path_count);
+  auto candidate = [&](int b, int i, int tr, int& path, int& pt, float& px, float& py, uint32_t draw0 = 0u) {
+    path = path_first + (int)__umulhi(rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, draw0 + 2u * tr), (uint32_t)path_count);
     int n = m.n_center[path];
     int end = n / 2;
     if (end < 4) end = 4;
-    pt = 3 + (int)__umulhi(rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, 2u * tr + 1u), (uint32_t)(end - 3));
+    pt = 3 + (int)__umulhi(rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, draw0 + 2u * tr + 1u), (uint32_t)(end - 3));
     px = m.center[((size_t)path * m.P + pt) * 2];
     py = m.center[((size_t)path * m.P + pt) * 2 + 1];
   };
   const int TR = 64 / N > 0 ? 64 / N : 1;  // tries per agent evaluated up front (all agents at once, loads in flight together)
   for (int e = wave; e < t.nenv; e += n_waves) {
-    if (!s_full[e]) continue;
     const int b = t.env0 + e;
+    if (!s_full[e]) {
+      // per-agent resets of an unfinished env (agents that left through an entry/exit, or collided in testing mode): agents in
+      // index order, each against ALL other agents' current positions (is_reset_single_agent, world_state_rt_sim.py:287-309);
+      // the 64 lanes evaluate tries 0..63 (draws 2000 + 2t, 2001 + 2t), first feasible wins, else the last one
+      unsigned long long rq = s_mask[e];
+      while (rq) {
+        const int i = __ffsll((long long)rq) - 1;
+        rq &= rq - 1ull;
+        const int sl = e * N + i;
+        int p2, q2;
+        float x2, y2;
+        candidate(b, i, lane, p2, q2, x2, y2, 2000u);
+        bool ok = true;
+        for (int j = 0; j < N; ++j) {
+          if (j == i) continue;
+          float dx = x2 - s.st[(e * N + j) * 8], dy = y2 - s.st[(e * N + j) * 8 + 1];
+          float d2 = dx * dx + dy * dy;
+          if (!(d2 >= min_d_sq)) ok = false;
+        }
+        unsigned long long f2 = __ballot(ok);
+        const int wl = f2 ? (__ffsll((long long)f2) - 1) : (AUTO_RESET_MAX_TRIES - 1);
+        if (lane == wl) {
+          float u = (float)(rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, 3000u) >> 8) * (1.0f / 16777216.0f);
+          int yi = q2 < m.yaw_stride ? q2 : m.yaw_stride - 1;
+          float rot = m.yaw[(size_t)p2 * m.yaw_stride + yi];
+          float speed = u * c.max_speed;
+          float sn, cs;
+          cr_sincos(0.0f + rot, sn, cs);
+          float st[8] = {x2, y2, rot, speed, 0.0f, speed * cs, speed * sn, 0.0f};
+          const size_t gi = t.a0 + sl;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { s.st[sl * 8 + k] = st[k]; g.state[gi * 8 + k] = st[k]; }
+          s.path[sl] = p2;
+          s.cp[sl * 3] = q2; s.cp[sl * 3 + 1] = q2; s.cp[sl * 3 + 2] = q2;  // scan guesses: the new centre-line point
+          g.path[gi * 4 + 0] = p2; g.path[gi * 4 + 2] = p2 - path_first; g.path[gi * 4 + 3] = q2;  // scenario_id is kept
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+      continue;
+    }
     const int ca = lane / TR, ctr = lane - ca * TR;  // this lane's (agent, try)
     const bool has_c = ca < N;
     int cpath = 0, cpt = 3;
@@ -974,7 +1019,7 @@ __global__ void __launch_bounds__(512) sigmaenv_auto_reset_kernel(sigmaenv_confi
   }
   __threadfence_block();
   __syncthreads();
-  reset_derive_body(c, m, g, s, t, s_mask, s_full, (G == 1) ? 2 : 1);
+  reset_derive_body(c, m, g, s, t, s_mask, s_full, (G == 1 && s_full[0]) ? 2 : 1);
 }
 
 // =====================================================================================================================

@@ -209,6 +209,7 @@ class WorldCustom:
             a.action.u = clamped[:, i]
         if self._scenario is not None:
             self._scenario._obs_dirty = False
+            self._scenario._auto_reset_done_this_step = False
 
 
 class ScenarioRoadTraffic(BaseScenario):
@@ -253,6 +254,11 @@ class ScenarioRoadTraffic(BaseScenario):
         self._world = world
         self._build_views()
         self._obs_dirty = True
+        # device_side_resets: serve BOTH the per-agent reset requests and the resets of finished envs inside done() with the
+        # device sampler (sigmaenv_auto_reset) instead of the reference's host loops over torch's generator.  The callbacks'
+        # results are the same tensors; only the random stream differs (distributional parity).  Off by default.
+        self.device_side_resets = bool(kwargs.pop("device_side_resets", getattr(self, "device_side_resets", False)))
+        self._auto_reset_done_this_step = False
         self.stored_observations = [None] * self.n_agents
         self._lanelet_table = torch.zeros((self.map.n_paths, max(1, self.map.n_lanelets_all)), dtype=torch.int32, device=device)
         ids = torch.as_tensor(self.map.lanelet_ids)
@@ -334,6 +340,8 @@ class ScenarioRoadTraffic(BaseScenario):
         if agent_index is not None:
             assert env_index is not None
             agent_index = int(agent_index)
+        if env_index is not None and agent_index is None and self._auto_reset_done_this_step:
+            return  # device_side_resets: done() already reset every finished env of this step on the GPU
         if env_index is None:
             if p.predefined_ref_path_idx is None:
                 if p.scenario_type == "cpm_mixed":
@@ -396,6 +404,13 @@ class ScenarioRoadTraffic(BaseScenario):
     def done(self):
         """[B] bool (road_traffic.py:1368-1487) + the per-agent resets the reference performs here (:1435-1447, :1456-1473)."""
         is_done = self.env.done.to(torch.bool)
+        if self.device_side_resets:
+            lid = 0 if self.parameters.scenario_type != "cpm_mixed" else 1
+            self.env.auto_reset(seed=int(getattr(self.parameters, "random_seed", 0)), path_first=self.map.list_first[lid],
+                                path_count=self.map.list_count[lid])
+            self._auto_reset_done_this_step = True
+            self._obs_dirty = False  # the reset kernel refreshed the observations of every touched env
+            return is_done
         if self.parameters.is_testing_mode or self.parameters.scenario_type != "cpm_entire":
             req = self.env.buffer(capi.BUF_COL_FLAGS)[..., 3]
             if bool(req.any()):

@@ -149,3 +149,32 @@ def test_host_driven_agent_resets(scen, N, testing):
     # every reset (and every step) leaves prev_pos == pos (state_buffer semantics, road_traffic.py:902-923,1226-1240)
     assert torch.equal(sc.env.buffer(capi.BUF_PREV_POS), sc.env.state[..., 0:2])
     sc.env.close()
+
+
+def test_device_side_resets_through_the_surface():
+    """device_side_resets=True: done() serves finished envs and per-agent requests on the GPU; TorchRL's later reset_world_at(e)
+    for the finished envs is then a no-op for that step."""
+    import torch
+    from sigmarl_amd.scenario import make_scenario
+
+    B, N = 64, 16
+    p = Parameters(n_agents=N, scenario_type="cpm_entire", is_use_mtv_distance=False, is_apply_mask=False, is_obs_noise=False)
+    sc = make_scenario(p)
+    sc.device_side_resets = True
+    world = sc.env_make_world(B, "cuda:0", n_agents=N)
+    sc.env_reset_world_at(None)
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    total_done = 0
+    for _ in range(8):
+        act = torch.rand((B, N, 2), generator=gen, device="cuda") - torch.tensor([0.0, 0.5], device="cuda")
+        obs, rew, done, info = _vmas_step(sc, act)
+        resets_before = int(sc.env.buffer(capi.BUF_TIMER)[:, 3].sum())
+        for e in torch.nonzero(done).flatten().tolist():
+            sc.env_reset_world_at(e)  # no second reset
+        assert int(sc.env.buffer(capi.BUF_TIMER)[:, 3].sum()) == resets_before
+        total_done += int(done.sum())
+        assert not sc.env.done.any() and (sc.timer.step[done] == 0).all()
+        new_obs = torch.stack([sc.observation(a) for a in world.agents], 1)
+        assert torch.isfinite(new_obs).all()
+    assert total_done > 0
+    sc.env.close()
