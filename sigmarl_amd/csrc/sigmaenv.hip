@@ -471,7 +471,7 @@ __device__ inline void observe_tile(const sigmaenv_config_t& c, const Smem& s, c
 // VMAS >= 1.4 call order restated per env: world.step(); reward(a) for all a; observation(a) for all a; done()
 // ---------------------------------------------------------------------------------------------------------------------
 #ifndef STEP_MIN_WAVES
-#define STEP_MIN_WAVES 1
+#define STEP_MIN_WAVES 4  // <= 128 VGPRs: 4 workgroups per CU resident, 16 workgroups per CU at 16x4096 = 4 full rounds
 #endif
 __global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigmaenv_config_t c, DevMap m, DevBufs g, const float* __restrict__ actions, int G, int dbg_skip) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
