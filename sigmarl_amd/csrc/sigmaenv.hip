@@ -34,10 +34,12 @@ __device__ __constant__ uint32_t W_REF_BITS[3] = {0x3F0E38E3u, 0x3EAAAAABu, 0x3D
 // ---------------------------------------------------------------------------------------------------------------------
 #define DIST_STRIDE(N) ((N) + 1)   /* odd float stride: lane-per-row column walks are bank-conflict free */
 #define COL_STRIDE(N) ((N) + 4)    /* byte stride whose word stride ((N+4)/4) is odd for N = 16 */
+#define CAND_LIST 16               /* candidate chunks listed per (agent, polyline); longer masks fall back to bit counting */
 struct Smem {
   float *st, *vold, *vnew, *shrt, *dref, *dleft, *dright, *dbound, *dist, *obs, *thr, *cs, *rew;
   int *path, *cp, *near, *flags, *npts;
   unsigned long long* cmask;  // candidate-chunk masks of the centre / left / right scan, [S][3]
+  uint8_t* cand;              // the first CAND_LIST set bits of every mask as a list of chunk indices, [S][3][CAND_LIST]
   uint8_t* col;
   __device__ Smem(char* base, int S, int N, int K, int D) {
     float* f = reinterpret_cast<float*>(base);
@@ -62,11 +64,12 @@ struct Smem {
     npts = i; i += S * 3;  // point counts of the agent's centre line / left / right boundary
     i += (S * 3) & 1;      // keep the 64-bit masks 8-byte aligned
     cmask = reinterpret_cast<unsigned long long*>(i); i += S * 3 * 2;
+    cand = reinterpret_cast<uint8_t*>(i); i += S * 3 * (CAND_LIST / 4);
     col = reinterpret_cast<uint8_t*>(i);
   }
   __host__ __device__ static size_t bytes(int S, int N, int K, int D) {
     size_t f = (size_t)S * 8 + S * 10 * 2 + S * NS * 2 + S + S * 5 * 2 + S + (size_t)S * DIST_STRIDE(N) + (size_t)S * D + S * 3 + S * 2 + S * 2;
-    size_t i = (size_t)S + S * 3 + S * (K > 0 ? K : 1) + S * 4 + S * 3 + 1 + (size_t)S * 3 * 2;
+    size_t i = (size_t)S + S * 3 + S * (K > 0 ? K : 1) + S * 4 + S * 3 + 1 + (size_t)S * 3 * 2 + (size_t)S * 3 * (CAND_LIST / 4);
     return (f + i) * 4 + (size_t)S * COL_STRIDE(N) + 16;
   }
 };
@@ -257,6 +260,11 @@ __device__ inline void scan_mask_task(const DevMap& m, const Smem& s, int task, 
     }
   }
   s.cmask[task] = mk;
+  uint8_t* cl = s.cand + task * CAND_LIST;
+  for (int j = 0; mk && j < CAND_LIST; ++j) {
+    cl[j] = (uint8_t)(__ffsll((long long)mk) - 1);
+    mk &= mk - 1ull;
+  }
 }
 
 template <bool COLLIDE>
@@ -275,6 +283,8 @@ __device__ inline void pair_scan(const DevMap& m, const sigmaenv_config_t& c, co
   const int n = s.npts[sl * 3], np = s.npts[sl * 3 + 1 + side];
   // ---- candidate chunk masks (scan_mask_task, one lane per (agent, polyline), computed before the scan)
   const unsigned long long mc = s.cmask[sl * 3], mb = s.cmask[sl * 3 + 1 + side];
+  const uint8_t* clc = s.cand + (sl * 3) * CAND_LIST;
+  const uint8_t* clb = s.cand + (sl * 3 + 1 + side) * CAND_LIST;
   Edge e[4];
   if (COLLIDE) {
 #pragma unroll
@@ -288,8 +298,9 @@ __device__ inline void pair_scan(const DevMap& m, const sigmaenv_config_t& c, co
   // one loop for both polylines so that the centre-line and boundary segment loads of a pass are in flight together
   for (int it = 0; __any(it * 32 < cnt_c || it * 16 < cnt_b); ++it) {
     const int jc = it * 32 + hl, jb = it * 16 + gl;
-    const int chc = (jc < cnt_c) ? nth_set_bit64(mc, jc / SIGMAENV_CHUNK) : -1;
-    const int chb = (jb < cnt_b) ? nth_set_bit64(mb, jb / SIGMAENV_CHUNK) : -1;
+    const int qc = jc / SIGMAENV_CHUNK, qb = jb / SIGMAENV_CHUNK;
+    const int chc = (jc < cnt_c) ? (qc < CAND_LIST ? (int)clc[qc] : nth_set_bit64(mc, qc)) : -1;
+    const int chb = (jb < cnt_b) ? (qb < CAND_LIST ? (int)clb[qb] : nth_set_bit64(mb, qb)) : -1;
     const int kc = chc * SIGMAENV_CHUNK + (jc % SIGMAENV_CHUNK), kb = chb * SIGMAENV_CHUNK + (jb % SIGMAENV_CHUNK);
     const bool do_c = chc >= 0 && kc + 1 < n, do_b = chb >= 0 && kb + 1 < np;
     float2 ca = make_float2(0.f, 0.f), cb = ca, ba = ca, bb2 = ca;
@@ -316,14 +327,16 @@ __device__ inline void pair_scan(const DevMap& m, const sigmaenv_config_t& c, co
       }
     }
   }
-  // ---- reductions: DPP inside the rows of 16 lanes; the centre line needs one cross-row step
-  row16_argmin(bd0, bk);
-  bs0 = row16_min(bs0); bs1 = row16_min(bs1); bs2 = row16_min(bs2); bs3 = row16_min(bs3);
-  row16_argmin(cd, ck);
+  // ---- reductions: DPP inside the rows of 16 lanes; the centre line needs one cross-row step.  The lexicographic
+  // (distance, index) minimum is taken as: minimum distance first, then the lowest index among the lanes that hold it.
   {
-    float od = __shfl_xor(cd, 16, 64);
-    int ok = __shfl_xor(ck, 16, 64);
-    if (od < cd || (od == cd && ok < ck)) { cd = od; ck = ok; }
+    const float bd_own = bd0, cd_own = cd;
+    row16_min6(bd0, bs0, bs1, bs2, bs3, cd);
+    cd = fminf(cd, __shfl_xor(cd, 16, 64));
+    int kb_c = (bd_own == bd0) ? bk : 0x7FFFFFFF, kc_c = (cd_own == cd) ? ck : 0x7FFFFFFF;
+    row16_min2_i32(kb_c, kc_c);
+    bk = kb_c;
+    ck = min(kc_c, __shfl_xor(kc_c, 16, 64));
   }
   const unsigned long long hb = COLLIDE ? __ballot(h && valid) : 0ull;
   if (gl == 0 && valid) {
@@ -492,6 +505,7 @@ __global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigm
     st[0] = s0.x; st[1] = s0.y; st[2] = s0.z; st[3] = s0.w; st[4] = s1.x; st[5] = s1.y; st[6] = s1.z; st[7] = s1.w;
     float2 u = reinterpret_cast<const float2*>(actions)[gi];
     bicycle_step(c, st, u.x, u.y, uc);
+    TS(6);
 #pragma unroll
     for (int k = 0; k < 8; ++k) s.st[sl * 8 + k] = st[k];
     reinterpret_cast<float2*>(g.action)[gi] = make_float2(uc[0], uc[1]);
@@ -513,6 +527,7 @@ __global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigm
     s.cp[sl * 3 + 0] = g.closest[gi * 3 + 0]; s.cp[sl * 3 + 1] = g.closest[gi * 3 + 1]; s.cp[sl * 3 + 2] = g.closest[gi * 3 + 2];
   }
   __syncthreads();
+  TS(7);
   if (m.nch > 0) {
     for (int task = tid; task < t.slots * 3; task += blockDim.x) scan_mask_task<true>(m, s, task, true, N);
   }

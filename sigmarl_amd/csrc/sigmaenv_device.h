@@ -321,6 +321,34 @@ __device__ __forceinline__ void row16_argmin(float& d, int& k) {
   SIGMA_ARGMIN_STEP(0x140)
 }
 
+// Six row-of-16 minima at once with the DPP operand folded into v_min_f32 (one instruction per step and value instead of
+// v_mov_dpp + canonicalise + v_min).  The six chains are interleaved step-major, so that a value is read through DPP five
+// instructions after the VALU write that produced it (the hardware needs two wait states there); the leading s_nop covers the
+// producers of the inputs.  Inputs are distances (>= 0 or +inf, never NaN for finite states).
+#define SIGMA_DPP_ROW6(OP, CTRL) \
+  OP " %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\t" OP " %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t" \
+  OP " %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\t" OP " %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf\n\t" \
+  OP " %4, %4, %4 " CTRL " row_mask:0xf bank_mask:0xf\n\t" OP " %5, %5, %5 " CTRL " row_mask:0xf bank_mask:0xf\n\t"
+__device__ __forceinline__ void row16_min6(float& a, float& b, float& c, float& d, float& e, float& f) {
+  asm volatile("s_nop 1\n\t"
+               SIGMA_DPP_ROW6("v_min_f32_dpp", "quad_perm:[1,0,3,2]")
+               SIGMA_DPP_ROW6("v_min_f32_dpp", "quad_perm:[2,3,0,1]")
+               SIGMA_DPP_ROW6("v_min_f32_dpp", "row_half_mirror")
+               SIGMA_DPP_ROW6("v_min_f32_dpp", "row_mirror")
+               : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
+}
+// two row-of-16 minima of non-negative ints (two interleaved chains, one s_nop between dependent steps)
+#define SIGMA_DPP_ROW2(OP, CTRL) \
+  OP " %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\t" OP " %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
+__device__ __forceinline__ void row16_min2_i32(int& a, int& b) {
+  asm volatile("s_nop 1\n\t"
+               SIGMA_DPP_ROW2("v_min_i32_dpp", "quad_perm:[1,0,3,2]")
+               SIGMA_DPP_ROW2("v_min_i32_dpp", "quad_perm:[2,3,0,1]")
+               SIGMA_DPP_ROW2("v_min_i32_dpp", "row_half_mirror")
+               SIGMA_DPP_ROW2("v_min_i32_dpp", "row_mirror")
+               : "+v"(a), "+v"(b));
+}
+
 // counter-based RNG (specification shared with the oracle): 32-bit multiplicative mix + murmur3 finalisers over (seed, counter, env, agent, draw)
 __device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint64_t counter, uint32_t env, uint32_t agent, uint32_t draw) {
   uint32_t h = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9E3779B9u);
