@@ -267,7 +267,7 @@ __device__ inline void scan_mask_task(const DevMap& m, const Smem& s, int task, 
   }
 }
 
-template <bool COLLIDE>
+template <bool COLLIDE, bool FASTDIV>
 __device__ inline void pair_scan(const DevMap& m, const sigmaenv_config_t& c, const Smem& s, int slotA, int valid_mask, int lane, bool stale_first, int N) {
   // valid_mask: bit 0 = scan agent slotA, bit 1 = scan agent slotA + 1 (an unselected half mirrors the selected one, results dropped)
   const int grp = lane >> 4, ag = grp >> 1, side = grp & 1, gl = lane & 15, hl = lane & 31;
@@ -308,18 +308,20 @@ __device__ inline void pair_scan(const DevMap& m, const sigmaenv_config_t& c, co
     if (do_b) { ba = pol2[kb]; bb2 = pol2[kb + 1]; }
     if (do_c) {
       float lx = cb.x - ca.x, ly = cb.y - ca.y;
-      float d = point_segment(cgx, cgy, ca.x, ca.y, lx, ly, lx * lx + ly * ly);
+      float len2 = lx * lx + ly * ly;
+      float d = point_segment_t<FASTDIV>(cgx, cgy, ca.x, ca.y, lx, ly, len2, FASTDIV ? shared_rcp(len2) : 0.0f);
       if (d < cd || (d == cd && kc < ck)) { cd = d; ck = kc; }
     }
     if (do_b) {
       float lx = bb2.x - ba.x, ly = bb2.y - ba.y;
       float len2 = lx * lx + ly * ly;
-      float d0 = point_segment(cgx, cgy, ba.x, ba.y, lx, ly, len2);
+      const float rcp = FASTDIV ? shared_rcp(len2) : 0.0f;
+      float d0 = point_segment_t<FASTDIV>(cgx, cgy, ba.x, ba.y, lx, ly, len2, rcp);
       if (d0 < bd0 || (d0 == bd0 && kb < bk)) { bd0 = d0; bk = kb; }
-      bs0 = fminf(bs0, point_segment_sq(q0x, q0y, ba.x, ba.y, lx, ly, len2));
-      bs1 = fminf(bs1, point_segment_sq(q1x, q1y, ba.x, ba.y, lx, ly, len2));
-      bs2 = fminf(bs2, point_segment_sq(q2x, q2y, ba.x, ba.y, lx, ly, len2));
-      bs3 = fminf(bs3, point_segment_sq(q3x, q3y, ba.x, ba.y, lx, ly, len2));
+      bs0 = fminf(bs0, point_segment_sq_t<FASTDIV>(q0x, q0y, ba.x, ba.y, lx, ly, len2, rcp));
+      bs1 = fminf(bs1, point_segment_sq_t<FASTDIV>(q1x, q1y, ba.x, ba.y, lx, ly, len2, rcp));
+      bs2 = fminf(bs2, point_segment_sq_t<FASTDIV>(q2x, q2y, ba.x, ba.y, lx, ly, len2, rcp));
+      bs3 = fminf(bs3, point_segment_sq_t<FASTDIV>(q3x, q3y, ba.x, ba.y, lx, ly, len2, rcp));
       if (COLLIDE) {
         float S2 = lx * ba.y - ly * ba.x;
 #pragma unroll
@@ -560,7 +562,11 @@ __global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigm
   // ---- B2: distance queries + boundary collisions (two agents per wavefront; full-scan fallback one agent per wavefront) ----
   if (dbg_skip & 2) {
   } else if (m.nch > 0) {
-    for (int pr = wave; 2 * pr < t.slots; pr += n_waves) pair_scan<true>(m, c, s, 2 * pr, (2 * pr + 1 < t.slots) ? 3 : 1, lane, true, N);
+    if (m.fast_div) {
+      for (int pr = wave; 2 * pr < t.slots; pr += n_waves) pair_scan<true, true>(m, c, s, 2 * pr, (2 * pr + 1 < t.slots) ? 3 : 1, lane, true, N);
+    } else {
+      for (int pr = wave; 2 * pr < t.slots; pr += n_waves) pair_scan<true, false>(m, c, s, 2 * pr, (2 * pr + 1 < t.slots) ? 3 : 1, lane, true, N);
+    }
   } else {
     for (int sl = wave; sl < t.slots; sl += n_waves) {
       const int i = sl % N;
@@ -785,7 +791,8 @@ __device__ inline void reset_derive_body(const sigmaenv_config_t& c, const DevMa
       bool ma = (agent_mask[sa / N] >> (sa % N)) & 1ull;
       bool mb = (sb < t.slots) && ((agent_mask[sb / N] >> (sb % N)) & 1ull);
       if (!(ma || mb)) continue;
-      pair_scan<false>(m, c, s, sa, (ma ? 1 : 0) | (mb ? 2 : 0), lane, false, N);
+      if (m.fast_div) pair_scan<false, true>(m, c, s, sa, (ma ? 1 : 0) | (mb ? 2 : 0), lane, false, N);
+      else pair_scan<false, false>(m, c, s, sa, (ma ? 1 : 0) | (mb ? 2 : 0), lane, false, N);
     }
   } else {
     for (int sl = wave; sl < t.slots; sl += n_waves) {
@@ -1226,7 +1233,21 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
   }
   const float lh = (float)((double)cfg->length / 2.0), wh = (float)((double)cfg->width / 2.0);
   const float rect_radius = sqrtf(lh * lh + wh * wh) * 1.00001f + 1e-5f;
-  h->map = DevMap{d_c, d_l, d_r, d_y, d_nc, d_nl, d_nr, d_loop, P, np, S, d_box, d_gbox, prune ? nch : 0, rect_radius};
+  // the shared-reciprocal division (div_shared) is exact when no segment needs the scaling of the general IEEE sequence
+  int fast_div = 1;
+  for (int p = 0; p < np && fast_div; ++p) {
+    const float* polys[3] = {hc.data() + (size_t)p * P * 2, hl.data() + (size_t)p * P * 2, hr.data() + (size_t)p * P * 2};
+    const int cnt[3] = {map->n_center[p], map->n_left[p], map->n_right[p]};
+    for (int q = 0; q < 3 && fast_div; ++q) {
+      for (int k = 0; k + 1 < cnt[q]; ++k) {
+        const float lx = polys[q][2 * (k + 1)] - polys[q][2 * k], ly = polys[q][2 * (k + 1) + 1] - polys[q][2 * k + 1];
+        const float len2 = lx * lx + ly * ly;  // the kernel's operation order (no contraction)
+        if (!(len2 >= 0x1p-60f && len2 <= 0x1p60f)) { fast_div = 0; break; }
+      }
+    }
+  }
+  if (const char* e = getenv("SIGMAENV_FASTDIV")) fast_div = fast_div && atoi(e) != 0;
+  h->map = DevMap{d_c, d_l, d_r, d_y, d_nc, d_nl, d_nr, d_loop, P, np, S, d_box, d_gbox, prune ? nch : 0, fast_div, rect_radius};
   const size_t BN = (size_t)B * N;
   DevBufs& g = h->buf;
   struct Spec { int id; void** p; size_t bytes; };

@@ -34,6 +34,7 @@ struct DevMap {
   const float4* chunk_box;  // (min_x, min_y, max_x, max_y)
   const float4* group_box;  // union boxes of groups of 8 consecutive chunks, [n_paths][3][8]
   int32_t nch;              // boxes per polyline (stride); 0 disables pruning (brute-force scan)
+  int32_t fast_div;         // every real segment has 2^-60 <= |l|^2 <= 2^60: the shared-reciprocal division is exact (div_shared)
   float rect_radius;        // upper bound of |vertex - centre| of a vehicle rectangle (half diagonal + slack)
 };
 #define SIGMAENV_CHUNK 4
@@ -146,6 +147,45 @@ __device__ __forceinline__ float point_segment(float px, float py, float sx, flo
 __device__ __forceinline__ float point_segment_sq(float px, float py, float sx, float sy, float lx, float ly, float len2) {
   float vx = px - sx, vy = py - sy;
   float proj = (vx * lx + vy * ly) / len2;
+  float t = clampf(proj, 0.0f, 1.0f);
+  float cx = sx + lx * t, cy = sy + ly * t;
+  float ex = cx - px, ey = cy - py;
+  return fmaf(ey, ey, ex * ex);
+}
+
+// Division by a denominator shared between several numerators (the five queries of one segment divide by the same |l|^2).
+// This is the compiler's own IEEE fp32 division sequence (rcp, one Newton step, quotient, two fma corrections) with the
+// reciprocal hoisted and WITHOUT the v_div_scale / v_div_fixup wrapping, which only matters when the denominator is denormal or
+// above 2^126, the quotient is denormal, the exponents differ by 96 or more, or the numerator is below 2^-103.  The map table is
+// checked at sigmaenv_create (2^-60 <= |l|^2 <= 2^60, else fast_div is off and the plain `/` is used); numerators are dot products
+// of fp32 coordinate differences, i.e. exactly zero or far above 2^-103.  In that regime the result is the correctly rounded
+// quotient, bit-identical to `/`.
+__device__ __forceinline__ float shared_rcp(float b) {
+  float y0 = __builtin_amdgcn_rcpf(b);
+  float e = fmaf(-b, y0, 1.0f);
+  return fmaf(e, y0, y0);
+}
+__device__ __forceinline__ float div_shared(float a, float b, float y) {
+  float q = a * y;
+  float r = fmaf(-b, q, a);
+  q = fmaf(r, y, q);
+  r = fmaf(-b, q, a);
+  return fmaf(r, y, q);
+}
+template <bool FAST>
+__device__ __forceinline__ float point_segment_t(float px, float py, float sx, float sy, float lx, float ly, float len2, float rcp) {
+  float vx = px - sx, vy = py - sy;
+  float num = vx * lx + vy * ly;
+  float proj = FAST ? div_shared(num, len2, rcp) : num / len2;
+  float t = clampf(proj, 0.0f, 1.0f);
+  float cx = sx + lx * t, cy = sy + ly * t;
+  return norm2(cx - px, cy - py);
+}
+template <bool FAST>
+__device__ __forceinline__ float point_segment_sq_t(float px, float py, float sx, float sy, float lx, float ly, float len2, float rcp) {
+  float vx = px - sx, vy = py - sy;
+  float num = vx * lx + vy * ly;
+  float proj = FAST ? div_shared(num, len2, rcp) : num / len2;
   float t = clampf(proj, 0.0f, 1.0f);
   float cx = sx + lx * t, cy = sy + ly * t;
   float ex = cx - px, ey = cy - py;
