@@ -34,15 +34,18 @@ __device__ __constant__ uint32_t W_REF_BITS[3] = {0x3F0E38E3u, 0x3EAAAAABu, 0x3D
 // ---------------------------------------------------------------------------------------------------------------------
 #define DIST_STRIDE(N) ((N) + 1)   /* odd float stride: lane-per-row column walks are bank-conflict free */
 #define COL_STRIDE(N) ((N) + 4)    /* byte stride whose word stride ((N+4)/4) is odd for N = 16 */
+#define ESCR_BYTES (8 * 4 * 4 * 16) /* up to 8 wavefronts x 4 lane groups x 4 segments x float4 */
 #define CAND_LIST 16               /* candidate chunks listed per (agent, polyline); longer masks fall back to bit counting */
 struct Smem {
   float *st, *vold, *vnew, *shrt, *dref, *dleft, *dright, *dbound, *dist, *obs, *thr, *cs, *rew;
   int *path, *cp, *near, *flags, *npts;
   unsigned long long* cmask;  // candidate-chunk masks of the centre / left / right scan, [S][3]
   uint8_t* cand;              // the first CAND_LIST set bits of every mask as a list of chunk indices, [S][3][CAND_LIST]
+  float4* escr;               // B2 staging of the segments close enough to hit the rectangle, [MAX_WAVES][4 lane groups][4]
   uint8_t* col;
   __device__ Smem(char* base, int S, int N, int K, int D) {
-    float* f = reinterpret_cast<float*>(base);
+    escr = reinterpret_cast<float4*>(base);  // first: the dynamic LDS base is 16-byte aligned
+    float* f = reinterpret_cast<float*>(base + ESCR_BYTES);
     st = f; f += S * 8;
     vold = f; f += S * 10;
     vnew = f; f += S * 10;
@@ -70,7 +73,7 @@ struct Smem {
   __host__ __device__ static size_t bytes(int S, int N, int K, int D) {
     size_t f = (size_t)S * 8 + S * 10 * 2 + S * NS * 2 + S + S * 5 * 2 + S + (size_t)S * DIST_STRIDE(N) + (size_t)S * D + S * 3 + S * 2 + S * 2;
     size_t i = (size_t)S + S * 3 + S * (K > 0 ? K : 1) + S * 4 + S * 3 + 1 + (size_t)S * 3 * 2 + (size_t)S * 3 * (CAND_LIST / 4);
-    return (f + i) * 4 + (size_t)S * COL_STRIDE(N) + 16;
+    return ESCR_BYTES + (f + i) * 4 + (size_t)S * COL_STRIDE(N) + 16;
   }
 };
 
@@ -285,11 +288,8 @@ __device__ inline void pair_scan(const DevMap& m, const sigmaenv_config_t& c, co
   const unsigned long long mc = s.cmask[sl * 3], mb = s.cmask[sl * 3 + 1 + side];
   const uint8_t* clc = s.cand + (sl * 3) * CAND_LIST;
   const uint8_t* clb = s.cand + (sl * 3 + 1 + side) * CAND_LIST;
-  Edge e[4];
-  if (COLLIDE) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) e[i] = make_edge(ev[2 * i], ev[2 * i + 1], ev[2 * i + 2], ev[2 * i + 3]);
-  }
+  float4* escr = s.escr + ((threadIdx.x >> 6) * 4 + grp) * 4;
+  const float near_thr = m.rect_radius + 1e-4f;
   const float q0x = qv[0], q0y = qv[1], q1x = qv[2], q1y = qv[3], q2x = qv[4], q2y = qv[5], q3x = qv[6], q3y = qv[7];
   const int cnt_c = __popcll(mc) * SIGMAENV_CHUNK, cnt_b = __popcll(mb) * SIGMAENV_CHUNK;
   float cd = INFINITY, bd0 = INFINITY, bs0 = INFINITY, bs1 = INFINITY, bs2 = INFINITY, bs3 = INFINITY;
@@ -312,20 +312,38 @@ __device__ inline void pair_scan(const DevMap& m, const sigmaenv_config_t& c, co
       float d = point_segment_t<FASTDIV>(cgx, cgy, ca.x, ca.y, lx, ly, len2, FASTDIV ? shared_rcp(len2) : 0.0f);
       if (d < cd || (d == cd && kc < ck)) { cd = d; ck = kc; }
     }
+    float d0 = INFINITY;
     if (do_b) {
       float lx = bb2.x - ba.x, ly = bb2.y - ba.y;
       float len2 = lx * lx + ly * ly;
       const float rcp = FASTDIV ? shared_rcp(len2) : 0.0f;
-      float d0 = point_segment_t<FASTDIV>(cgx, cgy, ba.x, ba.y, lx, ly, len2, rcp);
+      d0 = point_segment_t<FASTDIV>(cgx, cgy, ba.x, ba.y, lx, ly, len2, rcp);
       if (d0 < bd0 || (d0 == bd0 && kb < bk)) { bd0 = d0; bk = kb; }
       bs0 = fminf(bs0, point_segment_sq_t<FASTDIV>(q0x, q0y, ba.x, ba.y, lx, ly, len2, rcp));
       bs1 = fminf(bs1, point_segment_sq_t<FASTDIV>(q1x, q1y, ba.x, ba.y, lx, ly, len2, rcp));
       bs2 = fminf(bs2, point_segment_sq_t<FASTDIV>(q2x, q2y, ba.x, ba.y, lx, ly, len2, rcp));
       bs3 = fminf(bs3, point_segment_sq_t<FASTDIV>(q3x, q3y, ba.x, ba.y, lx, ly, len2, rcp));
-      if (COLLIDE) {
-        float S2 = lx * ba.y - ly * ba.x;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) h |= edge_hits_segment(e[i], ba.x, ba.y, bb2.x, bb2.y, lx, ly, S2);
+    }
+    if (COLLIDE) {
+      // Only a segment within the rectangle's circumradius of the (new) centre can cross an edge (same argument as the pruning,
+      // DESIGN.md).  Those few segments (1-3 per boundary) are staged in LDS and the (segment, edge) tests are spread over the
+      // lanes of the group, one test per lane, instead of four edge tests in every lane.
+      const bool nearseg = do_b && !(d0 > near_thr);
+      const unsigned long long nb = __ballot(nearseg);
+      if (nb) {
+        const unsigned gm16 = (unsigned)(nb >> (grp * 16)) & 0xFFFFu;
+        const int rank = __popc(gm16 & ((1u << gl) - 1u)), cntn = __popc(gm16);
+        for (int p0 = 0; __any(p0 < cntn); p0 += 4) {
+          if (nearseg && rank >= p0 && rank < p0 + 4) escr[rank - p0] = make_float4(ba.x, ba.y, bb2.x, bb2.y);
+          if (p0 + (gl >> 2) < cntn) {
+            const float4 sg = escr[gl >> 2];
+            const float* pv = ev + 2 * (gl & 3);
+            const Edge e = make_edge(pv[0], pv[1], pv[2], pv[3]);
+            const float lx2 = sg.z - sg.x, ly2 = sg.w - sg.y;
+            const float S2 = lx2 * sg.y - ly2 * sg.x;
+            h |= edge_hits_segment(e, sg.x, sg.y, sg.z, sg.w, lx2, ly2, S2);
+          }
+        }
       }
     }
   }
