@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--distance", choices=["c2c", "mtv"], default="c2c")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 disables it)")
     ap.add_argument("--no-reset", action="store_true", help="diagnostic: leave finished envs un-reset")
+    ap.add_argument("--separate-reset", action="store_true", help="two launches per step (sigmaenv_step; sigmaenv_auto_reset) instead of the fused one")
     ap.add_argument("--no-gather", action="store_true", help="diagnostic: skip the rollout-slab gather for N > 1")
     ap.add_argument("--chunk-steps", type=int, default=32, help="steps per rollout chunk gathered to the learner rank (N > 1)")
     ap.add_argument("--force-dist", action="store_true", help="diagnostic: init RCCL and run the gather even with one rank")
@@ -154,12 +155,15 @@ def main():
     def one_step(t):
         if gather is not None:
             env.set_slab(gather.slot())
-        env.step(acts[t % n_act])
+        if args.no_reset or args.separate_reset:
+            env.step(acts[t % n_act])
+            if not args.no_reset:
+                env.auto_reset(seed=seed, counter=counter[0], path_first=pf, path_count=pc)
+        else:  # one launch: the step, its record, then the device-side reset of the finished envs of the tile
+            env.step_autoreset(acts[t % n_act], seed=seed, counter=counter[0], path_first=pf, path_count=pc)
+        counter[0] += 1
         if gather is not None:
             gather.advance()
-        if not args.no_reset:
-            env.auto_reset(seed=seed, counter=counter[0], path_first=pf, path_count=pc)
-            counter[0] += 1
 
     for t in range(args.warmup):
         one_step(t)
@@ -192,7 +196,10 @@ def main():
     total_agent_steps = N * B * world * args.steps
     value = total_agent_steps / elapsed
     bytes_per = algorithmic_bytes_per_agent_step(N)
-    achieved = (bytes_per * N * B) / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None
+    fused = not (args.no_reset or args.separate_reset)
+    # the fused launch also rewrites the whole record of every agent of a reset env: 320 + 5 N bytes
+    reset_bytes = (320 + 5 * N) * N * (dones / max(1, args.steps)) if fused else 0.0
+    achieved = (bytes_per * N * B + reset_bytes) / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None
     traffic = None
     try:  # HBM bytes per launch from the separate rocprofv3 --pmc passes (tools/pmc_passes.sh), corrected as the MI355X guide says
         with open(os.path.join(ROOT, "profiles", "traffic_latest.json")) as f:
@@ -208,14 +215,15 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {
             "workload": f"cpm_entire map, {N} agents x {B} envs per GPU ({B * world} envs total), {args.distance} distance, rew_method=distance, "
-                        f"dt=0.05, obs_dim={env.D}, fused step + device-side reset of finished envs" + (" + rollout-slab gather" if gather else ""),
+                        f"dt=0.05, obs_dim={env.D}, fused step + device-side reset of finished envs "
+                        + ("(one launch)" if fused else "(two launches)" if not args.no_reset else "(resets disabled)") + (" + rollout-slab gather" if gather else ""),
             "n_agents": N, "envs_per_gpu": B, "envs_total": B * world, "distance": args.distance,
             "resets_per_step_per_gpu": dones / max(1, args.steps), "rollout_gather": gather_note,
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": (achieved / 8000.0) if achieved else None,
             "traffic": traffic, "kernel": "sigmaenv_step_kernel", "kernel_avg_ms": kernel_ms, "kernel_launches": n_launch,
-            "algorithmic_bytes_per_agent_env_step": bytes_per,
+            "algorithmic_bytes_per_agent_env_step": bytes_per, "algorithmic_bytes_per_launch": bytes_per * N * B + reset_bytes,
         },
     }
     if rank == 0 and args.cpu_seconds > 0 and world == 1:

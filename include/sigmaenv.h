@@ -166,6 +166,13 @@ int sigmaenv_observe(sigmaenv_t* h);
  * seed/counter select the counter-based random stream. */
 int sigmaenv_auto_reset(sigmaenv_t* h, uint64_t seed, uint64_t counter, int32_t path_first, int32_t path_count);
 
+/* sigmaenv_step immediately followed by sigmaenv_auto_reset, in ONE launch: after the record of the step is complete (all
+ * buffers, and the rollout slab row with the terminal observation / reward / done flag), the workgroup that still holds the tile
+ * in LDS re-places its finished envs / requesting agents.  Bit-identical end state to the two separate calls; what a rollout
+ * loop with TorchRL's step_and_maybe_reset semantics needs per step (sigmarl/helper_training.py:687-788).  Note: the terminal
+ * observation is only visible in the slab -- SIGMAENV_BUF_OBS holds the post-reset observation when the call returns. */
+int sigmaenv_step_autoreset(sigmaenv_t* h, const float* actions, uint64_t seed, uint64_t counter, int32_t path_first, int32_t path_count);
+
 int sigmaenv_get(sigmaenv_t* h, sigmaenv_buf_t which, void** dev_ptr, size_t* bytes);
 
 /* Rollout slab (wire format of the learner-boundary exchange): when dev_ptr != NULL every following sigmaenv_step also writes

@@ -106,6 +106,7 @@ _SIGS = {
 _PRODUCT_ONLY = {
     "step_time_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "set_slab": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "step_autoreset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32]),
 }
 
 

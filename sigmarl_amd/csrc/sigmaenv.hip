@@ -503,10 +503,16 @@ __device__ inline void observe_tile(const sigmaenv_config_t& c, const Smem& s, c
 // the fused step kernel: grid = ceil(n_envs / G), block = 64 * waves
 // VMAS >= 1.4 call order restated per env: world.step(); reward(a) for all a; observation(a) for all a; done()
 // ---------------------------------------------------------------------------------------------------------------------
+struct Smem;
+__device__ inline void auto_reset_tile(const sigmaenv_config_t& c, const DevMap& m, const DevBufs& g, const Smem& s, const Tile& t,
+                                       const unsigned long long* s_mask, const int* s_full, uint64_t seed, uint64_t counter, int path_first,
+                                       int path_count, int obs_mode);
+#define MAX_G 64
 #ifndef STEP_MIN_WAVES
 #define STEP_MIN_WAVES 4  // <= 128 VGPRs: 4 workgroups per CU resident, 16 workgroups per CU at 16x4096 = 4 full rounds
 #endif
-__global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigmaenv_config_t c, DevMap m, DevBufs g, const float* __restrict__ actions, int G, int dbg_skip) {
+__global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigmaenv_config_t c, DevMap m, DevBufs g, const float* __restrict__ actions, int G, int dbg_skip,
+                                                                              uint64_t seed, uint64_t counter, int path_first, int path_count) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const Tile t(c, G);
   const int N = t.N;
@@ -712,6 +718,7 @@ __global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigm
       if (c.is_testing_mode) rq = col_a | col_l | entry | goal;
       else if (c.has_entry_exit) rq = entry | goal;
       reinterpret_cast<uchar4*>(g.col_flags)[gi] = make_uchar4((uint8_t)col_l, (uint8_t)entry, (uint8_t)goal, (uint8_t)((rq && !done) ? 1 : 0));
+      s.flags[sl * 4 + 3] = (rq && !done) ? 1 : 0;
       if (i == 0) {
         g.timer[b * 4] = step;
         g.timer[b * 4 + 1] += __popcll(b_any & env_mask);
@@ -736,6 +743,26 @@ __global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigm
   }
   TS(5);
 #undef TS
+  // ---- fused device-side resets (sigmaenv_step_autoreset): the tile is still in LDS, the record of this step is written -------
+  if (path_count > 0) {
+    unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(smem_raw + ((Smem::bytes(G * N, N, t.K, t.D) + 15) & ~(size_t)15));
+    int* s_full = reinterpret_cast<int*>(s_mask + MAX_G);
+    int* s_any = s_full + MAX_G;
+    if (tid == 0) *s_any = 0;
+    __syncthreads();  // also: the slab rows above have read s.obs / s.rew
+    if (tid < t.nenv) {
+      const int dn = s.rew[G * N + tid] != 0.0f;
+      unsigned long long rq = 0ull;
+      if (!dn && (c.is_testing_mode || c.has_entry_exit)) {
+        for (int i = 0; i < N; ++i) rq |= (unsigned long long)(s.flags[(tid * N + i) * 4 + 3] != 0) << i;
+      }
+      s_mask[tid] = dn ? ((N >= 64) ? ~0ull : ((1ull << N) - 1ull)) : rq;
+      s_full[tid] = dn;
+      if (dn || rq) *s_any = 1;
+    }
+    __syncthreads();
+    if (*s_any) auto_reset_tile(c, m, g, s, t, s_mask, s_full, seed, counter, path_first, path_count, 2);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -784,10 +811,13 @@ __global__ void sigmaenv_reset_scatter_kernel(DevBufs g, int N, int n, const int
 // per-env tail (road_traffic.py:902-923) for the envs of the tile whose bit is set in env_bits; with_obs: also a fresh
 // observation of the whole tile.  Expects s.st / s.path / s.vnew / s.cp (scan guesses) of the tile in LDS; agent_mask[e] is the
 // per-env agent bit mask, full[e] the full-env flag.  All threads of the block participate.
+__device__ inline void reset_finish_body(const sigmaenv_config_t& c, const DevBufs& g, const Smem& s, const Tile& t,
+                                         const unsigned long long* agent_mask, const int* full, int with_obs);
 __device__ inline void reset_derive_body(const sigmaenv_config_t& c, const DevMap& m, const DevBufs& g, const Smem& s, const Tile& t,
                                          const unsigned long long* agent_mask, const int* full, int with_obs) {
   const int N = t.N;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
+#define TS2(k) do { if (g.dbg_ts2 && tid == 0) g.dbg_ts2[(size_t)blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
   for (int sl = tid; sl < t.slots; sl += blockDim.x) {
     int e = sl / N, i = sl - e * N;
     if ((agent_mask[e] >> i) & 1ull) {
@@ -804,6 +834,7 @@ __device__ inline void reset_derive_body(const sigmaenv_config_t& c, const DevMa
       if ((agent_mask[sl / N] >> (sl % N)) & 1ull) scan_mask_task<false>(m, s, task, false, N);
     }
     __syncthreads();
+    TS2(3);
     for (int pr = wave; 2 * pr < t.slots; pr += n_waves) {
       int sa = 2 * pr, sb = 2 * pr + 1;
       bool ma = (agent_mask[sa / N] >> (sa % N)) & 1ull;
@@ -827,6 +858,7 @@ __device__ inline void reset_derive_body(const sigmaenv_config_t& c, const DevMa
     }
   }
   __syncthreads();
+  TS2(4);
   for (int sl = tid; sl < t.slots; sl += blockDim.x) {  // only the marked agents' derived state is replaced
     int e = sl / N, i = sl - e * N;
     if (!((agent_mask[e] >> i) & 1ull)) continue;
@@ -847,7 +879,18 @@ __device__ inline void reset_derive_body(const sigmaenv_config_t& c, const DevMa
 #pragma unroll
     for (int k = 0; k < NS * 2; ++k) { g.short_term[gi * NS * 2 + k] = sp[k]; s.shrt[sl * NS * 2 + k] = sp[k]; }
   }
-  // tail of every touched env: mutual distances, collisions cleared, prev_pos := pos, timer
+#undef TS2
+  reset_finish_body(c, g, s, t, agent_mask, full, with_obs);
+}
+
+// tail of every touched env: mutual distances, collisions cleared, prev_pos := pos, timer (road_traffic.py:902-923); with_obs:
+// also a fresh observation of the whole tile (2: every input of it is already in LDS).  Expects the derived state of the marked
+// agents in LDS and HBM.
+__device__ inline void reset_finish_body(const sigmaenv_config_t& c, const DevBufs& g, const Smem& s, const Tile& t,
+                                         const unsigned long long* agent_mask, const int* full, int with_obs) {
+  const int N = t.N;
+  const int tid = threadIdx.x;
+#define TS2(k) do { if (g.dbg_ts2 && tid == 0) g.dbg_ts2[(size_t)blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
   const float diag = sqrtf(c.world_x_dim * c.world_x_dim + c.world_y_dim * c.world_y_dim);
   for (int p = tid; p < t.slots * N; p += blockDim.x) {
     int si = p / N, j = p - si * N;
@@ -876,13 +919,14 @@ __device__ inline void reset_derive_body(const sigmaenv_config_t& c, const DevMa
   if (with_obs) {
     __threadfence_block();
     __syncthreads();
+    TS2(5);
     // with every agent of the tile marked (device-side full-env reset) all inputs of the observation are already in LDS
     if (with_obs != 2) load_tile_for_observation(s, g, t);
     observe_tile(c, s, g, t);
+    TS2(6);
   }
+#undef TS2
 }
-
-#define MAX_G 64
 
 // host-driven resets: only tiles with marked agents do work
 __global__ void __launch_bounds__(512) sigmaenv_reset_derive_kernel(sigmaenv_config_t c, DevMap m, DevBufs g, int with_obs, int G) {
@@ -915,39 +959,149 @@ __global__ void __launch_bounds__(512) sigmaenv_reset_derive_kernel(sigmaenv_con
   reset_derive_body(c, m, g, s, t, s_mask, s_full, with_obs);
 }
 
-// Device-side reset of finished envs (tiles without a finished env exit at once).  One wavefront per finished env runs the
-// rejection sampler of world_state_rt_sim.py:215-311 (non-testing mode) from a counter-based RNG: the 64 lanes evaluate tries
-// 0..63 of one agent at once and the FIRST feasible try wins, which is exactly the sequential loop's result for the same draws
-// (bounded to 64 tries; the reference loops without bound).  Then the deterministic reset as in sigmaenv_reset(full_env=1).
-__global__ void __launch_bounds__(512) sigmaenv_auto_reset_kernel(sigmaenv_config_t c, DevMap m, DevBufs g, uint64_t seed, uint64_t counter,
-                                                                  int path_first, int path_count, int G) {
+// Start table (DevMap::start_table): one workgroup derives 64 consecutive (path, point) rows with the same code the resets use
+// (rect_vertices, scan_mask_task, pair_scan, short_term_path), so that copying a row is bit-identical to deriving it in place.
+__global__ void __launch_bounds__(256) sigmaenv_start_table_kernel(sigmaenv_config_t c, DevMap m, float* table) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const Tile t(c, G);
-  const int N = t.N;
+  const int S = 64;
+  Smem s(smem_raw, S, 1, 0, 1);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
-  unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(smem_raw + ((Smem::bytes(G * N, N, t.K, t.D) + 15) & ~(size_t)15));
-  int* s_full = reinterpret_cast<int*>(s_mask + MAX_G);
-  int* s_any = s_full + MAX_G;
-  if (tid == 0) *s_any = 0;
-  __syncthreads();
-  if (tid < t.nenv) {
-    const int dn = g.done[t.env0 + tid];
-    unsigned long long rq = 0ull;  // per-agent reset requests of an unfinished env (road_traffic.py:1435-1447, :1456-1473)
-    if (!dn && (c.is_testing_mode || c.has_entry_exit)) {  // no other configuration ever raises a request
-      for (int i = 0; i < N; ++i) rq |= (unsigned long long)(g.col_flags[((size_t)(t.env0 + tid) * N + i) * 4 + 3] != 0) << i;
+  __shared__ unsigned long long s_valid;
+  __shared__ float s_cosv[64], s_sinv[64];
+  const int total = m.n_paths * m.P;
+  const int idx = blockIdx.x * S + lane;
+  const int path = idx < total ? idx / m.P : 0, pt = idx < total ? idx - (idx / m.P) * m.P : 0;
+  const bool valid = idx < total && pt < m.n_center[path];
+  if (wave == 0) {
+    const unsigned long long vb = __ballot(valid);
+    if (lane == 0) s_valid = vb;
+    const int sl = lane;
+    float x = 0.f, y = 0.f, rot = 0.f;
+    if (valid) {
+      x = m.center[((size_t)path * m.P + pt) * 2];
+      y = m.center[((size_t)path * m.P + pt) * 2 + 1];
+      rot = m.yaw[(size_t)path * m.yaw_stride + (pt < m.yaw_stride ? pt : m.yaw_stride - 1)];
     }
-    s_mask[tid] = dn ? ((N >= 64) ? ~0ull : ((1ull << N) - 1ull)) : rq;
-    s_full[tid] = dn;
-    if (dn || rq) *s_any = 1;
+    s.st[sl * 8] = x; s.st[sl * 8 + 1] = y; s.st[sl * 8 + 2] = rot;
+    float v[10];
+    rect_vertices(c, x, y, rot, v, &s.cs[sl * 2]);
+#pragma unroll
+    for (int k = 0; k < 10; ++k) s.vnew[sl * 10 + k] = v[k];
+    s.path[sl] = path;
+    s.cp[sl * 3] = pt; s.cp[sl * 3 + 1] = pt; s.cp[sl * 3 + 2] = pt;  // the scan guesses of a reset (sigmaenv_auto_reset)
+    s_cosv[sl] = cr_cos(0.0f + rot);
+    s_sinv[sl] = cr_sin(0.0f + rot);
   }
   __syncthreads();
-  if (!*s_any) return;
-  Smem s(smem_raw, G * N, N, t.K, t.D);
-  // untouched envs of the tile keep their state (needed for the tile-wide observation)
-  for (int k = tid; k < t.slots * 8; k += blockDim.x) s.st[k] = g.state[t.a0 * 8 + k];
-  for (int k = tid; k < t.slots * 10; k += blockDim.x) s.vnew[k] = g.vertices[t.a0 * 10 + k];
-  for (int k = tid; k < t.slots; k += blockDim.x) s.path[k] = g.path[(t.a0 + k) * 4];
+  const unsigned long long vm = s_valid;
+  if (m.nch > 0) {
+    for (int task = tid; task < S * 3; task += blockDim.x) {
+      if ((vm >> (task / 3)) & 1ull) scan_mask_task<false>(m, s, task, false, 1);
+    }
+    __syncthreads();
+    for (int pr = wave; 2 * pr < S; pr += n_waves) {
+      const int va = (int)((vm >> (2 * pr)) & 1ull), vb = (int)((vm >> (2 * pr + 1)) & 1ull);
+      if (!(va || vb)) continue;
+      if (m.fast_div) pair_scan<false, true>(m, c, s, 2 * pr, va | (vb << 1), lane, false, 1);
+      else pair_scan<false, false>(m, c, s, 2 * pr, va | (vb << 1), lane, false, 1);
+    }
+  } else {
+    for (int sl = wave; sl < S; sl += n_waves) {
+      if (!((vm >> sl) & 1ull)) continue;
+      AgentScan r;
+      agent_scan_full<false>(m, c, s.path[sl], lane, s.st[sl * 8], s.st[sl * 8 + 1], s.vnew + sl * 10, s.vnew + sl * 10, r);
+      if (lane == 0) {
+        s.dref[sl] = r.d_ref;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) { s.dleft[sl * 5 + q] = r.dl[q]; s.dright[sl * 5 + q] = r.dr[q]; }
+        s.cp[sl * 3 + 0] = r.cp_ref; s.cp[sl * 3 + 1] = r.cp_l; s.cp[sl * 3 + 2] = r.cp_r;
+      }
+    }
+  }
   __syncthreads();
+  if (wave == 0 && idx < total) {
+    const int sl = lane;
+    float* row = table + (size_t)idx * START_ROW;
+    for (int k = 0; k < START_ROW; ++k) row[k] = 0.0f;
+    if (valid) {
+      row[START_X] = s.st[sl * 8]; row[START_X + 1] = s.st[sl * 8 + 1]; row[START_X + 2] = s.st[sl * 8 + 2];
+      row[START_COSV] = s_cosv[sl]; row[START_COSV + 1] = s_sinv[sl];
+      for (int k = 0; k < 10; ++k) row[START_VERT + k] = s.vnew[sl * 10 + k];
+      row[START_CS] = s.cs[sl * 2]; row[START_CS + 1] = s.cs[sl * 2 + 1];
+      row[START_DREF] = s.dref[sl];
+      float mbnd = INFINITY;
+      for (int q = 0; q < 5; ++q) { row[START_DLEFT + q] = s.dleft[sl * 5 + q]; row[START_DRIGHT + q] = s.dright[sl * 5 + q]; }
+      for (int q = 0; q < 5; ++q) mbnd = fminf(mbnd, s.dleft[sl * 5 + q]);
+      for (int q = 0; q < 5; ++q) mbnd = fminf(mbnd, s.dright[sl * 5 + q]);
+      row[START_DBOUND] = mbnd;
+      float sp[NS * 2];
+      short_term_path(m.center + (size_t)path * m.P * 2, m.n_center[path], m.is_loop[path] != 0, s.cp[sl * 3], sp);
+      for (int k = 0; k < NS * 2; ++k) row[START_SHORT + k] = sp[k];
+      for (int k = 0; k < 3; ++k) row[START_CP + k] = __int_as_float(s.cp[sl * 3 + k]);
+    }
+  }
+}
+
+// place agent slot `sl` on centre-line point `pt` of path `path` with speed `speed`: state and every derived tensor of the agent
+// come from the start table (LDS and HBM), as reset + reset_init_distances_and_short_term_ref_path leave them
+// (world_state_rt_sim.py:189-213, world_state_rt.py:422-529)
+__device__ __forceinline__ void place_from_start_table(const DevMap& m, const DevBufs& g, const Smem& s, const Tile& t, int sl, int path, int pt,
+                                                       float speed, int path_first, bool full_env) {
+  const float4* row4 = reinterpret_cast<const float4*>(m.start_table + ((size_t)path * m.P + pt) * START_ROW);
+  float r[START_ROW];
+#pragma unroll
+  for (int k = 0; k < START_ROW / 4; ++k) { float4 q = row4[k]; r[4 * k] = q.x; r[4 * k + 1] = q.y; r[4 * k + 2] = q.z; r[4 * k + 3] = q.w; }
+  const size_t gi = t.a0 + sl;
+  const float st[8] = {r[START_X], r[START_X + 1], r[START_X + 2], speed, 0.0f, speed * r[START_COSV], speed * r[START_COSV + 1], 0.0f};
+  float4* gs = reinterpret_cast<float4*>(g.state + gi * 8);
+  gs[0] = make_float4(st[0], st[1], st[2], st[3]);
+  gs[1] = make_float4(st[4], st[5], st[6], st[7]);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s.st[sl * 8 + k] = st[k];
+  float2* gv = reinterpret_cast<float2*>(g.vertices + gi * 10);
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    s.vnew[sl * 10 + 2 * k] = r[START_VERT + 2 * k]; s.vnew[sl * 10 + 2 * k + 1] = r[START_VERT + 2 * k + 1];
+    gv[k] = make_float2(r[START_VERT + 2 * k], r[START_VERT + 2 * k + 1]);
+  }
+  s.cs[sl * 2] = r[START_CS]; s.cs[sl * 2 + 1] = r[START_CS + 1];
+  s.dref[sl] = r[START_DREF];
+  g.dist_ref[gi] = r[START_DREF];
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    s.dleft[sl * 5 + q] = r[START_DLEFT + q]; s.dright[sl * 5 + q] = r[START_DRIGHT + q];
+    g.dist_left[gi * 5 + q] = r[START_DLEFT + q]; g.dist_right[gi * 5 + q] = r[START_DRIGHT + q];
+  }
+  s.dbound[sl] = r[START_DBOUND];
+  g.dist_bound[gi] = r[START_DBOUND];
+  float2* gso = reinterpret_cast<float2*>(g.short_term + gi * NS * 2);
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    s.shrt[sl * NS * 2 + 2 * k] = r[START_SHORT + 2 * k]; s.shrt[sl * NS * 2 + 2 * k + 1] = r[START_SHORT + 2 * k + 1];
+    gso[k] = make_float2(r[START_SHORT + 2 * k], r[START_SHORT + 2 * k + 1]);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { const int cpk = __float_as_int(r[START_CP + k]); s.cp[sl * 3 + k] = cpk; g.closest[gi * 3 + k] = cpk; }
+  s.path[sl] = path;
+  g.path[gi * 4 + 0] = path;
+  if (full_env) g.path[gi * 4 + 1] = 0;  // scenario_id is kept by a per-agent reset
+  g.path[gi * 4 + 2] = path - path_first;
+  g.path[gi * 4 + 3] = pt;
+}
+
+// Device-side reset of the marked envs / agents of one tile (s_mask[e]: agents to re-place, s_full[e]: the env is finished and
+// restarts as a whole).  Expects s.st / s.vnew / s.path of the whole tile in LDS.  One wavefront per env runs the rejection
+// sampler of world_state_rt_sim.py:215-311 (non-testing mode) from a counter-based RNG: the lanes evaluate 64/N tries of every
+// agent up front and the FIRST feasible try wins, which is exactly the sequential loop's result for the same draws (bounded to
+// 64 tries; the reference loops without bound).  Then the deterministic reset as in sigmaenv_reset and a fresh observation.
+// All threads of the block participate.
+__device__ inline void auto_reset_tile(const sigmaenv_config_t& c, const DevMap& m, const DevBufs& g, const Smem& s, const Tile& t,
+                                       const unsigned long long* s_mask, const int* s_full, uint64_t seed, uint64_t counter, int path_first,
+                                       int path_count, int obs_mode) {
+  const int N = t.N;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
+#define TS2(k) do { if (g.dbg_ts2 && tid == 0) g.dbg_ts2[(size_t)blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+  TS2(1);
   const float min_d = sqrtf((float)((double)c.length * (double)c.length + (double)c.width * (double)c.width)) * 1.5f;  // road_traffic.py:679-684
   const float min_d_sq = min_d * min_d;
   // candidate (path, point) of try `tr` for agent `i` of env `b` -- the draw layout shared with the oracle
@@ -986,18 +1140,7 @@ __global__ void __launch_bounds__(512) sigmaenv_auto_reset_kernel(sigmaenv_confi
         const int wl = f2 ? (__ffsll((long long)f2) - 1) : (AUTO_RESET_MAX_TRIES - 1);
         if (lane == wl) {
           float u = (float)(rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, 3000u) >> 8) * (1.0f / 16777216.0f);
-          int yi = q2 < m.yaw_stride ? q2 : m.yaw_stride - 1;
-          float rot = m.yaw[(size_t)p2 * m.yaw_stride + yi];
-          float speed = u * c.max_speed;
-          float sn, cs;
-          cr_sincos(0.0f + rot, sn, cs);
-          float st[8] = {x2, y2, rot, speed, 0.0f, speed * cs, speed * sn, 0.0f};
-          const size_t gi = t.a0 + sl;
-#pragma unroll
-          for (int k = 0; k < 8; ++k) { s.st[sl * 8 + k] = st[k]; g.state[gi * 8 + k] = st[k]; }
-          s.path[sl] = p2;
-          s.cp[sl * 3] = q2; s.cp[sl * 3 + 1] = q2; s.cp[sl * 3 + 2] = q2;  // scan guesses: the new centre-line point
-          g.path[gi * 4 + 0] = p2; g.path[gi * 4 + 2] = p2 - path_first; g.path[gi * 4 + 3] = q2;  // scenario_id is kept
+          place_from_start_table(m, g, s, t, sl, p2, q2, u * c.max_speed, path_first, false);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1044,22 +1187,52 @@ __global__ void __launch_bounds__(512) sigmaenv_auto_reset_kernel(sigmaenv_confi
     }
     if (lane < N) {  // finalise the accepted starts, one lane per agent (world_state_rt_sim.py:189-213)
       const int i = lane, sl = e * N + i;
-      const size_t gi = t.a0 + sl;
-      const int path = s.path[sl], pt = s.cp[sl * 3];
       float u = (float)(rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, 1000u) >> 8) * (1.0f / 16777216.0f);
-      int yi = pt < m.yaw_stride ? pt : m.yaw_stride - 1;
-      float rot = m.yaw[(size_t)path * m.yaw_stride + yi];
-      float speed = u * c.max_speed;
-      float st[8] = {s.st[sl * 8], s.st[sl * 8 + 1], rot, speed, 0.0f, speed * cr_cos(0.0f + rot), speed * cr_sin(0.0f + rot), 0.0f};
-#pragma unroll
-      for (int k = 0; k < 8; ++k) { s.st[sl * 8 + k] = st[k]; g.state[gi * 8 + k] = st[k]; }
-      s.cp[sl * 3 + 1] = pt; s.cp[sl * 3 + 2] = pt;
-      g.path[gi * 4 + 0] = path; g.path[gi * 4 + 1] = 0; g.path[gi * 4 + 2] = path - path_first; g.path[gi * 4 + 3] = pt;
+      place_from_start_table(m, g, s, t, sl, s.path[sl], s.cp[sl * 3], u * c.max_speed, path_first, true);
     }
   }
   __threadfence_block();
   __syncthreads();
-  reset_derive_body(c, m, g, s, t, s_mask, s_full, (G == 1 && s_full[0]) ? 2 : 1);
+  TS2(2);
+  reset_finish_body(c, g, s, t, s_mask, s_full, obs_mode);
+#undef TS2
+}
+
+// stand-alone launch: one workgroup per tile; tiles without a finished env / a reset request exit at once
+__global__ void __launch_bounds__(512) sigmaenv_auto_reset_kernel(sigmaenv_config_t c, DevMap m, DevBufs g, uint64_t seed, uint64_t counter,
+                                                                  int path_first, int path_count, int G) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const Tile t(c, G);
+  const int N = t.N;
+  const int tid = threadIdx.x;
+  unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(smem_raw + ((Smem::bytes(G * N, N, t.K, t.D) + 15) & ~(size_t)15));
+  int* s_full = reinterpret_cast<int*>(s_mask + MAX_G);
+  int* s_any = s_full + MAX_G;
+#define TS2(k) do { if (g.dbg_ts2 && tid == 0) g.dbg_ts2[(size_t)blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+  if (g.dbg_ts2 && tid < 8) g.dbg_ts2[(size_t)blockIdx.x * 8 + tid] = 0ull;
+  TS2(0);
+#undef TS2
+  if (tid == 0) *s_any = 0;
+  __syncthreads();
+  if (tid < t.nenv) {
+    const int dn = g.done[t.env0 + tid];
+    unsigned long long rq = 0ull;  // per-agent reset requests of an unfinished env (road_traffic.py:1435-1447, :1456-1473)
+    if (!dn && (c.is_testing_mode || c.has_entry_exit)) {  // no other configuration ever raises a request
+      for (int i = 0; i < N; ++i) rq |= (unsigned long long)(g.col_flags[((size_t)(t.env0 + tid) * N + i) * 4 + 3] != 0) << i;
+    }
+    s_mask[tid] = dn ? ((N >= 64) ? ~0ull : ((1ull << N) - 1ull)) : rq;
+    s_full[tid] = dn;
+    if (dn || rq) *s_any = 1;
+  }
+  __syncthreads();
+  if (!*s_any) return;
+  Smem s(smem_raw, G * N, N, t.K, t.D);
+  // untouched envs of the tile keep their state (needed for the tile-wide observation)
+  for (int k = tid; k < t.slots * 8; k += blockDim.x) s.st[k] = g.state[t.a0 * 8 + k];
+  for (int k = tid; k < t.slots * 10; k += blockDim.x) s.vnew[k] = g.vertices[t.a0 * 10 + k];
+  for (int k = tid; k < t.slots; k += blockDim.x) s.path[k] = g.path[(t.a0 + k) * 4];
+  __syncthreads();
+  auto_reset_tile(c, m, g, s, t, s_mask, s_full, seed, counter, path_first, path_count, (G == 1 && s_full[0]) ? 2 : 1);
 }
 
 // =====================================================================================================================
@@ -1265,7 +1438,17 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
     }
   }
   if (const char* e = getenv("SIGMAENV_FASTDIV")) fast_div = fast_div && atoi(e) != 0;
-  h->map = DevMap{d_c, d_l, d_r, d_y, d_nc, d_nl, d_nr, d_loop, P, np, S, d_box, d_gbox, prune ? nch : 0, fast_div, rect_radius};
+  h->map = DevMap{d_c, d_l, d_r, d_y, d_nc, d_nl, d_nr, d_loop, P, np, S, d_box, d_gbox, prune ? nch : 0, nullptr, fast_div, rect_radius};
+  {  // start table: derived state of an agent placed on any centre-line point, by the kernels' own scan code
+    float* d_tab = nullptr;
+    ALLOC(d_tab, (size_t)np * P * START_ROW * sizeof(float));
+    const size_t tab_smem = Smem::bytes(64, 1, 0, 1) + 16;
+    if (tab_smem > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_start_table_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tab_smem);
+    hipLaunchKernelGGL(sigmaenv_start_table_kernel, dim3((np * P + 63) / 64), dim3(256), tab_smem, h->stream, h->cfg, h->map, d_tab);
+    HIPCHK(h, hipGetLastError());
+    h->map.start_table = d_tab;
+  }
   const size_t BN = (size_t)B * N;
   DevBufs& g = h->buf;
   struct Spec { int id; void** p; size_t bytes; };
@@ -1290,8 +1473,10 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
   ALLOC(g.reset_full, (size_t)B);
   g.slab = nullptr;
   g.dbg_ts = nullptr;
+  g.dbg_ts2 = nullptr;
   if (const char* e = getenv("SIGMAENV_TIMESTAMPS")) {
-    if (atoi(e) != 0) { ALLOC(g.dbg_ts, (size_t)B * 8 * sizeof(unsigned long long)); }
+    if (atoi(e) == 1) { ALLOC(g.dbg_ts, (size_t)B * 8 * sizeof(unsigned long long)); }
+    if (atoi(e) == 2) { ALLOC(g.dbg_ts2, (size_t)B * 8 * sizeof(unsigned long long)); hipMemsetAsync(g.dbg_ts2, 0, (size_t)B * 64, h->stream); }
   }
 #undef ALLOC
 #undef H2D
@@ -1376,7 +1561,7 @@ extern "C" int sigmaenv_reset(sigmaenv_t* h, int32_t n, const int32_t* env_idx, 
   return SIGMAENV_OK;
 }
 
-extern "C" int sigmaenv_step(sigmaenv_t* h, const float* actions) {
+static int launch_step(sigmaenv* h, const float* actions, uint64_t seed, uint64_t counter, int path_first, int path_count) {
   if (!h || !actions) return SIGMAENV_EINVAL;
   int slot = -1;
   // HIP-event bracketing of a SAMPLE of the launches (every timing_stride-th): every event pair costs a few microseconds of
@@ -1392,10 +1577,18 @@ extern "C" int sigmaenv_step(sigmaenv_t* h, const float* actions) {
     h->ev_used.push_back(slot);
     HIPCHK(h, hipEventRecord(h->ev_pool[slot].first, h->stream));
   }
-  hipLaunchKernelGGL(sigmaenv_step_kernel, dim3(h->grid), dim3(h->block), h->smem_bytes, h->stream, h->cfg, h->map, h->buf, actions, h->G, h->dbg_skip);
+  hipLaunchKernelGGL(sigmaenv_step_kernel, dim3(h->grid), dim3(h->block), h->smem_bytes, h->stream, h->cfg, h->map, h->buf, actions, h->G, h->dbg_skip,
+                     seed, counter, path_first, path_count);
   HIPCHK(h, hipGetLastError());
   if (slot >= 0) HIPCHK(h, hipEventRecord(h->ev_pool[slot].second, h->stream));
   return SIGMAENV_OK;
+}
+
+extern "C" int sigmaenv_step(sigmaenv_t* h, const float* actions) { return launch_step(h, actions, 0, 0, 0, 0); }
+
+extern "C" int sigmaenv_step_autoreset(sigmaenv_t* h, const float* actions, uint64_t seed, uint64_t counter, int32_t path_first, int32_t path_count) {
+  if (!h || path_first < 0 || path_count < 1 || path_first + path_count > h->n_paths) return SIGMAENV_EINVAL;
+  return launch_step(h, actions, seed, counter, path_first, path_count);
 }
 
 extern "C" int sigmaenv_observe(sigmaenv_t* h) {
@@ -1438,6 +1631,12 @@ extern "C" int sigmaenv_set_slab(sigmaenv_t* h, void* dev_ptr) {
 // workgroups, 0 when SIGMAENV_TIMESTAMPS was not set at create.
 extern "C" int sigmaenv_debug_timestamps(sigmaenv_t* h, unsigned long long* out, int32_t max_groups) {
   if (!h || !out) return SIGMAENV_EINVAL;
+  if (!h->buf.dbg_ts && h->buf.dbg_ts2) {
+    int n2 = max_groups < h->B ? max_groups : h->B;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(out, h->buf.dbg_ts2, (size_t)n2 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return n2;
+  }
   if (!h->buf.dbg_ts) return 0;
   int n = h->grid < max_groups ? h->grid : max_groups;
   HIPCHK(h, hipStreamSynchronize(h->stream));

@@ -34,10 +34,25 @@ struct DevMap {
   const float4* chunk_box;  // (min_x, min_y, max_x, max_y)
   const float4* group_box;  // union boxes of groups of 8 consecutive chunks, [n_paths][3][8]
   int32_t nch;              // boxes per polyline (stride); 0 disables pruning (brute-force scan)
+  const float* start_table; // derived state of an agent freshly placed on centre-line point pt of path p, [n_paths][P][START_ROW]
   int32_t fast_div;         // every real segment has 2^-60 <= |l|^2 <= 2^60: the shared-reciprocal division is exact (div_shared)
   float rect_radius;        // upper bound of |vertex - centre| of a vehicle rectangle (half diagonal + slack)
 };
 #define SIGMAENV_CHUNK 4
+// row of the start table (floats): everything reset_init_distances_and_short_term_ref_path derives for an agent standing on a
+// centre-line point with the map's yaw there -- a pure function of (path, point), computed once at sigmaenv_create by the very
+// kernels' own scan code and copied by the device-side resets
+#define START_X 0        /* x, y, yaw */
+#define START_COSV 3     /* cr_cos(0 + yaw), cr_sin(0 + yaw): velocity direction (world_state_rt_sim.py:203-207) */
+#define START_VERT 5     /* 10 floats */
+#define START_CS 15      /* cos / sin of the yaw as rect_vertices produces them */
+#define START_DREF 17
+#define START_DLEFT 18   /* 5 */
+#define START_DRIGHT 23  /* 5 */
+#define START_DBOUND 28
+#define START_SHORT 29   /* 6 */
+#define START_CP 35      /* 3 ints */
+#define START_ROW 40
 
 struct DevBufs {
   float *state, *prev_pos, *vertices, *short_term, *dist_ref, *dist_left, *dist_right, *dist_bound, *dist_agents;
@@ -47,6 +62,7 @@ struct DevBufs {
   unsigned long long* reset_mask;  // [B] bit i: agent i needs its derived state rebuilt
   uint8_t* reset_full;             // [B] full-env reset pending
   float* slab;                     // optional rollout record of this step: [B][N*D obs | N reward | 1 done] fp32 (sigmaenv_set_slab)
+  unsigned long long* dbg_ts2;     // same for the auto-reset kernel (SIGMAENV_TIMESTAMPS=2)
   unsigned long long* dbg_ts;      // optional [grid][8] shader-clock timestamps at the phase boundaries (SIGMAENV_TIMESTAMPS=1)
 };
 

@@ -180,6 +180,21 @@ class SigmaEnv:
     def observe(self):
         self._chk(self.lib.observe(self.h), "observe")
 
+    def step_autoreset(self, actions: torch.Tensor, seed: int = 0, counter: int | None = None, path_first: int | None = None,
+                       path_count: int | None = None):
+        """``step`` + ``auto_reset`` in one launch (same end state); the terminal observation goes to the slab only."""
+        if not (isinstance(actions, torch.Tensor) and actions.is_cuda and actions.dtype == torch.float32 and actions.is_contiguous()):
+            raise TypeError("actions must be a contiguous float32 CUDA tensor")
+        if tuple(actions.shape) != (self.B, self.N, 2):
+            raise ValueError(f"actions must have shape {(self.B, self.N, 2)}, got {tuple(actions.shape)}")
+        if counter is None:
+            counter = self._reset_counter
+            self._reset_counter += 1
+        if path_first is None:
+            path_first, path_count = self.map.list_first[0], self.map.list_count[0]
+        self._chk(self.lib.step_autoreset(self.h, C.c_void_p(actions.data_ptr()), int(seed), int(counter), int(path_first), int(path_count)),
+                  "step_autoreset")
+
     def auto_reset(self, seed: int = 0, counter: int | None = None, path_first: int | None = None, path_count: int | None = None):
         if counter is None:
             counter = self._reset_counter
@@ -249,6 +264,11 @@ class NumpyAdapter:
 
     def auto_reset(self, seed, counter, path_first, path_count):
         self.env.auto_reset(seed, counter, path_first, path_count)
+
+    def step_autoreset(self, actions, seed, counter, path_first, path_count):
+        a = torch.as_tensor(np.ascontiguousarray(actions, np.float32).reshape(self.B, self.N, 2)).to(self.env.device)
+        self.env.step_autoreset(a, seed, counter, path_first, path_count)
+        self.env.sync()
 
     def get(self, which, copy=True):
         self.env.sync()

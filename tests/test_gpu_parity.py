@@ -297,3 +297,50 @@ def test_device_side_agent_resets_on_exit(scen):
     assert exits > 0 and served > 0
     dev.close()
     ora.close()
+
+
+@pytest.mark.parametrize("scen,N,B,mtv,rew,dt,testing", [
+    ("cpm_entire", 16, 200, False, "distance", 0.05, False),       # whole tiles of 4 envs with 0..4 finished envs each
+    ("cpm_entire", 5, 33, True, "ttc_sparse", 0.1, False),         # ragged tile
+    ("cpm_entire", 8, 24, True, "sparse", 0.1, True),              # testing mode: per-agent requests inside the fused tail
+    ("intersection_1", 4, 40, False, "distance", 0.1, False),      # entry / exit requests
+])
+def test_fused_step_autoreset_equals_step_then_auto_reset(scen, N, B, mtv, rew, dt, testing):
+    """sigmaenv_step_autoreset == sigmaenv_step; sigmaenv_auto_reset -- every buffer bit-identical after every step, and the slab
+    row written by the fused launch holds the terminal observation / reward / done flag of the step (HIP separate == oracle is
+    covered above, so the fused launch is tied to the oracle through it)."""
+    import torch
+    from sigmarl_amd.shard import slab_width, unpack_slab
+
+    p = Parameters(n_agents=N, scenario_type=scen, is_use_mtv_distance=mtv, rew_method=rew, dt=dt, is_testing_mode=testing,
+                   is_apply_mask=False, is_obs_noise=False, max_steps=9)
+    mp = load_map(scen)
+    cfg = make_config(p, mp, B)
+    pf, pc = mp.list_first[0], mp.list_count[0]
+    sep, fus = _hip_env(cfg, mp), _hip_env(cfg, mp)
+    for d in (sep, fus):
+        d.env.buffer(capi.BUF_DONE).fill_(1)
+        d.auto_reset(5, 0, pf, pc)
+    W = slab_width(N, fus.env.D)
+    rng = np.random.default_rng(7)
+    total_done = 0
+    for t in range(14):
+        act = np.stack([rng.uniform(-0.2, 1.3, (B, N)), rng.uniform(-0.7, 0.7, (B, N))], axis=-1).astype(np.float32)
+        if t % 3 == 2:
+            act = np.stack([rng.uniform(0.0, 0.3, (B, N)), rng.uniform(-0.05, 0.05, (B, N))], axis=-1).astype(np.float32)
+        sep.step(act)
+        term = {w: sep.get(w) for w in (capi.BUF_OBS, capi.BUF_REWARD, capi.BUF_DONE)}
+        total_done += int(term[capi.BUF_DONE].sum())
+        sep.auto_reset(5, t + 1, pf, pc)
+        row = torch.full((B, W), float("nan"), device="cuda")
+        fus.env.set_slab(row)
+        fus.step_autoreset(act, 5, t + 1, pf, pc)
+        obs, r, dn = unpack_slab(row, N, fus.env.D)
+        assert np.array_equal(obs.cpu().numpy(), term[capi.BUF_OBS]) and np.array_equal(r.cpu().numpy(), term[capi.BUF_REWARD])
+        assert np.array_equal(dn.cpu().numpy(), term[capi.BUF_DONE].astype(bool))
+        for w in INT_BUFS + FLT_BUFS:
+            a, b = sep.get(w), fus.get(w)
+            assert a.tobytes() == b.tobytes(), f"step {t}: buffer {w} differs between the fused and the separate launches"
+    assert total_done > 0
+    sep.close()
+    fus.close()
