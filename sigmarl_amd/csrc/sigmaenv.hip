@@ -46,6 +46,7 @@ struct Smem {
   __device__ Smem(char* base, int S, int N, int K, int D) {
     escr = reinterpret_cast<float4*>(base);  // first: the dynamic LDS base is 16-byte aligned
     float* f = reinterpret_cast<float*>(base + ESCR_BYTES);
+    obs = f; f += (S * D + 3) & ~3;  // 16-byte aligned (vector copy to HBM), and so is everything up to vold
     st = f; f += S * 8;
     vold = f; f += S * 10;
     vnew = f; f += S * 10;
@@ -55,7 +56,6 @@ struct Smem {
     dright = f; f += S * 5;
     dbound = f; f += S;
     dist = f; f += S * DIST_STRIDE(N);
-    obs = f; f += S * D;
     thr = f; f += S * 3;   // pruning thresholds of the centre / left / right scan
     cs = f; f += S * 2;    // cos / sin of the yaw (shared by the vertices and the ego-view transforms)
     rew = f; f += S * 2;   // reward per slot, then done flag per env (rollout slab record)
@@ -73,7 +73,7 @@ struct Smem {
   __host__ __device__ static size_t bytes(int S, int N, int K, int D) {
     size_t f = (size_t)S * 8 + S * 10 * 2 + S * NS * 2 + S + S * 5 * 2 + S + (size_t)S * DIST_STRIDE(N) + (size_t)S * D + S * 3 + S * 2 + S * 2;
     size_t i = (size_t)S + S * 3 + S * (K > 0 ? K : 1) + S * 4 + S * 3 + 1 + (size_t)S * 3 * 2 + (size_t)S * 3 * (CAND_LIST / 4);
-    return ESCR_BYTES + (f + i) * 4 + (size_t)S * COL_STRIDE(N) + 16;
+    return ESCR_BYTES + (f + i + 3) * 4 + (size_t)S * COL_STRIDE(N) + 16;
   }
 };
 
@@ -418,6 +418,27 @@ __device__ inline float ttc_penalty(const sigmaenv_config_t& c, const float* st,
 
 // top-k nearest agents of one agent (observation_provider_rt.py:629-636): ascending, lowest index on ties
 __device__ inline void topk_nearest(const float* Drow, int N, int K, int* out) {
+  if (K == 2) {
+    // one pass keeping the two best; the row is read four entries at a time so that the LDS reads are in flight together.
+    // `idx < 0` makes the first entries win unconditionally, as the selection loop below does (inf / NaN rows)
+    float b0 = INFINITY, b1 = INFINITY;
+    int i0 = -1, i1 = -1;
+    for (int j0 = 0; j0 < N; j0 += 4) {
+      float d[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) d[u] = Drow[min(j0 + u, N - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = j0 + u;
+        if (j < N) {
+          if (i0 < 0 || d[u] < b0) { b1 = b0; i1 = i0; b0 = d[u]; i0 = j; }
+          else if (i1 < 0 || d[u] < b1) { b1 = d[u]; i1 = j; }
+        }
+      }
+    }
+    out[0] = i0; out[1] = i1;
+    return;
+  }
   unsigned long long taken = 0ull;
   for (int k = 0; k < K; ++k) {
     int bj = -1;
@@ -495,7 +516,13 @@ __device__ inline void observe_tile(const sigmaenv_config_t& c, const Smem& s, c
     for (int k = 0; k < K; ++k) s.obs[sl * D + 4 + 2 * NS + 11 * k + 10] = s.dist[sl * DIST_STRIDE(N) + s.near[sl * K + k]] / n_dl;  // :373-375
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < t.slots * D; k += blockDim.x) g.obs[t.a0 * D + k] = s.obs[k];
+  if ((D & 3) == 0) {  // rows are whole float4s: both the LDS staging area and the tile's slice of g.obs are 16-byte aligned
+    const float4* so4 = reinterpret_cast<const float4*>(s.obs);
+    float4* go4 = reinterpret_cast<float4*>(g.obs + t.a0 * D);
+    for (int k = threadIdx.x; k < t.slots * D / 4; k += blockDim.x) go4[k] = so4[k];
+  } else {
+    for (int k = threadIdx.x; k < t.slots * D; k += blockDim.x) g.obs[t.a0 * D + k] = s.obs[k];
+  }
   for (int k = threadIdx.x; k < t.slots * K; k += blockDim.x) g.nearing[t.a0 * K + k] = s.near[k];
 }
 

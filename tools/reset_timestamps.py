@@ -23,8 +23,7 @@ print("workgroups", n, "active", int(act.sum()))
 t0 = ts[:, 0].min()
 print("start spread (all wgs)", ts[:, 0].max() - t0, " last end", ts[act, 6].max() - t0)
 a = ts[act]
-names = ["flags+sync", "state load", "sampler", "vertices+masks", "scans", "write-out+pairs", "observation"]
-for k, nm in enumerate(names):
-    d = a[:, k + 1] - a[:, k]
-    print(f"{nm:16s} mean {d.mean():9.0f}  p10 {np.percentile(d, 10):9.0f}  p90 {np.percentile(d, 90):9.0f}")
-print("active wg total mean", (a[:, 6] - a[:, 0]).mean(), " active start offset mean", (a[:, 0] - t0).mean())
+for a0, a1, nm in ((0, 1, "flags + state load"), (1, 2, "sampler + placement"), (2, 5, "pair distances + env tail"), (5, 6, "observation")):
+    d = a[:, a1] - a[:, a0]
+    print(f"{nm:28s} mean {d.mean():9.0f}  p10 {np.percentile(d, 10):9.0f}  p90 {np.percentile(d, 90):9.0f}")
+print("active wg total mean", (a[:, 6] - a[:, 0]).mean())
