@@ -186,10 +186,9 @@ __device__ inline void agent_scan_full(const DevMap& m, const sigmaenv_config_t&
 __device__ __forceinline__ float guess_distance(const float* __restrict__ poly, int n, int cp_guess, float px, float py) {
   int k = cp_guess - 1;
   k = k < 0 ? 0 : (k > n - 2 ? n - 2 : k);
-  const float2* p2 = reinterpret_cast<const float2*>(poly);
-  float2 a = p2[k], b = p2[k + 1];
-  float lx = b.x - a.x, ly = b.y - a.y;
-  return point_segment(px, py, a.x, a.y, lx, ly, lx * lx + ly * ly);
+  const Seg4 sg = load_segment(reinterpret_cast<const float2*>(poly), k);
+  float lx = sg.bx - sg.ax, ly = sg.by - sg.ay;
+  return point_segment(px, py, sg.ax, sg.ay, lx, ly, lx * lx + ly * ly);
 }
 
 // exact radius of the corner-query points around the centre (used for agent 0, whose query points are last step's vertices)
@@ -304,8 +303,8 @@ __device__ inline void pair_scan(const DevMap& m, const sigmaenv_config_t& c, co
     const int kc = chc * SIGMAENV_CHUNK + (jc % SIGMAENV_CHUNK), kb = chb * SIGMAENV_CHUNK + (jb % SIGMAENV_CHUNK);
     const bool do_c = chc >= 0 && kc + 1 < n, do_b = chb >= 0 && kb + 1 < np;
     float2 ca = make_float2(0.f, 0.f), cb = ca, ba = ca, bb2 = ca;
-    if (do_c) { ca = ctr2[kc]; cb = ctr2[kc + 1]; }
-    if (do_b) { ba = pol2[kb]; bb2 = pol2[kb + 1]; }
+    if (do_c) { const Seg4 sg = load_segment(ctr2, kc); ca = make_float2(sg.ax, sg.ay); cb = make_float2(sg.bx, sg.by); }
+    if (do_b) { const Seg4 sg = load_segment(pol2, kb); ba = make_float2(sg.ax, sg.ay); bb2 = make_float2(sg.bx, sg.by); }
     if (do_c) {
       float lx = cb.x - ca.x, ly = cb.y - ca.y;
       float len2 = lx * lx + ly * ly;

@@ -66,6 +66,11 @@ struct DevBufs {
   unsigned long long* dbg_ts;      // optional [grid][8] shader-clock timestamps at the phase boundaries (SIGMAENV_TIMESTAMPS=1)
 };
 
+// two consecutive polyline points (one segment) in ONE 16-byte load: the points are 8-byte aligned, which a global dwordx4 load
+// accepts; halves the address-coalescer work of the scan compared with two 8-byte loads
+struct __attribute__((packed, aligned(8))) Seg4 { float ax, ay, bx, by; };
+__device__ __forceinline__ Seg4 load_segment(const float2* p, int k) { return *reinterpret_cast<const Seg4*>(p + k); }
+
 // ---- scalar helpers ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float cr_sin(float x) { return (float)sin((double)x); }
 __device__ __forceinline__ float cr_cos(float x) { return (float)cos((double)x); }
