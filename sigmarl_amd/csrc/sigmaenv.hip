@@ -457,13 +457,16 @@ __device__ inline void topk_nearest(const float* Drow, int N, int K, int* out) {
 //   2. relative velocities (self + observed neighbours): angle wrap + cos + sin each
 //   3. normalised distances
 // Rows are assembled in LDS and written out coalesced.  All threads of the block participate.
-__device__ inline void observe_tile(const sigmaenv_config_t& c, const Smem& s, const DevBufs& g, const Tile& t) {
+__device__ inline void observe_tile(const sigmaenv_config_t& c, const Smem& s, const DevBufs& g, const Tile& t, int ts_base = -1) {
   const int N = t.N, K = t.K, D = t.D;
+#define TSO(k) do { if (ts_base >= 0 && g.dbg_ts && threadIdx.x == 0) g.dbg_ts[(size_t)blockIdx.x * 16 + ts_base + (k)] = __builtin_readcyclecounter(); } while (0)
   const float n_pos = (float)((double)c.length * 10.0);   // normalizers.pos, road_traffic.py:588-592
   const float n_v = c.max_speed;                            // :596
   const float n_dl = (float)((double)c.lane_width * 3.0);   // :599-601 (distance_lanelet also normalises the agent distances)
   for (int sl = threadIdx.x; sl < t.slots; sl += blockDim.x) topk_nearest(s.dist + sl * DIST_STRIDE(N), N, K, s.near + sl * K);
+  TSO(0);
   __syncthreads();
+  TSO(1);
   // The reference goes through atan2 / cos / sin (helper_scenario.py:1261-1271); the same rotation is applied here with the
   // agent's cos(psi), sin(psi) (already needed for the vertices): rel = R(-psi_i) (p_j - p_i).  Identical up to ~1e-7, well inside
   // the 1e-5 bar; no mask or index depends on it.  The oracle keeps the reference's formulation.
@@ -488,33 +491,44 @@ __device__ inline void observe_tile(const sigmaenv_config_t& c, const Smem& s, c
     s.obs[sl * D + pos] = (dx * ci + dy * sn) / n_pos;
     s.obs[sl * D + pos + 1] = (dy * ci - dx * sn) / n_pos;
   }
+  TSO(2);
+  // relative velocities (one lane per (agent, self or observed neighbour)) from the front of the block, the per-agent distances
+  // from its back, so that both run at the same time when the block is wide enough
   const int T2 = K + 1;
-  for (int w = threadIdx.x; w < t.slots * T2; w += blockDim.x) {
-    int sl = w / T2, q = w - sl * T2;
-    int ebase = (sl / N) * N;
-    int sj = (q == 0) ? sl : (ebase + s.near[sl * K + (q - 1)]);
-    const float* sjp = s.st + sj * 8;
-    float va = norm2(sjp[5], sjp[6]);                      // :444
-    float ci = s.cs[sl * 2], si_ = s.cs[sl * 2 + 1], cj = s.cs[sj * 2], sj_ = s.cs[sj * 2 + 1];
-    float cr = cj * ci + sj_ * si_, sr = sj_ * ci - cj * si_;   // cos / sin of (psi_j - psi_i) (:439, :447-449)
-    if (q == 0) {
-      s.obs[sl * D] = va / n_v;  // [own] only the longitudinal component is observed; cos(0) = 1 (:864-868, :885-887)
-    } else {
-      int base = 4 + 2 * NS + 11 * (q - 1);
-      s.obs[sl * D + base + 8] = (va * cr) / n_v;
-      s.obs[sl * D + base + 9] = (va * sr) / n_v;
+  const int n2 = t.slots * T2, n3 = t.slots;
+  const int span = max(n2 + n3, (int)blockDim.x);
+  for (int w0 = threadIdx.x; w0 < span; w0 += blockDim.x) {
+    const int w3 = (span - 1) - w0;  // the back of the span carries the third pass
+    if (w0 < n2) {
+      const int w = w0;
+      int sl = w / T2, q = w - sl * T2;
+      int ebase = (sl / N) * N;
+      int sj = (q == 0) ? sl : (ebase + s.near[sl * K + (q - 1)]);
+      const float* sjp = s.st + sj * 8;
+      float va = norm2(sjp[5], sjp[6]);                      // :444
+      float ci = s.cs[sl * 2], si_ = s.cs[sl * 2 + 1], cj = s.cs[sj * 2], sj_ = s.cs[sj * 2 + 1];
+      float cr = cj * ci + sj_ * si_, sr = sj_ * ci - cj * si_;   // cos / sin of (psi_j - psi_i) (:439, :447-449)
+      if (q == 0) {
+        s.obs[sl * D] = va / n_v;  // [own] only the longitudinal component is observed; cos(0) = 1 (:864-868, :885-887)
+      } else {
+        int base = 4 + 2 * NS + 11 * (q - 1);
+        s.obs[sl * D + base + 8] = (va * cr) / n_v;
+        s.obs[sl * D + base + 9] = (va * sr) / n_v;
+      }
+    } else if (w3 < n3) {
+      const int sl = w3;
+      float ml = INFINITY, mr = INFINITY;
+#pragma unroll
+      for (int q = 0; q < 5; ++q) { ml = fminf(ml, s.dleft[sl * 5 + q]); mr = fminf(mr, s.dright[sl * 5 + q]); }
+      s.obs[sl * D + 1 + 2 * NS] = s.dref[sl] / n_dl;        // :376-378, :898-904
+      s.obs[sl * D + 2 + 2 * NS] = ml / n_dl;                // :379-382
+      s.obs[sl * D + 3 + 2 * NS] = mr / n_dl;                // :383-386
+      for (int k = 0; k < K; ++k) s.obs[sl * D + 4 + 2 * NS + 11 * k + 10] = s.dist[sl * DIST_STRIDE(N) + s.near[sl * K + k]] / n_dl;  // :373-375
     }
   }
-  for (int sl = threadIdx.x; sl < t.slots; sl += blockDim.x) {
-    float ml = INFINITY, mr = INFINITY;
-#pragma unroll
-    for (int q = 0; q < 5; ++q) { ml = fminf(ml, s.dleft[sl * 5 + q]); mr = fminf(mr, s.dright[sl * 5 + q]); }
-    s.obs[sl * D + 1 + 2 * NS] = s.dref[sl] / n_dl;        // :376-378, :898-904
-    s.obs[sl * D + 2 + 2 * NS] = ml / n_dl;                // :379-382
-    s.obs[sl * D + 3 + 2 * NS] = mr / n_dl;                // :383-386
-    for (int k = 0; k < K; ++k) s.obs[sl * D + 4 + 2 * NS + 11 * k + 10] = s.dist[sl * DIST_STRIDE(N) + s.near[sl * K + k]] / n_dl;  // :373-375
-  }
+  TSO(3);
   __syncthreads();
+  TSO(4);
   if ((D & 3) == 0) {  // rows are whole float4s: both the LDS staging area and the tile's slice of g.obs are 16-byte aligned
     const float4* so4 = reinterpret_cast<const float4*>(s.obs);
     float4* go4 = reinterpret_cast<float4*>(g.obs + t.a0 * D);
@@ -523,6 +537,8 @@ __device__ inline void observe_tile(const sigmaenv_config_t& c, const Smem& s, c
     for (int k = threadIdx.x; k < t.slots * D; k += blockDim.x) g.obs[t.a0 * D + k] = s.obs[k];
   }
   for (int k = threadIdx.x; k < t.slots * K; k += blockDim.x) g.nearing[t.a0 * K + k] = s.near[k];
+  TSO(5);
+#undef TSO
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -544,7 +560,7 @@ __global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigm
   const int N = t.N;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
   Smem s(smem_raw, G * N, N, t.K, t.D);
-#define TS(k) do { if (g.dbg_ts && tid == 0) g.dbg_ts[(size_t)blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#define TS(k) do { if (g.dbg_ts && tid == 0) g.dbg_ts[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
   TS(0);
 
   // ---- A: dynamics + vertices (one lane per agent; slots <= 64 so this is wavefront 0) -------------------------------
@@ -758,7 +774,7 @@ __global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigm
   TS(4);
 
   // ---- D: observations ---------------------------------------------------------------------------------------------
-  if (!(dbg_skip & 8)) observe_tile(c, s, g, t);
+  if (!(dbg_skip & 8)) observe_tile(c, s, g, t, 8);
   if (g.slab) {  // rollout record of this step (observation AFTER the step, reward, done), one contiguous row per env
     const int ND = N * t.D, W = ND + N + 1;
     for (int k = tid; k < t.nenv * W; k += blockDim.x) {
@@ -843,7 +859,7 @@ __device__ inline void reset_derive_body(const sigmaenv_config_t& c, const DevMa
                                          const unsigned long long* agent_mask, const int* full, int with_obs) {
   const int N = t.N;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
-#define TS2(k) do { if (g.dbg_ts2 && tid == 0) g.dbg_ts2[(size_t)blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#define TS2(k) do { if (g.dbg_ts2 && tid == 0) g.dbg_ts2[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
   for (int sl = tid; sl < t.slots; sl += blockDim.x) {
     int e = sl / N, i = sl - e * N;
     if ((agent_mask[e] >> i) & 1ull) {
@@ -916,7 +932,7 @@ __device__ inline void reset_finish_body(const sigmaenv_config_t& c, const DevBu
                                          const unsigned long long* agent_mask, const int* full, int with_obs) {
   const int N = t.N;
   const int tid = threadIdx.x;
-#define TS2(k) do { if (g.dbg_ts2 && tid == 0) g.dbg_ts2[(size_t)blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#define TS2(k) do { if (g.dbg_ts2 && tid == 0) g.dbg_ts2[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
   const float diag = sqrtf(c.world_x_dim * c.world_x_dim + c.world_y_dim * c.world_y_dim);
   for (int p = tid; p < t.slots * N; p += blockDim.x) {
     int si = p / N, j = p - si * N;
@@ -1126,7 +1142,7 @@ __device__ inline void auto_reset_tile(const sigmaenv_config_t& c, const DevMap&
                                        int path_count, int obs_mode) {
   const int N = t.N;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
-#define TS2(k) do { if (g.dbg_ts2 && tid == 0) g.dbg_ts2[(size_t)blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#define TS2(k) do { if (g.dbg_ts2 && tid == 0) g.dbg_ts2[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
   TS2(1);
   const float min_d = sqrtf((float)((double)c.length * (double)c.length + (double)c.width * (double)c.width)) * 1.5f;  // road_traffic.py:679-684
   const float min_d_sq = min_d * min_d;
@@ -1234,8 +1250,8 @@ __global__ void __launch_bounds__(512) sigmaenv_auto_reset_kernel(sigmaenv_confi
   unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(smem_raw + ((Smem::bytes(G * N, N, t.K, t.D) + 15) & ~(size_t)15));
   int* s_full = reinterpret_cast<int*>(s_mask + MAX_G);
   int* s_any = s_full + MAX_G;
-#define TS2(k) do { if (g.dbg_ts2 && tid == 0) g.dbg_ts2[(size_t)blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
-  if (g.dbg_ts2 && tid < 8) g.dbg_ts2[(size_t)blockIdx.x * 8 + tid] = 0ull;
+#define TS2(k) do { if (g.dbg_ts2 && tid == 0) g.dbg_ts2[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+  if (g.dbg_ts2 && tid < 16) g.dbg_ts2[(size_t)blockIdx.x * 16 + tid] = 0ull;
   TS2(0);
 #undef TS2
   if (tid == 0) *s_any = 0;
@@ -1501,8 +1517,8 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
   g.dbg_ts = nullptr;
   g.dbg_ts2 = nullptr;
   if (const char* e = getenv("SIGMAENV_TIMESTAMPS")) {
-    if (atoi(e) == 1) { ALLOC(g.dbg_ts, (size_t)B * 8 * sizeof(unsigned long long)); }
-    if (atoi(e) == 2) { ALLOC(g.dbg_ts2, (size_t)B * 8 * sizeof(unsigned long long)); hipMemsetAsync(g.dbg_ts2, 0, (size_t)B * 64, h->stream); }
+    if (atoi(e) == 1) { ALLOC(g.dbg_ts, (size_t)B * 16 * sizeof(unsigned long long)); }
+    if (atoi(e) == 2) { ALLOC(g.dbg_ts2, (size_t)B * 16 * sizeof(unsigned long long)); hipMemsetAsync(g.dbg_ts2, 0, (size_t)B * 128, h->stream); }
   }
 #undef ALLOC
 #undef H2D
@@ -1660,13 +1676,13 @@ extern "C" int sigmaenv_debug_timestamps(sigmaenv_t* h, unsigned long long* out,
   if (!h->buf.dbg_ts && h->buf.dbg_ts2) {
     int n2 = max_groups < h->B ? max_groups : h->B;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipMemcpy(out, h->buf.dbg_ts2, (size_t)n2 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(out, h->buf.dbg_ts2, (size_t)n2 * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return n2;
   }
   if (!h->buf.dbg_ts) return 0;
   int n = h->grid < max_groups ? h->grid : max_groups;
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  HIPCHK(h, hipMemcpy(out, h->buf.dbg_ts, (size_t)n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(out, h->buf.dbg_ts, (size_t)n * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return n;
 }
 

@@ -15,7 +15,7 @@ for t in range(20):
 env.sync()
 f = env.lib.cdll.sigmaenv_debug_timestamps
 f.restype = C.c_int; f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
-ts = np.zeros((B, 8), np.uint64)
+ts = np.zeros((B, 16), np.uint64)
 n = f(env.h, ts.ctypes.data_as(C.c_void_p), B)
 ts = ts[:n].astype(np.int64)
 act = ts[:, 6] > 0
