@@ -14,6 +14,8 @@
 // Reference citations are relative to /root/reference/sigmarl; see sigmaenv_device.h for the arithmetic contract.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -223,19 +225,34 @@ __device__ __forceinline__ bool box_within(const float4 b, float px, float py, f
   return !((dx * dx + dy * dy) > T2);  // a NaN threshold keeps every box
 }
 template <bool COLLIDE>
-__device__ inline void scan_mask_task(const DevMap& m, const Smem& s, int task, bool stale_first, int N) {
+__device__ inline void scan_mask_task(const DevMap& m, const Smem& s, int task, bool stale_first, int N, unsigned long long* dbg = nullptr) {
   // task = (agent slot, polyline): 0 centre line, 1 left boundary, 2 right boundary
   const int sl = task / 3, pl = task - sl * 3;
   const int path = s.path[sl];
   const float px = s.st[sl * 8], py = s.st[sl * 8 + 1];
   const float* poly = (pl == 0 ? m.center : (pl == 1 ? m.left : m.right)) + (size_t)path * m.P * 2;
+  const float4* box = m.chunk_box + ((size_t)path * 3 + pl) * m.nch;
+  const ulonglong2* neigh = m.chunk_neigh + ((size_t)path * 3 + pl) * m.nch;
+  // One round trip: the point count, and -- speculatively, the index is almost always in range -- the segment that was closest
+  // last step together with the neighbour mask of its chunk.
+  int k = s.cp[sl * 3 + pl] - 1;
+  k = k < 0 ? 0 : (k > m.P - 2 ? m.P - 2 : k);
   const int npt = (pl == 0 ? m.n_center : (pl == 1 ? m.n_left : m.n_right))[path];
+  Seg4 sg = load_segment(reinterpret_cast<const float2*>(poly), k);
+  ulonglong2 nm = neigh[k / SIGMAENV_CHUNK];
   s.npts[sl * 3 + pl] = npt;
+  if (k > npt - 2) {  // rare (a caller-provided start index beyond this polyline)
+    k = npt - 2 < 0 ? 0 : npt - 2;
+    sg = load_segment(reinterpret_cast<const float2*>(poly), k);
+    nm = neigh[k / SIGMAENV_CHUNK];
+  }
   // pruning threshold T (see the exactness argument above): distance to last step's closest segment, plus (boundaries) twice the
   // radius of the query points around the centre -- exact for the agent whose corners are stale -- and at least the circumradius
   // when the rectangle is also tested for collision
   const float MARGIN = 1e-4f;
-  float T = guess_distance(poly, npt, s.cp[sl * 3 + pl], px, py);
+  const float glx = sg.bx - sg.ax, gly = sg.by - sg.ay;
+  const float dg = point_segment(px, py, sg.ax, sg.ay, glx, gly, glx * glx + gly * gly);
+  float T = dg;
   if (pl != 0) {
     const bool stale = stale_first && (sl % N == 0);
     const float Rq = stale ? query_radius(s.vold + sl * 10, px, py) : m.rect_radius;
@@ -243,24 +260,46 @@ __device__ inline void scan_mask_task(const DevMap& m, const Smem& s, int task, 
   }
   T += MARGIN;
   const float T2 = T * T;
+  if (dbg && threadIdx.x == 0) dbg[14] = __builtin_readcyclecounter() + (T2 > 1e30f ? 1 : 0);
   const int nch = (npt - 1 + SIGMAENV_CHUNK - 1) / SIGMAENV_CHUNK;
-  const float4* gbox = m.group_box + ((size_t)path * 3 + pl) * 8;
-  const float4* box = m.chunk_box + ((size_t)path * 3 + pl) * m.nch;
-  unsigned gm = 0u;
-#pragma unroll
-  for (int gidx = 0; gidx < 8; ++gidx) {
-    if (gidx * 8 < nch && box_within(gbox[gidx], px, py, T2)) gm |= 1u << gidx;
-  }
   unsigned long long mk = 0ull;
-  while (gm) {
-    const int gidx = __ffs((int)gm) - 1;
-    gm &= gm - 1u;
+  if (T + dg <= m.neigh_radius_far) {
+    // Every chunk within T of the agent is within T + dg of the chunk of that segment (the segment lies inside its chunk's box and
+    // is dg away), i.e. in the precomputed neighbour mask of that radius (the wider one mostly serves the agent whose query points
+    // are stale): only those few boxes are tested, eight loads in flight at a time.
+    unsigned long long rest = (T + dg <= m.neigh_radius) ? nm.x : nm.y;
+    while (rest) {
+      int idx[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int cidx = gidx * 8 + k;
-      if (cidx < nch && box_within(box[cidx], px, py, T2)) mk |= 1ull << cidx;
+      for (int q = 0; q < 8; ++q) { idx[q] = rest ? (__ffsll((long long)rest) - 1) : -1; rest &= rest - 1ull; }
+      float4 b[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) b[q] = box[idx[q] < 0 ? 0 : idx[q]];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if (idx[q] >= 0 && idx[q] < nch && box_within(b[q], px, py, T2)) mk |= 1ull << idx[q];
+      }
+    }
+  } else {
+    // far from the own path (or a NaN state): two-level search over all boxes -- the <= 8 group boxes, then the 8 chunk boxes of
+    // every group within the threshold
+    const float4* gbox = m.group_box + ((size_t)path * 3 + pl) * 8;
+    unsigned gm = 0u;
+#pragma unroll
+    for (int gidx = 0; gidx < 8; ++gidx) {
+      if (gidx * 8 < nch && box_within(gbox[gidx], px, py, T2)) gm |= 1u << gidx;
+    }
+    while (gm) {
+      const int gidx = __ffs((int)gm) - 1;
+      gm &= gm - 1u;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int cidx = gidx * 8 + q;
+        if (cidx < nch && box_within(box[cidx], px, py, T2)) mk |= 1ull << cidx;
+      }
     }
   }
+  if (dbg && threadIdx.x == 0) dbg[15] = __builtin_readcyclecounter() + (mk == 0x123456789ull ? 1 : 0);
   s.cmask[task] = mk;
   uint8_t* cl = s.cand + task * CAND_LIST;
   for (int j = 0; mk && j < CAND_LIST; ++j) {
@@ -597,7 +636,7 @@ __global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigm
   __syncthreads();
   TS(7);
   if (m.nch > 0) {
-    for (int task = tid; task < t.slots * 3; task += blockDim.x) scan_mask_task<true>(m, s, task, true, N);
+    for (int task = tid; task < t.slots * 3; task += blockDim.x) scan_mask_task<true>(m, s, task, true, N, g.dbg_ts ? g.dbg_ts + (size_t)blockIdx.x * 16 : nullptr);
   }
   TS(1);
 
@@ -1435,6 +1474,12 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
   if (const char* e = getenv("SIGMAENV_PRUNE")) prune = prune && atoi(e) != 0;
   float4 *d_box = nullptr, *d_gbox = nullptr;
   std::vector<float4> hb, hg;  // must outlive the asynchronous uploads below
+  std::vector<ulonglong2> hn;
+  ulonglong2* d_neigh = nullptr;
+  const float neigh_radius_far = 9.0f * (sqrtf((float)((double)cfg->length / 2.0) * (float)((double)cfg->length / 2.0) +
+                                               (float)((double)cfg->width / 2.0) * (float)((double)cfg->width / 2.0)) * 1.00001f + 1e-5f);
+  const float neigh_radius = 6.0f * (sqrtf((float)((double)cfg->length / 2.0) * (float)((double)cfg->length / 2.0) +
+                                           (float)((double)cfg->width / 2.0) * (float)((double)cfg->width / 2.0)) * 1.00001f + 1e-5f);
   if (prune) {
     hb.assign((size_t)np * 3 * nch, make_float4(1e30f, 1e30f, -1e30f, -1e30f));
     for (int p = 0; p < np; ++p) {
@@ -1463,6 +1508,27 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
     }
     ALLOC(d_gbox, hg.size() * sizeof(float4));
     H2D(d_gbox, hg.data(), hg.size() * sizeof(float4));
+    // neighbour masks: chunks whose box is within neigh_radius of a chunk's box (double arithmetic, inclusive with slack)
+    hn.assign((size_t)np * 3 * nch, make_ulonglong2(0ull, 0ull));
+    for (size_t pq = 0; pq < (size_t)np * 3; ++pq) {
+      for (int a = 0; a < nch; ++a) {
+        const float4& A = hb[pq * nch + a];
+        if (A.x > A.z) continue;
+        unsigned long long bits = 0ull, bits_far = 0ull;
+        for (int b2 = 0; b2 < nch; ++b2) {
+          const float4& Bx = hb[pq * nch + b2];
+          if (Bx.x > Bx.z) continue;
+          double dx = std::max(std::max((double)A.x - Bx.z, (double)Bx.x - A.z), 0.0);
+          double dy = std::max(std::max((double)A.y - Bx.w, (double)Bx.y - A.w), 0.0);
+          const double dd = std::sqrt(dx * dx + dy * dy);
+          if (dd <= (double)neigh_radius + 1e-5) bits |= 1ull << b2;
+          if (dd <= (double)neigh_radius_far + 1e-5) bits_far |= 1ull << b2;
+        }
+        hn[pq * nch + a] = make_ulonglong2(bits, bits_far);
+      }
+    }
+    ALLOC(d_neigh, hn.size() * sizeof(ulonglong2));
+    H2D(d_neigh, hn.data(), hn.size() * sizeof(ulonglong2));
   }
   const float lh = (float)((double)cfg->length / 2.0), wh = (float)((double)cfg->width / 2.0);
   const float rect_radius = sqrtf(lh * lh + wh * wh) * 1.00001f + 1e-5f;
@@ -1480,7 +1546,7 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
     }
   }
   if (const char* e = getenv("SIGMAENV_FASTDIV")) fast_div = fast_div && atoi(e) != 0;
-  h->map = DevMap{d_c, d_l, d_r, d_y, d_nc, d_nl, d_nr, d_loop, P, np, S, d_box, d_gbox, prune ? nch : 0, nullptr, fast_div, rect_radius};
+  h->map = DevMap{d_c, d_l, d_r, d_y, d_nc, d_nl, d_nr, d_loop, P, np, S, d_box, d_gbox, d_neigh, neigh_radius, neigh_radius_far, prune ? nch : 0, nullptr, fast_div, rect_radius};
   {  // start table: derived state of an agent placed on any centre-line point, by the kernels' own scan code
     float* d_tab = nullptr;
     ALLOC(d_tab, (size_t)np * P * START_ROW * sizeof(float));

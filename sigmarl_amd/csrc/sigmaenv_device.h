@@ -33,6 +33,8 @@ struct DevMap {
   // pruning table: axis-aligned boxes of runs of CHUNK consecutive real segments, [n_paths][3 (centre,left,right)][nch]
   const float4* chunk_box;  // (min_x, min_y, max_x, max_y)
   const float4* group_box;  // union boxes of groups of 8 consecutive chunks, [n_paths][3][8]
+  const ulonglong2* chunk_neigh;  // [n_paths][3][nch]: bit c set iff the box of chunk c is within neigh_radius (.x) / neigh_radius_far (.y) of this chunk's box
+  float neigh_radius, neigh_radius_far;
   int32_t nch;              // boxes per polyline (stride); 0 disables pruning (brute-force scan)
   const float* start_table; // derived state of an agent freshly placed on centre-line point pt of path p, [n_paths][P][START_ROW]
   int32_t fast_div;         // every real segment has 2^-60 <= |l|^2 <= 2^60: the shared-reciprocal division is exact (div_shared)
