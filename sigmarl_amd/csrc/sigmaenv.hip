@@ -224,34 +224,53 @@ __device__ __forceinline__ bool box_within(const float4 b, float px, float py, f
   float dy = fmaxf(fmaxf(b.y - py, py - b.w), 0.0f);
   return !((dx * dx + dy * dy) > T2);  // a NaN threshold keeps every box
 }
-template <bool COLLIDE>
-__device__ inline void scan_mask_task(const DevMap& m, const Smem& s, int task, bool stale_first, int N, unsigned long long* dbg = nullptr) {
-  // task = (agent slot, polyline): 0 centre line, 1 left boundary, 2 right boundary
-  const int sl = task / 3, pl = task - sl * 3;
-  const int path = s.path[sl];
-  const float px = s.st[sl * 8], py = s.st[sl * 8 + 1];
-  const float* poly = (pl == 0 ? m.center : (pl == 1 ? m.left : m.right)) + (size_t)path * m.P * 2;
-  const float4* box = m.chunk_box + ((size_t)path * 3 + pl) * m.nch;
+// The task is written in stages so that the step kernel can issue stage 1 early: it only needs the path row and last step's closest
+// index (known before the dynamics), stage 2 needs the new position, stage 3 tests the boxes.
+struct MaskTask {
+  int sl, pl, path, k, npt, nch;
+  float ax, ay, bx, by;          // the segment that was closest last step
+  unsigned long long nm_near, nm_far;
+  const float4* box;
+  float px, py, T2;
+  unsigned long long rest;  // neighbour-mask bits to test
+  bool fast;
+};
+__device__ __forceinline__ void mask_stage1(const DevMap& m, MaskTask& mt, int task, int path, int cp) {
+  mt.sl = task / 3; mt.pl = task - mt.sl * 3; mt.path = path;
+  const int pl = mt.pl;
+  const float* poly = m.center + (size_t)pl * m.poly_stride + (size_t)path * m.P * 2;
+  mt.box = m.chunk_box + ((size_t)path * 3 + pl) * m.nch;
   const ulonglong2* neigh = m.chunk_neigh + ((size_t)path * 3 + pl) * m.nch;
   // One round trip: the point count, and -- speculatively, the index is almost always in range -- the segment that was closest
-  // last step together with the neighbour mask of its chunk.
-  int k = s.cp[sl * 3 + pl] - 1;
+  // last step together with the neighbour masks of its chunk.
+  int k = cp - 1;
   k = k < 0 ? 0 : (k > m.P - 2 ? m.P - 2 : k);
-  const int npt = (pl == 0 ? m.n_center : (pl == 1 ? m.n_left : m.n_right))[path];
-  Seg4 sg = load_segment(reinterpret_cast<const float2*>(poly), k);
-  ulonglong2 nm = neigh[k / SIGMAENV_CHUNK];
-  s.npts[sl * 3 + pl] = npt;
-  if (k > npt - 2) {  // rare (a caller-provided start index beyond this polyline)
-    k = npt - 2 < 0 ? 0 : npt - 2;
-    sg = load_segment(reinterpret_cast<const float2*>(poly), k);
-    nm = neigh[k / SIGMAENV_CHUNK];
+  mt.k = k;
+  mt.npt = m.n_center[pl * m.n_paths + path];
+  const Seg4 sg = load_segment(reinterpret_cast<const float2*>(poly), k);
+  mt.ax = sg.ax; mt.ay = sg.ay; mt.bx = sg.bx; mt.by = sg.by;
+  const ulonglong2 nm = neigh[k / SIGMAENV_CHUNK];
+  mt.nm_near = nm.x; mt.nm_far = nm.y;
+}
+template <bool COLLIDE>
+__device__ __forceinline__ void mask_stage2(const DevMap& m, const Smem& s, MaskTask& mt, bool stale_first, int N) {
+  const int sl = mt.sl, pl = mt.pl, npt = mt.npt;
+  if (mt.k > npt - 2) {  // rare (a caller-provided start index beyond this polyline)
+    const float* poly = m.center + (size_t)pl * m.poly_stride + (size_t)mt.path * m.P * 2;
+    const int k = npt - 2 < 0 ? 0 : npt - 2;
+    const Seg4 sg = load_segment(reinterpret_cast<const float2*>(poly), k);
+    mt.ax = sg.ax; mt.ay = sg.ay; mt.bx = sg.bx; mt.by = sg.by;
+    const ulonglong2 nm = (m.chunk_neigh + ((size_t)mt.path * 3 + pl) * m.nch)[k / SIGMAENV_CHUNK];
+    mt.nm_near = nm.x; mt.nm_far = nm.y;
   }
+  const float px = s.st[sl * 8], py = s.st[sl * 8 + 1];
+  mt.px = px; mt.py = py;
   // pruning threshold T (see the exactness argument above): distance to last step's closest segment, plus (boundaries) twice the
   // radius of the query points around the centre -- exact for the agent whose corners are stale -- and at least the circumradius
   // when the rectangle is also tested for collision
   const float MARGIN = 1e-4f;
-  const float glx = sg.bx - sg.ax, gly = sg.by - sg.ay;
-  const float dg = point_segment(px, py, sg.ax, sg.ay, glx, gly, glx * glx + gly * gly);
+  const float glx = mt.bx - mt.ax, gly = mt.by - mt.ay;
+  const float dg = point_segment(px, py, mt.ax, mt.ay, glx, gly, glx * glx + gly * gly);
   float T = dg;
   if (pl != 0) {
     const bool stale = stale_first && (sl % N == 0);
@@ -259,31 +278,35 @@ __device__ inline void scan_mask_task(const DevMap& m, const Smem& s, int task, 
     T = fmaxf(T + 2.0f * Rq, COLLIDE ? m.rect_radius : 0.0f);
   }
   T += MARGIN;
-  const float T2 = T * T;
-  if (dbg && threadIdx.x == 0) dbg[14] = __builtin_readcyclecounter() + (T2 > 1e30f ? 1 : 0);
-  const int nch = (npt - 1 + SIGMAENV_CHUNK - 1) / SIGMAENV_CHUNK;
+  mt.T2 = T * T;
+  mt.nch = (npt - 1 + SIGMAENV_CHUNK - 1) / SIGMAENV_CHUNK;
+  // Every chunk within T of the agent is within T + dg of the chunk of that segment (the segment lies inside its chunk's box and is
+  // dg away), i.e. in the precomputed neighbour mask of that radius (the wider one mostly serves the agent whose query points are
+  // stale): only those few boxes are tested, eight loads in flight at a time.
+  mt.fast = T + dg <= m.neigh_radius_far;
+  mt.rest = mt.fast ? ((T + dg <= m.neigh_radius) ? mt.nm_near : mt.nm_far) : 0ull;
+}
+__device__ __forceinline__ void mask_stage3(const DevMap& m, const Smem& s, MaskTask& mt, int task) {
+  const float px = mt.px, py = mt.py, T2 = mt.T2;
+  const int nch = mt.nch;
   unsigned long long mk = 0ull;
-  if (T + dg <= m.neigh_radius_far) {
-    // Every chunk within T of the agent is within T + dg of the chunk of that segment (the segment lies inside its chunk's box and
-    // is dg away), i.e. in the precomputed neighbour mask of that radius (the wider one mostly serves the agent whose query points
-    // are stale): only those few boxes are tested, eight loads in flight at a time.
-    unsigned long long rest = (T + dg <= m.neigh_radius) ? nm.x : nm.y;
-    while (rest) {
-      int idx[8];
+  unsigned long long rest = mt.rest;
+  while (rest) {  // one pass unless the neighbourhood has more than eight chunks (dense map regions with the wide radius)
+    int idx[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) { idx[q] = rest ? (__ffsll((long long)rest) - 1) : -1; rest &= rest - 1ull; }
-      float4 b[8];
+    for (int q = 0; q < 8; ++q) { idx[q] = rest ? (__ffsll((long long)rest) - 1) : -1; rest &= rest - 1ull; }
+    float4 b[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) b[q] = box[idx[q] < 0 ? 0 : idx[q]];
+    for (int q = 0; q < 8; ++q) b[q] = mt.box[idx[q] < 0 ? 0 : idx[q]];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        if (idx[q] >= 0 && idx[q] < nch && box_within(b[q], px, py, T2)) mk |= 1ull << idx[q];
-      }
+    for (int q = 0; q < 8; ++q) {
+      if (idx[q] >= 0 && idx[q] < nch && box_within(b[q], px, py, T2)) mk |= 1ull << idx[q];
     }
-  } else {
+  }
+  if (!mt.fast) {
     // far from the own path (or a NaN state): two-level search over all boxes -- the <= 8 group boxes, then the 8 chunk boxes of
     // every group within the threshold
-    const float4* gbox = m.group_box + ((size_t)path * 3 + pl) * 8;
+    const float4* gbox = m.group_box + ((size_t)mt.path * 3 + mt.pl) * 8;
     unsigned gm = 0u;
 #pragma unroll
     for (int gidx = 0; gidx < 8; ++gidx) {
@@ -295,17 +318,25 @@ __device__ inline void scan_mask_task(const DevMap& m, const Smem& s, int task, 
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int cidx = gidx * 8 + q;
-        if (cidx < nch && box_within(box[cidx], px, py, T2)) mk |= 1ull << cidx;
+        if (cidx < nch && box_within(mt.box[cidx], px, py, T2)) mk |= 1ull << cidx;
       }
     }
   }
-  if (dbg && threadIdx.x == 0) dbg[15] = __builtin_readcyclecounter() + (mk == 0x123456789ull ? 1 : 0);
+  s.npts[task] = mt.npt;
   s.cmask[task] = mk;
   uint8_t* cl = s.cand + task * CAND_LIST;
   for (int j = 0; mk && j < CAND_LIST; ++j) {
     cl[j] = (uint8_t)(__ffsll((long long)mk) - 1);
     mk &= mk - 1ull;
   }
+}
+template <bool COLLIDE>
+__device__ inline void scan_mask_task(const DevMap& m, const Smem& s, int task, bool stale_first, int N) {
+  // task = (agent slot, polyline): 0 centre line, 1 left boundary, 2 right boundary
+  MaskTask mt;
+  mask_stage1(m, mt, task, s.path[task / 3], s.cp[task]);
+  mask_stage2<COLLIDE>(m, s, mt, stale_first, N);
+  mask_stage3(m, s, mt, task);
 }
 
 template <bool COLLIDE, bool FASTDIV>
@@ -601,7 +632,6 @@ __global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigm
   Smem s(smem_raw, G * N, N, t.K, t.D);
 #define TS(k) do { if (g.dbg_ts && tid == 0) g.dbg_ts[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
   TS(0);
-
   // ---- A: dynamics + vertices (one lane per agent; slots <= 64 so this is wavefront 0) -------------------------------
   if (tid < t.slots && !(dbg_skip & 16)) {
     const int sl = tid;
@@ -635,8 +665,10 @@ __global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigm
   }
   __syncthreads();
   TS(7);
+  // candidate-chunk masks of the scan, one lane per (agent, polyline); the last lanes first, so that wavefront 0 (which has just
+  // integrated the dynamics alone) gets the pair phase below to itself when there are fewer tasks than lanes
   if (m.nch > 0) {
-    for (int task = tid; task < t.slots * 3; task += blockDim.x) scan_mask_task<true>(m, s, task, true, N, g.dbg_ts ? g.dbg_ts + (size_t)blockIdx.x * 16 : nullptr);
+    for (int task = (int)blockDim.x - 1 - tid; task < t.slots * 3; task += blockDim.x) scan_mask_task<true>(m, s, task, true, N);
   }
   TS(1);
 
@@ -1457,8 +1489,12 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
   float *d_c, *d_l, *d_r, *d_y;
   int32_t *d_nc, *d_nl, *d_nr;
   uint8_t* d_loop;
-  ALLOC(d_c, hc.size() * 4); ALLOC(d_l, hl.size() * 4); ALLOC(d_r, hr.size() * 4); ALLOC(d_y, (size_t)np * S * 4);
-  ALLOC(d_nc, (size_t)np * 4); ALLOC(d_nl, (size_t)np * 4); ALLOC(d_nr, (size_t)np * 4); ALLOC(d_loop, (size_t)np);
+  // centre / left / right tables in ONE allocation each (polyline pl of path p at d_c + pl * poly_stride + p * P * 2, its point
+  // count at d_nc[pl * np + p]): a per-lane polyline choice is then an address offset, not a select between kernel arguments
+  ALLOC(d_c, hc.size() * 4 * 3); d_l = d_c + hc.size(); d_r = d_l + hc.size();
+  ALLOC(d_y, (size_t)np * S * 4);
+  ALLOC(d_nc, (size_t)np * 4 * 3); d_nl = d_nc + np; d_nr = d_nl + np;
+  ALLOC(d_loop, (size_t)np);
 #define H2D(dst, src, bytes)                                                                     \
   if (hipMemcpyAsync((dst), (src), (bytes), hipMemcpyHostToDevice, h->stream) != hipSuccess) {   \
     sigmaenv_destroy(h);                                                                         \
@@ -1546,7 +1582,7 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
     }
   }
   if (const char* e = getenv("SIGMAENV_FASTDIV")) fast_div = fast_div && atoi(e) != 0;
-  h->map = DevMap{d_c, d_l, d_r, d_y, d_nc, d_nl, d_nr, d_loop, P, np, S, d_box, d_gbox, d_neigh, neigh_radius, neigh_radius_far, prune ? nch : 0, nullptr, fast_div, rect_radius};
+  h->map = DevMap{d_c, d_l, d_r, d_y, d_nc, d_nl, d_nr, d_loop, P, np, S, d_box, d_gbox, d_neigh, neigh_radius, neigh_radius_far, prune ? nch : 0, nullptr, fast_div, rect_radius, (int32_t)hc.size()};
   {  // start table: derived state of an agent placed on any centre-line point, by the kernels' own scan code
     float* d_tab = nullptr;
     ALLOC(d_tab, (size_t)np * P * START_ROW * sizeof(float));

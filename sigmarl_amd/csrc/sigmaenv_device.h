@@ -39,6 +39,7 @@ struct DevMap {
   const float* start_table; // derived state of an agent freshly placed on centre-line point pt of path p, [n_paths][P][START_ROW]
   int32_t fast_div;         // every real segment has 2^-60 <= |l|^2 <= 2^60: the shared-reciprocal division is exact (div_shared)
   float rect_radius;        // upper bound of |vertex - centre| of a vehicle rectangle (half diagonal + slack)
+  int32_t poly_stride;      // floats between the centre / left / right tables (they share one allocation, as do the point counts)
 };
 #define SIGMAENV_CHUNK 4
 // row of the start table (floats): everything reset_init_distances_and_short_term_ref_path derives for an agent standing on a
