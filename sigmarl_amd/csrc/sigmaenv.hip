@@ -347,11 +347,13 @@ __device__ inline void pair_scan(const DevMap& m, const sigmaenv_config_t& c, co
   const int sl = slotA + (valid ? ag : (ag ^ 1));
   const int path = s.path[sl];
   const float cgx = s.st[sl * 8], cgy = s.st[sl * 8 + 1];
-  const bool stale = stale_first && (sl % N == 0);
+  const int rA = slotA % N;  // wavefront-uniform
+  const int rs = rA + (sl - slotA);
+  const bool stale = stale_first && (rs == 0 || rs == N);
   const float* qv = stale ? (s.vold + sl * 10) : (s.vnew + sl * 10);
   const float* ev = s.vnew + sl * 10;
   const float2* ctr2 = reinterpret_cast<const float2*>(m.center + (size_t)path * m.P * 2);
-  const float2* pol2 = reinterpret_cast<const float2*>((side ? m.right : m.left) + (size_t)path * m.P * 2);
+  const float2* pol2 = reinterpret_cast<const float2*>(m.left + (size_t)side * m.poly_stride + (size_t)path * m.P * 2);
   const int n = s.npts[sl * 3], np = s.npts[sl * 3 + 1 + side];
   // ---- candidate chunk masks (scan_mask_task, one lane per (agent, polyline), computed before the scan)
   const unsigned long long mc = s.cmask[sl * 3], mb = s.cmask[sl * 3 + 1 + side];
@@ -428,11 +430,14 @@ __device__ inline void pair_scan(const DevMap& m, const sigmaenv_config_t& c, co
     ck = min(kc_c, __shfl_xor(kc_c, 16, 64));
   }
   const unsigned long long hb = COLLIDE ? __ballot(h && valid) : 0ull;
+  // the four corner minima are row-uniform after the reduction: lanes 0..3 of the row take one square root each
+  const float bsq = gl == 0 ? bs0 : (gl == 1 ? bs1 : (gl == 2 ? bs2 : bs3));
+  const float bcorner = sqrtf(bsq);
+  if (gl < 4 && valid) ((side ? s.dright : s.dleft) + sl * 5)[1 + gl] = bcorner;
   if (gl == 0 && valid) {
     float wh = (float)((double)c.width / 2.0);
     float* dst = (side ? s.dright : s.dleft) + sl * 5;
     dst[0] = bd0 - wh;  // world_state_rt.py:608-610
-    dst[1] = sqrtf(bs0); dst[2] = sqrtf(bs1); dst[3] = sqrtf(bs2); dst[4] = sqrtf(bs3);
     s.cp[sl * 3 + 1 + side] = bk + 1;
     if (side == 0) {
       s.dref[sl] = cd;
@@ -697,12 +702,13 @@ __global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigm
   __syncthreads();  // the candidate masks (written by other lanes) must be visible to the scan
   TS(2);
   // ---- B2: distance queries + boundary collisions (two agents per wavefront; full-scan fallback one agent per wavefront) ----
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);  // wavefront-uniform: the pair bookkeeping of the scan stays on the scalar unit
   if (dbg_skip & 2) {
   } else if (m.nch > 0) {
     if (m.fast_div) {
-      for (int pr = wave; 2 * pr < t.slots; pr += n_waves) pair_scan<true, true>(m, c, s, 2 * pr, (2 * pr + 1 < t.slots) ? 3 : 1, lane, true, N);
+      for (int pr = wave_u; 2 * pr < t.slots; pr += n_waves) pair_scan<true, true>(m, c, s, 2 * pr, (2 * pr + 1 < t.slots) ? 3 : 1, lane, true, N);
     } else {
-      for (int pr = wave; 2 * pr < t.slots; pr += n_waves) pair_scan<true, false>(m, c, s, 2 * pr, (2 * pr + 1 < t.slots) ? 3 : 1, lane, true, N);
+      for (int pr = wave_u; 2 * pr < t.slots; pr += n_waves) pair_scan<true, false>(m, c, s, 2 * pr, (2 * pr + 1 < t.slots) ? 3 : 1, lane, true, N);
     }
   } else {
     for (int sl = wave; sl < t.slots; sl += n_waves) {
