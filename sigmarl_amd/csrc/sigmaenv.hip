@@ -620,10 +620,32 @@ __device__ inline void observe_tile(const sigmaenv_config_t& c, const Smem& s, c
 // the fused step kernel: grid = ceil(n_envs / G), block = 64 * waves
 // VMAS >= 1.4 call order restated per env: world.step(); reward(a) for all a; observation(a) for all a; done()
 // ---------------------------------------------------------------------------------------------------------------------
-struct Smem;
+// candidate (path, point) of try `tr` for agent `i` of env `b` -- the draw layout shared with the oracle
+struct ResetDraw {
+  uint64_t seed, counter;
+  int path_first, path_count;
+};
+__device__ __forceinline__ void reset_candidate(const DevMap& m, const ResetDraw& rd, int b, int i, int tr, int& path, int& pt, float& px, float& py,
+                                                uint32_t draw0 = 0u) {
+  path = rd.path_first + (int)__umulhi(rng_u32(rd.seed, rd.counter, (uint32_t)b, (uint32_t)i, draw0 + 2u * tr), (uint32_t)rd.path_count);
+  int n = m.n_center[path];
+  int end = n / 2;
+  if (end < 4) end = 4;
+  pt = 3 + (int)__umulhi(rng_u32(rd.seed, rd.counter, (uint32_t)b, (uint32_t)i, draw0 + 2u * tr + 1u), (uint32_t)(end - 3));
+  const float2 xy = reinterpret_cast<const float2*>(m.center)[(size_t)path * m.P + pt];
+  px = xy.x;
+  py = xy.y;
+}
+// the tries a wavefront evaluates up front for a finished env: lane -> (agent, try), 64/N tries per agent
+struct ResetPrefetch {
+  int path, pt;
+  float x, y;
+  bool have;  // the first env of this wavefront (e == wave) has its candidates here already
+};
+
 __device__ inline void auto_reset_tile(const sigmaenv_config_t& c, const DevMap& m, const DevBufs& g, const Smem& s, const Tile& t,
                                        const unsigned long long* s_mask, const int* s_full, uint64_t seed, uint64_t counter, int path_first,
-                                       int path_count, int obs_mode);
+                                       int path_count, int obs_mode, const ResetPrefetch& pre);
 #define MAX_G 64
 #ifndef STEP_MIN_WAVES
 #define STEP_MIN_WAVES 4  // <= 128 VGPRs: 4 workgroups per CU resident, 16 workgroups per CU at 16x4096 = 4 full rounds
@@ -850,6 +872,18 @@ __global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigm
   __syncthreads();
   TS(4);
 
+  // fused resets: the start candidates of a finished env only depend on the random stream and the map, so the wavefront that
+  // will re-place env `wave` requests them now and the two dependent loads complete behind the observation phase
+  ResetPrefetch pre;
+  pre.have = false;
+  pre.path = 0; pre.pt = 3; pre.x = 0.f; pre.y = 0.f;
+  if (path_count > 0 && wave < t.nenv && s.rew[G * N + wave] != 0.0f) {
+    const int TRp = 64 / N > 0 ? 64 / N : 1;
+    const int ca = lane / TRp, ctr = lane - ca * TRp;
+    const ResetDraw rd{seed, counter, path_first, path_count};
+    if (ca < N) reset_candidate(m, rd, t.env0 + wave, ca, ctr, pre.path, pre.pt, pre.x, pre.y);
+    pre.have = true;
+  }
   // ---- D: observations ---------------------------------------------------------------------------------------------
   if (!(dbg_skip & 8)) observe_tile(c, s, g, t, 8);
   if (g.slab) {  // rollout record of this step (observation AFTER the step, reward, done), one contiguous row per env
@@ -880,7 +914,7 @@ __global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigm
       if (dn || rq) *s_any = 1;
     }
     __syncthreads();
-    if (*s_any) auto_reset_tile(c, m, g, s, t, s_mask, s_full, seed, counter, path_first, path_count, 2);
+    if (*s_any) auto_reset_tile(c, m, g, s, t, s_mask, s_full, seed, counter, path_first, path_count, 2, pre);
   }
 }
 
@@ -1216,23 +1250,14 @@ __device__ __forceinline__ void place_from_start_table(const DevMap& m, const De
 // All threads of the block participate.
 __device__ inline void auto_reset_tile(const sigmaenv_config_t& c, const DevMap& m, const DevBufs& g, const Smem& s, const Tile& t,
                                        const unsigned long long* s_mask, const int* s_full, uint64_t seed, uint64_t counter, int path_first,
-                                       int path_count, int obs_mode) {
+                                       int path_count, int obs_mode, const ResetPrefetch& pre) {
   const int N = t.N;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
+  const ResetDraw rd{seed, counter, path_first, path_count};
 #define TS2(k) do { if (g.dbg_ts2 && tid == 0) g.dbg_ts2[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
   TS2(1);
   const float min_d = sqrtf((float)((double)c.length * (double)c.length + (double)c.width * (double)c.width)) * 1.5f;  // road_traffic.py:679-684
   const float min_d_sq = min_d * min_d;
-  // candidate (path, point) of try `tr` for agent `i` of env `b` -- the draw layout shared with the oracle
-  auto candidate = [&](int b, int i, int tr, int& path, int& pt, float& px, float& py, uint32_t draw0 = 0u) {
-    path = path_first + (int)__umulhi(rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, draw0 + 2u * tr), (uint32_t)path_count);
-    int n = m.n_center[path];
-    int end = n / 2;
-    if (end < 4) end = 4;
-    pt = 3 + (int)__umulhi(rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, draw0 + 2u * tr + 1u), (uint32_t)(end - 3));
-    px = m.center[((size_t)path * m.P + pt) * 2];
-    py = m.center[((size_t)path * m.P + pt) * 2 + 1];
-  };
   const int TR = 64 / N > 0 ? 64 / N : 1;  // tries per agent evaluated up front (all agents at once, loads in flight together)
   for (int e = wave; e < t.nenv; e += n_waves) {
     const int b = t.env0 + e;
@@ -1247,7 +1272,7 @@ __device__ inline void auto_reset_tile(const sigmaenv_config_t& c, const DevMap&
         const int sl = e * N + i;
         int p2, q2;
         float x2, y2;
-        candidate(b, i, lane, p2, q2, x2, y2, 2000u);
+        reset_candidate(m, rd, b, i, lane, p2, q2, x2, y2, 2000u);
         bool ok = true;
         for (int j = 0; j < N; ++j) {
           if (j == i) continue;
@@ -1271,7 +1296,8 @@ __device__ inline void auto_reset_tile(const sigmaenv_config_t& c, const DevMap&
     const bool has_c = ca < N;
     int cpath = 0, cpt = 3;
     float cx = 0.f, cy = 0.f;
-    if (has_c) candidate(b, ca, ctr, cpath, cpt, cx, cy);
+    if (pre.have && e == wave) { cpath = pre.path; cpt = pre.pt; cx = pre.x; cy = pre.y; }
+    else if (has_c) reset_candidate(m, rd, b, ca, ctr, cpath, cpt, cx, cy);
     bool cok = has_c;  // still feasible w.r.t. every agent accepted so far
     for (int i = 0; i < N; ++i) {
       const int sl = e * N + i;
@@ -1284,7 +1310,7 @@ __device__ inline void auto_reset_tile(const sigmaenv_config_t& c, const DevMap&
       } else {     // rare: tries TR..63 of this agent, all lanes at once; none feasible -> the last try (as the bounded loop would)
         int p2, q2;
         float x2, y2;
-        candidate(b, i, lane, p2, q2, x2, y2);
+        reset_candidate(m, rd, b, i, lane, p2, q2, x2, y2);
         bool ok = lane >= TR;
         for (int j = 0; j < i; ++j) {
           float dx = x2 - s.st[(e * N + j) * 8], dy = y2 - s.st[(e * N + j) * 8 + 1];
@@ -1351,7 +1377,9 @@ __global__ void __launch_bounds__(512) sigmaenv_auto_reset_kernel(sigmaenv_confi
   for (int k = tid; k < t.slots * 10; k += blockDim.x) s.vnew[k] = g.vertices[t.a0 * 10 + k];
   for (int k = tid; k < t.slots; k += blockDim.x) s.path[k] = g.path[(t.a0 + k) * 4];
   __syncthreads();
-  auto_reset_tile(c, m, g, s, t, s_mask, s_full, seed, counter, path_first, path_count, (G == 1 && s_full[0]) ? 2 : 1);
+  ResetPrefetch none;
+  none.have = false;
+  auto_reset_tile(c, m, g, s, t, s_mask, s_full, seed, counter, path_first, path_count, (G == 1 && s_full[0]) ? 2 : 1, none);
 }
 
 // =====================================================================================================================
