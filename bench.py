@@ -5,9 +5,11 @@ Contract (see the round prompt): ``python bench.py --gpus N --steps K --warmup W
 ``python -m torch.distributed.run`` with one rank per GPU.  W untimed warm-up steps, then exactly K timed steps bracketed by a
 barrier + torch.cuda.synchronize() on both sides, MAX over ranks, rank 0 prints ONE JSON line.
 
-A "step" is one pass of the hot path over one batch of synthetic input: the fused HIP step over agents x envs, the
-device-side reset of the envs that finished (the reference's step_and_maybe_reset), and -- for N > 1 -- the rollout-buffer
-exchange (the step kernel records each step's slab, one asynchronous RCCL gather per chunk of steps to the learner rank).  Inputs (actions) are resident in HBM before the timed region starts.
+A "step" is one pass of the hot path over one batch of synthetic input: ONE launch (sigmaenv_step_autoreset) that steps agents x envs,
+writes the rollout record of the step (observation incl. the terminal one, reward, done -- the reference's step_and_maybe_reset
+keeps both the terminal and the post-reset observation) into the rollout chunk buffer and re-places the envs that finished; for
+N > 1 additionally one asynchronous RCCL gather per chunk of steps to the learner rank.  Inputs (actions) are resident in HBM
+before the timed region starts.
 Weak scaling: every GPU steps BASELINE config 2 (16 agents x 4096 envs); N = 8 is config 3 (32768 envs).
 """
 from __future__ import annotations
@@ -84,7 +86,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 disables it)")
     ap.add_argument("--no-reset", action="store_true", help="diagnostic: leave finished envs un-reset")
     ap.add_argument("--separate-reset", action="store_true", help="two launches per step (sigmaenv_step; sigmaenv_auto_reset) instead of the fused one")
-    ap.add_argument("--no-gather", action="store_true", help="diagnostic: skip the rollout-slab gather for N > 1")
+    ap.add_argument("--no-gather", action="store_true", help="diagnostic: no rollout record (and no gather to the learner rank for N > 1)")
     ap.add_argument("--chunk-steps", type=int, default=32, help="steps per rollout chunk gathered to the learner rank (N > 1)")
     ap.add_argument("--force-dist", action="store_true", help="diagnostic: init RCCL and run the gather even with one rank")
     args = ap.parse_args()
@@ -129,8 +131,8 @@ def main():
     acts[..., 0] = torch.rand((n_act, B, N), generator=gen, device=device)                 # v_cmd ~ U[0, 1]
     acts[..., 1] = torch.rand((n_act, B, N), generator=gen, device=device) * 0.5 - 0.25    # delta_cmd ~ U[-0.25, 0.25] rad
     gather = None
-    gather_note = "n/a (single GPU)"
-    if use_dist and not args.no_gather:
+    gather_note = "disabled by --no-gather"
+    if not args.no_gather:
         try:  # the rollout exchange must never take the benchmark down: fall back to "no gather" and say so in the JSON line
             gather = RolloutExchange(B, N, env.D, args.chunk_steps, device, force_collective=args.force_dist)
             env.set_slab(gather.slot())
@@ -140,15 +142,13 @@ def main():
             gather.wait_all()
             torch.cuda.synchronize()
             env.auto_reset(seed=seed, counter=0, path_first=env.map.list_first[0], path_count=env.map.list_count[0])
-            gather_note = (f"step kernel records (obs, reward, done) into a [{args.chunk_steps}, B, {N * (env.D + 1) + 1}] chunk buffer; "
-                           "one async gather per chunk to rank 0, double buffered")
+            gather_note = (f"step kernel records (obs, reward, done) into a [{args.chunk_steps}, B, {N * (env.D + 1) + 1}] chunk buffer"
+                           + ("; one async gather per chunk to rank 0, double buffered" if gather.collective else " (single GPU: no exchange)"))
         except Exception as exc:  # noqa: BLE001
             gather = None
             env.set_slab(None)
             gather_note = f"disabled: {type(exc).__name__}: {exc}"
             print(f"[bench] rollout exchange disabled: {exc}", file=sys.stderr)
-    elif use_dist:
-        gather_note = "disabled by --no-gather"
     pf, pc = env.map.list_first[0], env.map.list_count[0]
     counter = [1]
 
@@ -216,7 +216,7 @@ def main():
         "config": {
             "workload": f"cpm_entire map, {N} agents x {B} envs per GPU ({B * world} envs total), {args.distance} distance, rew_method=distance, "
                         f"dt=0.05, obs_dim={env.D}, fused step + device-side reset of finished envs "
-                        + ("(one launch)" if fused else "(two launches)" if not args.no_reset else "(resets disabled)") + (" + rollout-slab gather" if gather else ""),
+                        + ("(one launch)" if fused else "(two launches)" if not args.no_reset else "(resets disabled)") + ((" + rollout record" + (" + gather" if gather.collective else "")) if gather else ""),
             "n_agents": N, "envs_per_gpu": B, "envs_total": B * world, "distance": args.distance,
             "resets_per_step_per_gpu": dones / max(1, args.steps), "rollout_gather": gather_note,
         },
