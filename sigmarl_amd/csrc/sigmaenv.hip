@@ -58,7 +58,7 @@ struct Smem {
     dright = f; f += S * 5;
     dbound = f; f += S;
     dist = f; f += S * DIST_STRIDE(N);
-    thr = f; f += S * 3;   // pruning thresholds of the centre / left / right scan
+    thr = f; f += S * 3;   // step kernel: last step's position (x, y) of the slot, loaded early for the reward phase
     cs = f; f += S * 2;    // cos / sin of the yaw (shared by the vertices and the ego-view transforms)
     rew = f; f += S * 2;   // reward per slot, then done flag per env (rollout slab record)
     int* i = reinterpret_cast<int*>(f);
@@ -664,10 +664,28 @@ __global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigm
     const int sl = tid;
     const size_t gi = t.a0 + sl;
     float st[8], uc[2];
+    // every load of the phase is requested first (the stores below would otherwise fence the later loads behind them)
     const float4* gs = reinterpret_cast<const float4*>(g.state + gi * 8);
-    float4 s0 = gs[0], s1 = gs[1];
+    const float4 s0 = gs[0], s1 = gs[1];
+    const float2 u = reinterpret_cast<const float2*>(actions)[gi];
+    const int pth = g.path[gi * 4];
+    // last step's vertices: agent 0's corner queries and the whole mtv matrix still see them, because update_distances
+    // runs before update_vertices (world_state_rt_sim.py:439-448)
+    const float2* gv = reinterpret_cast<const float2*>(g.vertices + gi * 10);
+    float2 vo[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) vo[k] = gv[k];
+    // last step's closest-point indices: the pruned scan derives its distance upper bounds from them
+    const int cp0 = g.closest[gi * 3 + 0], cp1 = g.closest[gi * 3 + 1], cp2 = g.closest[gi * 3 + 2];
+    // inputs of the reward phase that do not depend on this step
+    const float2 pp = reinterpret_cast<const float2*>(g.prev_pos)[gi];
+    const float2* gst = reinterpret_cast<const float2*>(g.short_term + gi * NS * 2);
+    float2 spo[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) spo[k] = gst[k];
+    const int loop_flag = m.is_loop[pth];
+    const int4 tm = reinterpret_cast<const int4*>(g.timer)[t.env0 + sl / N];  // step count and counters of the env
     st[0] = s0.x; st[1] = s0.y; st[2] = s0.z; st[3] = s0.w; st[4] = s1.x; st[5] = s1.y; st[6] = s1.z; st[7] = s1.w;
-    float2 u = reinterpret_cast<const float2*>(actions)[gi];
     bicycle_step(c, st, u.x, u.y, uc);
     TS(6);
 #pragma unroll
@@ -676,19 +694,22 @@ __global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigm
     float4* go = reinterpret_cast<float4*>(g.state + gi * 8);
     go[0] = make_float4(st[0], st[1], st[2], st[3]);
     go[1] = make_float4(st[4], st[5], st[6], st[7]);
-    // last step's vertices: agent 0's corner queries and the whole mtv matrix still see them, because update_distances
-    // runs before update_vertices (world_state_rt_sim.py:439-448)
-    const float2* gv = reinterpret_cast<const float2*>(g.vertices + gi * 10);
 #pragma unroll
-    for (int k = 0; k < 5; ++k) { float2 vv = gv[k]; s.vold[sl * 10 + 2 * k] = vv.x; s.vold[sl * 10 + 2 * k + 1] = vv.y; }
+    for (int k = 0; k < 5; ++k) { s.vold[sl * 10 + 2 * k] = vo[k].x; s.vold[sl * 10 + 2 * k + 1] = vo[k].y; }
     float v[10];
     rect_vertices(c, st[0], st[1], st[2], v, &s.cs[sl * 2]);
     float2* gvo = reinterpret_cast<float2*>(g.vertices + gi * 10);
 #pragma unroll
     for (int k = 0; k < 5; ++k) { s.vnew[sl * 10 + 2 * k] = v[2 * k]; s.vnew[sl * 10 + 2 * k + 1] = v[2 * k + 1]; gvo[k] = make_float2(v[2 * k], v[2 * k + 1]); }
-    s.path[sl] = g.path[gi * 4];
-    // last step's closest-point indices: the pruned scan derives its distance upper bounds from them
-    s.cp[sl * 3 + 0] = g.closest[gi * 3 + 0]; s.cp[sl * 3 + 1] = g.closest[gi * 3 + 1]; s.cp[sl * 3 + 2] = g.closest[gi * 3 + 2];
+    s.path[sl] = pth;
+    s.thr[sl * 3] = pp.x; s.thr[sl * 3 + 1] = pp.y;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) { s.shrt[sl * NS * 2 + 2 * k] = spo[k].x; s.shrt[sl * NS * 2 + 2 * k + 1] = spo[k].y; }
+    s.flags[sl * 4 + 1] = loop_flag;
+    s.thr[sl * 3 + 2] = __int_as_float(tm.x);
+    s.flags[sl * 4 + 2] = tm.y;  // counters: the first agent's lane of every env keeps them for the done() bookkeeping
+    s.near[sl * (t.K > 0 ? t.K : 1)] = tm.z;  // (the nearest-neighbour list is only filled by the observation phase)
+    s.cp[sl * 3 + 0] = cp0; s.cp[sl * 3 + 1] = cp1; s.cp[sl * 3 + 2] = cp2;
   }
   __syncthreads();
   TS(7);
@@ -761,15 +782,14 @@ __global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigm
     int col_a = 0, col_l = 0, goal = 0, entry = 0;
     if (act) {
       const float* si = s.st + sl * 8;
-      float2 pp = reinterpret_cast<const float2*>(g.prev_pos)[gi];
+      const float2 pp = make_float2(s.thr[sl * 3], s.thr[sl * 3 + 1]);
       float w[3];
       w[0] = __uint_as_float(W_REF_BITS[0]); w[1] = __uint_as_float(W_REF_BITS[1]); w[2] = __uint_as_float(W_REF_BITS[2]);
       float mvx = si[0] - pp.x, mvy = si[1] - pp.y;                  // road_traffic.py:972-974
       float acc = 0.0f;
-      const float2* gst = reinterpret_cast<const float2*>(g.short_term + gi * NS * 2);
 #pragma unroll
-      for (int k = 0; k < NS; ++k) {  // the short-term path of the PREVIOUS step is still in HBM (:976-984)
-        float2 sp = gst[k];
+      for (int k = 0; k < NS; ++k) {  // the short-term path of the PREVIOUS step (:976-984), staged in LDS by phase A
+        const float2 sp = make_float2(s.shrt[sl * NS * 2 + 2 * k], s.shrt[sl * NS * 2 + 2 * k + 1]);
         float rx = sp.x - pp.x, ry = sp.y - pp.y;
         float mp = mvx * rx + mvy * ry;
         acc = acc + mp * w[k];
@@ -779,7 +799,7 @@ __global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigm
       rew += acc / denom * c.reward_progress;                        // :986-991
       {  // entry / exit segments of non-loop paths (world_state_rt_sim.py:413-424) and the boundary minimum (world_state_rt.py:648-656)
         const int pth = s.path[sl];
-        if (!m.is_loop[pth]) {
+        if (!s.flags[sl * 4 + 1]) {
           const float* lb = m.left + (size_t)pth * m.P * 2;
           const float* rb = m.right + (size_t)pth * m.P * 2;
           const int nl = m.n_left[pth], nr = m.n_right[pth];
@@ -794,7 +814,14 @@ __global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigm
         s.dbound[sl] = mbnd;
       }
       float reward_goal = (float)goal * c.reward_reach_goal;
-      for (int j = 0; j < N; ++j) col_a |= s.col[sl * COL_STRIDE(N) + j];        // :1008-1013
+      if ((N & 3) == 0) {  // the row of collision bytes is word aligned (COL_STRIDE): N / 4 LDS reads instead of N  (:1008-1013)
+        const uint32_t* cw = reinterpret_cast<const uint32_t*>(s.col + sl * COL_STRIDE(N));
+        uint32_t any = 0u;
+        for (int j = 0; j < N / 4; ++j) any |= cw[j];
+        col_a = any != 0u;
+      } else {
+        for (int j = 0; j < N; ++j) col_a |= s.col[sl * COL_STRIDE(N) + j];
+      }
       float pca = (float)col_a * c.penalty_collide_with_agents;
       col_l = s.flags[sl * 4 + 0];
       float pcl = (float)col_l * c.penalty_collide_with_boundaries;  // :1021-1026
@@ -813,13 +840,33 @@ __global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigm
         }
         if (c.rew_flags & SIGMAENV_REW_DISTANCE) {                   // :1086-1110
           float ssum = 0.0f;
-          for (int j = 0; j < N; ++j) ssum += decreasing_lin(s.dist[sl * DIST_STRIDE(N) + j], c.threshold_near_other_agents_low, c.threshold_near_other_agents_high);
+          {  // decreasing_lin (helper_scenario.py:960-996) with the division by the constant (x1 - x0) through its reciprocal (exact, see
+             // div_shared; the numerator is 0 or at least an ulp of the thresholds)
+            const float x0 = c.threshold_near_other_agents_low, x1 = c.threshold_near_other_agents_high;
+            const float denom = x1 - x0;
+            const bool fast = denom >= 0x1p-60f && denom <= 0x1p60f;
+            const float rcp = fast ? shared_rcp(denom) : 0.0f;
+            for (int j0 = 0; j0 < N; j0 += 4) {
+              float d[4];
+#pragma unroll
+              for (int u2 = 0; u2 < 4; ++u2) d[u2] = s.dist[sl * DIST_STRIDE(N) + min(j0 + u2, N - 1)];
+#pragma unroll
+              for (int u2 = 0; u2 < 4; ++u2) {
+                if (j0 + u2 < N) {
+                  const float x = clampf(d[u2], x0, x1);
+                  const float q = fast ? div_shared(x - x0, denom, rcp) : (x - x0) / denom;
+                  ssum += 1.0f - q;
+                }
+              }
+            }
+          }
           float p = ssum * c.penalty_near_other_agents;
           near_other = p; has_near = true;
           rew += p; rew += pen_lane;
           if (c.rew_flags & SIGMAENV_REW_HAS_SPARSE) { rew += pca; rew += pcl; }
         }
       }
+      TS(14);
       float r = clampf(rew, -1.0f, 1.0f);                            // :1249
       g.reward[gi] = r;
       s.rew[sl] = r;
@@ -834,7 +881,9 @@ __global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigm
       // update_state_after_rewarding: new short-term path (world_state_rt_sim.py:450-454)
       int path = s.path[sl];
       float sp[NS * 2];
-      short_term_path(m.center + (size_t)path * m.P * 2, m.n_center[path], m.is_loop[path] != 0, s.cp[sl * 3], sp);
+      short_term_path(m.center + (size_t)path * m.P * 2, s.npts[sl * 3], s.flags[sl * 4 + 1] != 0, s.cp[sl * 3], sp);
+      if (sp[0] == 12345.0f) TS(15);
+      TS(15);
       float2* gso = reinterpret_cast<float2*>(g.short_term + gi * NS * 2);
 #pragma unroll
       for (int k = 0; k < NS; ++k) { s.shrt[sl * NS * 2 + 2 * k] = sp[2 * k]; s.shrt[sl * NS * 2 + 2 * k + 1] = sp[2 * k + 1]; gso[k] = make_float2(sp[2 * k], sp[2 * k + 1]); }
@@ -851,7 +900,7 @@ __global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigm
     const unsigned long long b_any = __ballot(act && (col_a | col_l | goal));
     if (act) {
       const int b = t.env0 + e;
-      const int step = g.timer[b * 4] + 1;
+      const int step = __float_as_int(s.thr[sl * 3 + 2]) + 1;
       const int max_reached = (step == c.max_steps - 1);
       const int any_ca = (b_ca & env_mask) != 0ull, any_cl = (b_cl & env_mask) != 0ull;
       const int done = c.is_testing_mode ? max_reached : (max_reached | any_ca | any_cl);
@@ -862,8 +911,8 @@ __global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigm
       s.flags[sl * 4 + 3] = (rq && !done) ? 1 : 0;
       if (i == 0) {
         g.timer[b * 4] = step;
-        g.timer[b * 4 + 1] += __popcll(b_any & env_mask);
-        g.timer[b * 4 + 2] += __popcll(b_goal & env_mask);
+        g.timer[b * 4 + 1] = s.flags[sl * 4 + 2] + __popcll(b_any & env_mask);
+        g.timer[b * 4 + 2] = s.near[sl * (t.K > 0 ? t.K : 1)] + __popcll(b_goal & env_mask);
         g.done[b] = (uint8_t)done;
         s.rew[G * N + e] = done ? 1.0f : 0.0f;
       }

@@ -20,6 +20,7 @@ ts = np.zeros((B, 16), np.uint64)
 n = f(env.h, ts.ctypes.data_as(C.c_void_p), B)
 ts8 = ts[:n].astype(np.int64)
 print("A split: loads+bicycle %.0f  vertices+stores %.0f  mask stage 2 %.0f" % ((ts8[:, 6] - ts8[:, 0]).mean(), (ts8[:, 7] - ts8[:, 6]).mean(), (ts8[:, 1] - ts8[:, 7]).mean()))
+print("C split: reward terms %.0f  short-term path %.0f  stores+done %.0f" % ((ts8[:, 14] - ts8[:, 3]).mean(), (ts8[:, 15] - ts8[:, 14]).mean(), (ts8[:, 4] - ts8[:, 15]).mean()))
 o = ts8[:, 8:14]
 print("D split: topk %.0f  sync %.0f  pass1 %.0f  pass2+3 %.0f  sync %.0f  stores %.0f" % tuple([(ts8[:, 8] - ts8[:, 4]).mean()] + [(o[:, k + 1] - o[:, k]).mean() for k in range(5)]))
 ts = ts[:n, :6].astype(np.int64)
