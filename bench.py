@@ -199,7 +199,8 @@ def main():
     fused = not (args.no_reset or args.separate_reset)
     # the fused launch also rewrites the whole record of every agent of a reset env: 320 + 5 N bytes
     reset_bytes = (320 + 5 * N) * N * (dones / max(1, args.steps)) if fused else 0.0
-    achieved = (bytes_per * N * B + reset_bytes) / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None
+    slab_bytes = 4.0 * (N * (env.D + 1) + 1) * B if gather is not None else 0.0  # the rollout record row of every env
+    achieved = (bytes_per * N * B + reset_bytes + slab_bytes) / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None
     traffic = None
     try:  # HBM bytes per launch from the separate rocprofv3 --pmc passes (tools/pmc_passes.sh), corrected as the MI355X guide says
         with open(os.path.join(ROOT, "profiles", "traffic_latest.json")) as f:
@@ -223,7 +224,7 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": (achieved / 8000.0) if achieved else None,
             "traffic": traffic, "kernel": "sigmaenv_step_kernel", "kernel_avg_ms": kernel_ms, "kernel_launches": n_launch,
-            "algorithmic_bytes_per_agent_env_step": bytes_per, "algorithmic_bytes_per_launch": bytes_per * N * B + reset_bytes,
+            "algorithmic_bytes_per_agent_env_step": bytes_per, "algorithmic_bytes_per_launch": bytes_per * N * B + reset_bytes + slab_bytes,
         },
     }
     if rank == 0 and args.cpu_seconds > 0 and world == 1:
