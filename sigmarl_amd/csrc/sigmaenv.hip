@@ -658,6 +658,8 @@ __global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigm
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
   Smem s(smem_raw, G * N, N, t.K, t.D);
 #define TS(k) do { if (g.dbg_ts && tid == 0) g.dbg_ts[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+  int* pair_ctr = reinterpret_cast<int*>(smem_raw + ((Smem::bytes(G * N, N, t.K, t.D) + 15) & ~(size_t)15)) + MAX_G * 3 + 1;  // after s_mask / s_full / s_any
+  if (tid == blockDim.x - 1) *pair_ctr = 0;  // visible to everyone after the barrier that ends phase A
   TS(0);
   // ---- A: dynamics + vertices (one lane per agent; slots <= 64 so this is wavefront 0) -------------------------------
   if (tid < t.slots && !(dbg_skip & 16)) {
@@ -722,24 +724,70 @@ __global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigm
 
   // ---- B1: mutual distances + agent-agent collisions (one lane per ordered pair) -------------------------------------
   const float diag = sqrtf(c.world_x_dim * c.world_x_dim + c.world_y_dim * c.world_y_dim);  // helper_scenario.py:1140-1143
-  for (int p = tid; p < t.slots * N; p += blockDim.x) {
-    if (dbg_skip & 1) break;  // profiling experiments only (results invalid)
-    int si = p / N, j = p - si * N;
-    int sj = (si / N) * N + j;
-    float d = (si == sj) ? diag : pair_distance(c, s.st, s.vold, si, sj);
-    s.dist[si * DIST_STRIDE(N) + j] = d;
-    g.dist_agents[t.a0 * N + p] = d;
-    uint8_t col = 0;
-    if (c.distance_type == SIGMAENV_DIST_C2C) {
-      // world_state_rt_sim.py:382-393; rectangles whose circumcircles are disjoint cannot produce a proper edge crossing
-      // (DESIGN.md "Pruned scan"), so the 16 edge tests are skipped for them
-      if (si != sj && !(d > 2.0f * m.rect_radius + 1e-4f))
-        col = interx_rect_rect(s.vnew + (si < sj ? si : sj) * 10, s.vnew + (si < sj ? sj : si) * 10) ? 1 : 0;
-    } else {
-      col = (d == 0.0f) ? 1 : 0;  // :394-396
+  // The pairs are handed out in batches of 64 from an LDS counter: the wavefront that has no candidate masks to compute (it
+  // integrated the dynamics alone) starts on the pairs at once and takes the larger share, the others join as they finish.
+  const int n_pairs = t.slots * N;
+  for (;;) {
+    int base = 0;
+    if (lane == 0) base = atomicAdd(pair_ctr, 64);
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (base >= n_pairs || (dbg_skip & 1)) break;
+    const int p = base + lane;
+    const bool in_range = p < n_pairs;
+    int si = 0, sj = 0, j = 0;
+    bool near_low = false;
+    if (in_range) {
+      si = p / N; j = p - si * N;
+      sj = (si / N) * N + j;
+      float d = (si == sj) ? diag : pair_distance(c, s.st, s.vold, si, sj);
+      s.dist[si * DIST_STRIDE(N) + j] = d;
+      g.dist_agents[t.a0 * N + p] = d;
+      if (c.distance_type == SIGMAENV_DIST_C2C) {
+        // world_state_rt_sim.py:382-393; rectangles whose circumcircles are disjoint cannot produce a proper edge crossing
+        // (DESIGN.md "Pruned scan"): no collision.  A close pair is tested once, by the lane that holds it as (low, high); that
+        // lane's group writes both entries of the symmetric matrix.
+        const bool near = si != sj && !(d > 2.0f * m.rect_radius + 1e-4f);
+        near_low = near && si < sj;
+        if (!near) { s.col[si * COL_STRIDE(N) + j] = 0; g.col_agents[t.a0 * N + p] = 0; }
+      } else {
+        const uint8_t col = (d == 0.0f) ? 1 : 0;  // :394-396
+        s.col[si * COL_STRIDE(N) + j] = col;
+        g.col_agents[t.a0 * N + p] = col;
+      }
     }
-    s.col[si * COL_STRIDE(N) + j] = col;
-    g.col_agents[t.a0 * N + p] = col;
+    // the 16 (edge of A, edge of B) tests of a close pair, one per lane, four pairs per pass (interX, helper_scenario.py:1165-1196)
+    unsigned long long todo = __ballot(near_low);
+    while (todo) {
+      const int q = lane >> 4, tt = lane & 15;
+      unsigned long long rest = todo;
+      int src = -1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {  // the q-th pending pair of this pass (wavefront-uniform bit peeling)
+        const int b = rest ? (__ffsll((long long)rest) - 1) : -1;
+        if (k == q) src = b;
+        rest &= rest - 1ull;
+      }
+      todo = rest;
+      const int a_sl = __shfl(si, src < 0 ? 0 : src, 64), b_sl = __shfl(sj, src < 0 ? 0 : src, 64);
+      bool hit = false;
+      if (src >= 0) {
+        const float* va = s.vnew + a_sl * 10 + 2 * (tt >> 2);
+        const float* vb = s.vnew + b_sl * 10 + 2 * (tt & 3);
+        const Edge e = make_edge(va[0], va[1], va[2], va[3]);
+        const float dx2 = vb[2] - vb[0], dy2 = vb[3] - vb[1];
+        const float S2 = dx2 * vb[1] - dy2 * vb[0];
+        hit = edge_hits_segment(e, vb[0], vb[1], vb[2], vb[3], dx2, dy2, S2);
+      }
+      const unsigned long long hb = __ballot(hit);
+      if (src >= 0 && tt == 0) {
+        const uint8_t col = ((hb >> (q * 16)) & 0xFFFFull) ? 1 : 0;
+        const int ja = b_sl - (a_sl / N) * N, jb = a_sl - (a_sl / N) * N;  // column of B in A's row and of A in B's row
+        s.col[a_sl * COL_STRIDE(N) + ja] = col;
+        s.col[b_sl * COL_STRIDE(N) + jb] = col;
+        g.col_agents[(t.a0 + a_sl) * N + ja] = col;
+        g.col_agents[(t.a0 + b_sl) * N + jb] = col;
+      }
+    }
   }
 
   __syncthreads();  // the candidate masks (written by other lanes) must be visible to the scan
