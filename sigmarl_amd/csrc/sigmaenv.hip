@@ -43,6 +43,7 @@ struct Smem {
   int *path, *cp, *near, *flags, *npts;
   unsigned long long* cmask;  // candidate-chunk masks of the centre / left / right scan, [S][3]
   uint8_t* cand;              // the first CAND_LIST set bits of every mask as a list of chunk indices, [S][3][CAND_LIST]
+  uint16_t* pidx;             // (i, j), i < j, of the u-th unordered agent pair of an env: i | j << 8, [N (N - 1) / 2]
   float4* escr;               // B2 staging of the segments close enough to hit the rectangle, [MAX_WAVES][4 lane groups][4]
   uint8_t* col;
   __device__ Smem(char* base, int S, int N, int K, int D) {
@@ -70,12 +71,13 @@ struct Smem {
     i += (S * 3) & 1;      // keep the 64-bit masks 8-byte aligned
     cmask = reinterpret_cast<unsigned long long*>(i); i += S * 3 * 2;
     cand = reinterpret_cast<uint8_t*>(i); i += S * 3 * (CAND_LIST / 4);
+    pidx = reinterpret_cast<uint16_t*>(i); i += (N * (N - 1) / 2 + 1) / 2;
     col = reinterpret_cast<uint8_t*>(i);
   }
   __host__ __device__ static size_t bytes(int S, int N, int K, int D) {
     size_t f = (size_t)S * 8 + S * 10 * 2 + S * NS * 2 + S + S * 5 * 2 + S + (size_t)S * DIST_STRIDE(N) + (size_t)S * D + S * 3 + S * 2 + S * 2;
     size_t i = (size_t)S + S * 3 + S * (K > 0 ? K : 1) + S * 4 + S * 3 + 1 + (size_t)S * 3 * 2 + (size_t)S * 3 * (CAND_LIST / 4);
-    return ESCR_BYTES + (f + i + 3) * 4 + (size_t)S * COL_STRIDE(N) + 16;
+    return ESCR_BYTES + (f + i + 3 + (size_t)(N * (N - 1) / 2 + 1) / 2) * 4 + (size_t)S * COL_STRIDE(N) + 16;
   }
 };
 
@@ -660,6 +662,13 @@ __global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigm
 #define TS(k) do { if (g.dbg_ts && tid == 0) g.dbg_ts[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
   int* pair_ctr = reinterpret_cast<int*>(smem_raw + ((Smem::bytes(G * N, N, t.K, t.D) + 15) & ~(size_t)15)) + MAX_G * 3 + 1;  // after s_mask / s_full / s_any
   if (tid == blockDim.x - 1) *pair_ctr = 0;  // visible to everyone after the barrier that ends phase A
+  {  // pair table rows, by threads that have nothing to do in phase A: row i holds (i, i+1) .. (i, N-1)
+    const int i = (int)blockDim.x - 2 - tid;
+    if (i >= 0 && i < N - 1) {
+      const int off = i * (2 * N - i - 1) / 2;
+      for (int j = i + 1; j < N; ++j) s.pidx[off + j - i - 1] = (uint16_t)(i | (j << 8));
+    }
+  }
   TS(0);
   // ---- A: dynamics + vertices (one lane per agent; slots <= 64 so this is wavefront 0) -------------------------------
   if (tid < t.slots && !(dbg_skip & 16)) {
@@ -724,9 +733,18 @@ __global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigm
 
   // ---- B1: mutual distances + agent-agent collisions (one lane per ordered pair) -------------------------------------
   const float diag = sqrtf(c.world_x_dim * c.world_x_dim + c.world_y_dim * c.world_y_dim);  // helper_scenario.py:1140-1143
-  // The pairs are handed out in batches of 64 from an LDS counter: the wavefront that has no candidate masks to compute (it
-  // integrated the dynamics alone) starts on the pairs at once and takes the larger share, the others join as they finish.
-  const int n_pairs = t.slots * N;
+  // The matrices are symmetric: one lane per UNORDERED pair (i < j; s.pidx maps the pair number to (i, j)) computes the distance and
+  // the collision flag and writes both entries.  The pairs are handed out in batches of 64 from an LDS counter: the wavefront that has
+  // no candidate masks to compute (it integrated the dynamics alone) starts at once and takes the larger share, the others join.
+  const int TP = N * (N - 1) / 2;
+  const int n_pairs = t.nenv * TP;
+  for (int sl = tid; sl < t.slots; sl += blockDim.x) {  // diagonal (helper_scenario.py:1140-1143)
+    const int i = sl % N;
+    s.dist[sl * DIST_STRIDE(N) + i] = diag;
+    g.dist_agents[(t.a0 + sl) * N + i] = diag;
+    s.col[sl * COL_STRIDE(N) + i] = 0;
+    g.col_agents[(t.a0 + sl) * N + i] = 0;
+  }
   for (;;) {
     int base = 0;
     if (lane == 0) base = atomicAdd(pair_ctr, 64);
@@ -734,29 +752,33 @@ __global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigm
     if (base >= n_pairs || (dbg_skip & 1)) break;
     const int p = base + lane;
     const bool in_range = p < n_pairs;
-    int si = 0, sj = 0, j = 0;
-    bool near_low = false;
+    int si = 0, sj = 0, i = 0, j = 0;
+    bool near = false;
     if (in_range) {
-      si = p / N; j = p - si * N;
-      sj = (si / N) * N + j;
-      float d = (si == sj) ? diag : pair_distance(c, s.st, s.vold, si, sj);
+      const int e = p / TP;
+      const unsigned ij = s.pidx[p - e * TP];
+      i = (int)(ij & 0xFFu); j = (int)(ij >> 8);
+      si = e * N + i; sj = e * N + j;
+      const float d = pair_distance(c, s.st, s.vold, si, sj);
       s.dist[si * DIST_STRIDE(N) + j] = d;
-      g.dist_agents[t.a0 * N + p] = d;
+      s.dist[sj * DIST_STRIDE(N) + i] = d;
+      g.dist_agents[(t.a0 + si) * N + j] = d;
+      g.dist_agents[(t.a0 + sj) * N + i] = d;
+      uint8_t col = 0;
       if (c.distance_type == SIGMAENV_DIST_C2C) {
         // world_state_rt_sim.py:382-393; rectangles whose circumcircles are disjoint cannot produce a proper edge crossing
-        // (DESIGN.md "Pruned scan"): no collision.  A close pair is tested once, by the lane that holds it as (low, high); that
-        // lane's group writes both entries of the symmetric matrix.
-        const bool near = si != sj && !(d > 2.0f * m.rect_radius + 1e-4f);
-        near_low = near && si < sj;
-        if (!near) { s.col[si * COL_STRIDE(N) + j] = 0; g.col_agents[t.a0 * N + p] = 0; }
+        // (DESIGN.md "Pruned scan"): no collision; close pairs are tested below
+        near = !(d > 2.0f * m.rect_radius + 1e-4f);
       } else {
-        const uint8_t col = (d == 0.0f) ? 1 : 0;  // :394-396
-        s.col[si * COL_STRIDE(N) + j] = col;
-        g.col_agents[t.a0 * N + p] = col;
+        col = (d == 0.0f) ? 1 : 0;  // :394-396
+      }
+      if (!near) {
+        s.col[si * COL_STRIDE(N) + j] = col; s.col[sj * COL_STRIDE(N) + i] = col;
+        g.col_agents[(t.a0 + si) * N + j] = col; g.col_agents[(t.a0 + sj) * N + i] = col;
       }
     }
     // the 16 (edge of A, edge of B) tests of a close pair, one per lane, four pairs per pass (interX, helper_scenario.py:1165-1196)
-    unsigned long long todo = __ballot(near_low);
+    unsigned long long todo = __ballot(near);
     while (todo) {
       const int q = lane >> 4, tt = lane & 15;
       unsigned long long rest = todo;
