@@ -344,3 +344,64 @@ def test_fused_step_autoreset_equals_step_then_auto_reset(scen, N, B, mtv, rew, 
     assert total_done > 0
     sep.close()
     fus.close()
+
+
+ALL_MAPS = ["cpm_mixed", "interchange_1", "interchange_2", "interchange_3", "intersection_2", "intersection_3", "intersection_4",
+            "intersection_5", "intersection_6", "intersection_7", "intersection_8", "on_ramp_2_multilane", "roundabout_1", "roundabout_2"]
+
+
+@pytest.mark.parametrize("scen", ALL_MAPS)
+def test_every_shipped_map_hip_vs_oracle(scen):
+    """Every scenario table the package ships (the three used above are covered there): a short seeded episode with device-side
+    resets through the HIP path and the oracle, every buffer compared after every call."""
+    N, B = 3, 10
+    p = Parameters(n_agents=N, scenario_type=scen, is_use_mtv_distance=(len(scen) % 2 == 0), rew_method="distance_sparse", dt=0.1,
+                   is_apply_mask=False, is_obs_noise=False, max_steps=7)
+    mp = load_map(scen)
+    cfg = make_config(p, mp, B)
+    dev, ora = _hip_env(cfg, mp), ob.OracleEnv(cfg, mp)
+    dev.env.buffer(capi.BUF_DONE).fill_(1)
+    ora.get(capi.BUF_DONE, copy=False)[:] = 1
+    lid = 1 if scen == "cpm_mixed" else 0
+    pf, pc = mp.list_first[lid], mp.list_count[lid]
+    dev.auto_reset(21, 0, pf, pc)
+    ora.auto_reset(21, 0, pf, pc)
+    _compare_all(dev, ora, f"{scen} initial reset")
+    rng = np.random.default_rng(len(scen))
+    n_diff = 0
+    for t in range(10):
+        act = np.stack([rng.uniform(0.0, 1.2, (B, N)), rng.uniform(-0.5, 0.5, (B, N))], axis=-1).astype(np.float32)
+        dev.step(act)
+        ora.step(act)
+        n_diff += _compare_all(dev, ora, f"{scen} step {t}")
+        dev.auto_reset(21, t + 1, pf, pc)
+        ora.auto_reset(21, t + 1, pf, pc)
+        n_diff += _compare_all(dev, ora, f"{scen} reset {t}")
+    assert n_diff <= 16
+    dev.close()
+    ora.close()
+
+
+def test_sixty_four_agents_one_env_per_workgroup():
+    """N = 64: the largest agent count of the layout (one env fills the 64 agent slots of a workgroup, 64-bit agent masks)."""
+    scen, N, B = "cpm_entire", 64, 6
+    p = Parameters(n_agents=N, scenario_type=scen, is_use_mtv_distance=False, rew_method="distance", is_apply_mask=False, is_obs_noise=False,
+                   max_steps=6)
+    mp = load_map(scen)
+    cfg = make_config(p, mp, B)
+    dev, ora = _hip_env(cfg, mp), ob.OracleEnv(cfg, mp)
+    dev.env.buffer(capi.BUF_DONE).fill_(1)
+    ora.get(capi.BUF_DONE, copy=False)[:] = 1
+    pf, pc = mp.list_first[0], mp.list_count[0]
+    dev.auto_reset(4, 0, pf, pc)
+    ora.auto_reset(4, 0, pf, pc)
+    _compare_all(dev, ora, "N=64 initial reset")
+    rng = np.random.default_rng(64)
+    for t in range(6):
+        act = np.stack([rng.uniform(0.0, 1.0, (B, N)), rng.uniform(-0.3, 0.3, (B, N))], axis=-1).astype(np.float32)
+        dev.step_autoreset(act, 4, t + 1, pf, pc)
+        ora.step(act)
+        ora.auto_reset(4, t + 1, pf, pc)
+        _compare_all(dev, ora, f"N=64 fused step {t}")
+    dev.close()
+    ora.close()
