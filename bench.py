@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--no-reset", action="store_true", help="diagnostic: leave finished envs un-reset")
     ap.add_argument("--separate-reset", action="store_true", help="two launches per step (sigmaenv_step; sigmaenv_auto_reset) instead of the fused one")
     ap.add_argument("--no-gather", action="store_true", help="diagnostic: no rollout record (and no gather to the learner rank for N > 1)")
+    ap.add_argument("--streams", type=int, default=2, help="env shards per GPU, each stepped by its own handle on its own HIP stream "
+                    "(envs are independent: same total work per step, the shards' latency-bound phases overlap the others' scan)")
     ap.add_argument("--chunk-steps", type=int, default=32, help="steps per rollout chunk gathered to the learner rank (N > 1)")
     ap.add_argument("--force-dist", action="store_true", help="diagnostic: init RCCL and run the gather even with one rank")
     args = ap.parse_args()
@@ -95,6 +97,7 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
 
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the HIP runtime starts: enough hardware queues for the shard + RCCL streams
     import torch
     import torch.distributed as dist
 
@@ -122,56 +125,100 @@ def main():
     B, N = args.envs_per_gpu, args.agents
     params_kw = dict(n_agents=N, scenario_type="cpm_entire", dt=0.05, is_use_mtv_distance=(args.distance == "mtv"), rew_method="distance",
                      is_apply_mask=False, is_obs_noise=False, max_steps=128, num_vmas_envs=B)
-    env = SigmaEnv(Parameters(**params_kw), n_envs=B, device=device)
+    # env shards of this GPU: S handles of B / S envs, each on its own HIP stream (no cross-env dependency anywhere in the path)
+    # (only when every shard still fills the GPU's CUs with whole tiles; small batches are launch-bound and stay in one piece)
+    S = args.streams if (args.streams >= 1 and B % max(1, args.streams) == 0 and (B // max(1, args.streams)) * N >= 64 * 512) else 1
+    Bs = B // S
+    main_stream = torch.cuda.current_stream(device)
+    # alternate priorities: the runtime maps streams to a few hardware queues, and two shard streams that land on the same queue
+    # (observed once RCCL has created its own streams) would run their kernels back to back instead of side by side
+    streams = [main_stream] if S == 1 else [torch.cuda.Stream(device, priority=-(k % 2)) for k in range(S)]
     seed = 1000 + rank
-    env.reset_random(seed=seed)
+    envs = []
+    for k in range(S):
+        with torch.cuda.stream(streams[k]):
+            kw = dict(params_kw, num_vmas_envs=Bs)
+            e = SigmaEnv(Parameters(**kw), n_envs=Bs, device=device, envs_per_group=(max(1, 64 // N) if S > 1 else 0))
+            e.reset_random(seed=seed * 64 + k)
+            envs.append(e)
+    env = envs[0]
     gen = torch.Generator(device=device).manual_seed(seed)
     n_act = 16
     acts = torch.empty((n_act, B, N, 2), dtype=torch.float32, device=device)
     acts[..., 0] = torch.rand((n_act, B, N), generator=gen, device=device)                 # v_cmd ~ U[0, 1]
     acts[..., 1] = torch.rand((n_act, B, N), generator=gen, device=device) * 0.5 - 0.25    # delta_cmd ~ U[-0.25, 0.25] rad
+    torch.cuda.synchronize()
     gather = None
     gather_note = "disabled by --no-gather"
     if not args.no_gather:
         try:  # the rollout exchange must never take the benchmark down: fall back to "no gather" and say so in the JSON line
             gather = RolloutExchange(B, N, env.D, args.chunk_steps, device, force_collective=args.force_dist)
-            env.set_slab(gather.slot())
-            env.step(acts[0])
+            slot0 = gather.slot()
+            for k, e in enumerate(envs):
+                e.set_slab(slot0[k * Bs:(k + 1) * Bs])
+                e.step(acts[0][k * Bs:(k + 1) * Bs])
+            torch.cuda.synchronize()
             gather.advance()
             gather.flush()
             gather.wait_all()
             torch.cuda.synchronize()
-            env.auto_reset(seed=seed, counter=0, path_first=env.map.list_first[0], path_count=env.map.list_count[0])
+            for k, e in enumerate(envs):
+                e.auto_reset(seed=seed * 64 + k, counter=0, path_first=env.map.list_first[0], path_count=env.map.list_count[0])
             gather_note = (f"step kernel records (obs, reward, done) into a [{args.chunk_steps}, B, {N * (env.D + 1) + 1}] chunk buffer"
                            + ("; one async gather per chunk to rank 0, double buffered" if gather.collective else " (single GPU: no exchange)"))
         except Exception as exc:  # noqa: BLE001
             gather = None
-            env.set_slab(None)
+            for e in envs:
+                e.set_slab(None)
             gather_note = f"disabled: {type(exc).__name__}: {exc}"
             print(f"[bench] rollout exchange disabled: {exc}", file=sys.stderr)
     pf, pc = env.map.list_first[0], env.map.list_count[0]
     counter = [1]
 
+    W = N * (env.D + 1) + 1
+    act_ptrs = [[acts[q].data_ptr() + k * Bs * N * 2 * 4 for k in range(S)] for q in range(n_act)]
+    shard_seeds = [seed * 64 + k for k in range(S)]
+    fused = not (args.no_reset or args.separate_reset)
+
     def one_step(t):
         if gather is not None:
-            env.set_slab(gather.slot())
-        if args.no_reset or args.separate_reset:
-            env.step(acts[t % n_act])
-            if not args.no_reset:
-                env.auto_reset(seed=seed, counter=counter[0], path_first=pf, path_count=pc)
-        else:  # one launch: the step, its record, then the device-side reset of the finished envs of the tile
-            env.step_autoreset(acts[t % n_act], seed=seed, counter=counter[0], path_first=pf, path_count=pc)
+            slot = gather.slot(streams if S > 1 else None)  # orders the shard streams behind the gather that still reads this buffer
+            base = slot.data_ptr()
+            for k, e in enumerate(envs):
+                e.set_slab_ptr(base + k * Bs * W * 4)
+        ap = act_ptrs[t % n_act]
+        cnt = counter[0]
+        if fused:  # one launch per shard: the step, its record, then the device-side reset of the finished envs of the tile
+            for k, e in enumerate(envs):
+                e.step_autoreset_ptr(ap[k], shard_seeds[k], cnt, pf, pc)
+        else:
+            a = acts[t % n_act]
+            for k, e in enumerate(envs):
+                e.step(a[k * Bs:(k + 1) * Bs])
+                if not args.no_reset:
+                    e.auto_reset(seed=shard_seeds[k], counter=cnt, path_first=pf, path_count=pc)
         counter[0] += 1
         if gather is not None:
+            if S > 1 and gather.t == gather.T - 1:  # the chunk is complete: the gather (main stream) follows every shard's last write
+                for st in streams:
+                    main_stream.wait_stream(st)
             gather.advance()
+
+    def finish_chunk():
+        if gather is not None:
+            if S > 1:
+                for st in streams:
+                    main_stream.wait_stream(st)
+            gather.flush()
+            gather.wait_all()
 
     for t in range(args.warmup):
         one_step(t)
-    if gather is not None:
-        gather.flush()
-        gather.wait_all()
-    env.step_time_ms()  # arms the HIP-event bracketing of the step launches (on the env's stream)
-    resets_before = int(env.buffer(capi.BUF_TIMER)[:, 3].sum().item())  # episodes_reset counters
+    finish_chunk()
+    torch.cuda.synchronize()
+    for e in envs:
+        e.step_time_ms()  # arms the HIP-event bracketing of the step launches (on the env's stream)
+    resets_before = sum(int(e.buffer(capi.BUF_TIMER)[:, 3].sum().item()) for e in envs)  # episodes_reset counters
 
     if use_dist:
         dist.barrier()
@@ -179,9 +226,7 @@ def main():
     t0 = time.perf_counter()
     for t in range(args.steps):
         one_step(args.warmup + t)
-    if gather is not None:
-        gather.flush()
-        gather.wait_all()
+    finish_chunk()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -191,22 +236,30 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
 
-    kernel_ms, n_launch = env.step_time_ms()
-    dones = int(env.buffer(capi.BUF_TIMER)[:, 3].sum().item()) - resets_before
+    timings = [e.step_time_ms() for e in envs]
+    n_launch = sum(n for _, n in timings)
+    kernel_ms = sum(ms * n for ms, n in timings) / max(1, n_launch)
+    dones = sum(int(e.buffer(capi.BUF_TIMER)[:, 3].sum().item()) for e in envs) - resets_before
     total_agent_steps = N * B * world * args.steps
     value = total_agent_steps / elapsed
     bytes_per = algorithmic_bytes_per_agent_step(N)
-    fused = not (args.no_reset or args.separate_reset)
     # the fused launch also rewrites the whole record of every agent of a reset env: 320 + 5 N bytes
     reset_bytes = (320 + 5 * N) * N * (dones / max(1, args.steps)) if fused else 0.0
     slab_bytes = 4.0 * (N * (env.D + 1) + 1) * B if gather is not None else 0.0  # the rollout record row of every env
-    achieved = (bytes_per * N * B + reset_bytes + slab_bytes) / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None
+    step_bytes = bytes_per * N * B + reset_bytes + slab_bytes  # algorithmic bytes of one step over all shards of this GPU
+    if S == 1:
+        achieved = step_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None
+        achieved_basis = "algorithmic bytes per launch / average launch duration (HIP events)"
+    else:  # S launches per step run concurrently: the rate the GPU sustains is bytes per step over the wall time per step
+        achieved = step_bytes / (elapsed / args.steps) / 1e9
+        achieved_basis = (f"{S} concurrent launches per step (one per env shard): algorithmic bytes of all shards per step / wall time per step; "
+                          "kernel_avg_ms is the average duration of ONE shard's launch while it shares the GPU with the others")
     traffic = None
     try:  # HBM bytes per launch from the separate rocprofv3 --pmc passes (tools/pmc_passes.sh), corrected as the MI355X guide says
         with open(os.path.join(ROOT, "profiles", "traffic_latest.json")) as f:
             tr = json.load(f)
-        if tr.get("n_agents") == N and tr.get("envs_per_gpu") == B and tr.get("distance") == args.distance:
-            traffic = tr["hbm_bytes_per_launch"]
+        if tr.get("n_agents") == N and tr.get("envs_per_launch", tr.get("envs_per_gpu")) == Bs and tr.get("distance") == args.distance:
+            traffic = tr["hbm_bytes_per_launch"] * S  # per step, like `achieved` (S launches of B / S envs)
     except Exception:  # noqa: BLE001
         pass
     out = {
@@ -218,18 +271,19 @@ def main():
             "workload": f"cpm_entire map, {N} agents x {B} envs per GPU ({B * world} envs total), {args.distance} distance, rew_method=distance, "
                         f"dt=0.05, obs_dim={env.D}, fused step + device-side reset of finished envs "
                         + ("(one launch)" if fused else "(two launches)" if not args.no_reset else "(resets disabled)") + ((" + rollout record" + (" + gather" if gather.collective else "")) if gather else ""),
-            "n_agents": N, "envs_per_gpu": B, "envs_total": B * world, "distance": args.distance,
+            "n_agents": N, "envs_per_gpu": B, "envs_total": B * world, "distance": args.distance, "env_shards_per_gpu": S,
             "resets_per_step_per_gpu": dones / max(1, args.steps), "rollout_gather": gather_note,
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": (achieved / 8000.0) if achieved else None,
             "traffic": traffic, "kernel": "sigmaenv_step_kernel", "kernel_avg_ms": kernel_ms, "kernel_launches": n_launch,
-            "algorithmic_bytes_per_agent_env_step": bytes_per, "algorithmic_bytes_per_launch": bytes_per * N * B + reset_bytes + slab_bytes,
+            "algorithmic_bytes_per_agent_env_step": bytes_per, "algorithmic_bytes_per_launch": step_bytes / S, "launches_per_step": S, "achieved_basis": achieved_basis,
         },
     }
     if rank == 0 and args.cpu_seconds > 0 and world == 1:
         out["cpu_baseline"] = cpu_baseline(params_kw, B, args.cpu_seconds)
-    env.close()
+    for e in envs:
+        e.close()
     if use_dist:
         dist.destroy_process_group()
     sys.stdout.flush()

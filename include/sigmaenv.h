@@ -76,7 +76,9 @@ typedef struct sigmaenv_config {
   int32_t has_entry_exit;/* scenario_type != "cpm_entire": per-agent reset requests for entry/exit leavers (road_traffic.py:1456-1473) */
   int32_t max_steps;     /* Parameters.max_steps */
   int32_t n_nearing;     /* min(n_nearing_agents_observed, n_agents-1) */
-  int32_t reserved0;
+  int32_t envs_per_group;   /* envs per workgroup of the step kernel (envs_per_group * n_agents <= 64); 0: chosen by the library
+                             * (64 / n_agents, fewer for small batches).  Callers that step several handles concurrently on
+                             * different streams -- env shards of one GPU -- pass 64 / n_agents. */
   float dt;
   float length, width, l_f, l_r;                    /* constants.py:628-636 */
   float max_speed, max_steering;                    /* constants.py:637-640 */

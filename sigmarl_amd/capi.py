@@ -36,7 +36,7 @@ class Config(C.Structure):
     _fields_ = [
         ("abi_version", C.c_int32), ("n_envs", C.c_int32), ("n_agents", C.c_int32), ("distance_type", C.c_int32),
         ("rew_flags", C.c_int32), ("is_testing_mode", C.c_int32), ("has_entry_exit", C.c_int32), ("max_steps", C.c_int32),
-        ("n_nearing", C.c_int32), ("reserved0", C.c_int32),
+        ("n_nearing", C.c_int32), ("envs_per_group", C.c_int32),
         ("dt", C.c_float), ("length", C.c_float), ("width", C.c_float), ("l_f", C.c_float), ("l_r", C.c_float),
         ("max_speed", C.c_float), ("max_steering", C.c_float), ("min_acc", C.c_float), ("max_acc", C.c_float),
         ("min_steering_rate", C.c_float), ("max_steering_rate", C.c_float),

@@ -1781,6 +1781,7 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
   int n_cu = 256;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) n_cu = prop.multiProcessorCount;
   h->G = pick_envs_per_group(N, B, n_cu);
+  if (cfg->envs_per_group >= 1 && cfg->envs_per_group * N <= 64) h->G = cfg->envs_per_group;
   if (const char* e = getenv("SIGMAENV_G")) {
     int v = atoi(e);
     if (v >= 1 && v * N <= 64) h->G = v;

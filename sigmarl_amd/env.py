@@ -100,7 +100,8 @@ class SigmaEnv:
     """One env shard on one GPU.  ``step(actions)`` is one fused HIP launch over agents x envs."""
 
     def __init__(self, parameters: Parameters | None = None, n_envs: int | None = None, device=None, *, cfg: capi.Config | None = None,
-                 map_table: MapTable | None = None, make_world_scenario_type: str = "cpm_entire", lib_path: str | None = None):
+                 map_table: MapTable | None = None, make_world_scenario_type: str = "cpm_entire", lib_path: str | None = None,
+                 envs_per_group: int = 0):
         if not torch.cuda.is_available():
             raise RuntimeError("sigmarl_amd.SigmaEnv needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
         self.lib = capi.load_library(lib_path)
@@ -109,6 +110,8 @@ class SigmaEnv:
                 raise ValueError("pass `parameters` (+ n_envs) or a ready `cfg` + `map_table`")
             map_table = map_table or load_map(parameters.scenario_type)
             cfg = make_config(parameters, map_table, int(n_envs if n_envs is not None else parameters.num_vmas_envs), make_world_scenario_type)
+        if envs_per_group:  # full tiles even for a small shard (several handles stepped concurrently on different streams)
+            cfg.envs_per_group = int(envs_per_group)
         self.parameters = parameters
         self.cfg = cfg
         self.map = map_table
@@ -211,6 +214,13 @@ class SigmaEnv:
         if not (slab.is_cuda and slab.dtype == torch.float32 and slab.is_contiguous() and tuple(slab.shape) == (self.B, self.N * (self.D + 1) + 1)):
             raise ValueError(f"slab must be a contiguous float32 CUDA tensor of shape {(self.B, self.N * (self.D + 1) + 1)}")
         self._chk(self.lib.set_slab(self.h, C.c_void_p(slab.data_ptr())), "set_slab")
+
+    # pointer-level variants for rollout loops that precompute their device addresses (no per-call tensor checks / views)
+    def set_slab_ptr(self, ptr: int):
+        self._chk(self.lib.set_slab(self.h, C.c_void_p(ptr)), "set_slab")
+
+    def step_autoreset_ptr(self, actions_ptr: int, seed: int, counter: int, path_first: int, path_count: int):
+        self._chk(self.lib.step_autoreset(self.h, C.c_void_p(actions_ptr), seed, counter, path_first, path_count), "step_autoreset")
 
     def sync(self):
         self._chk(self.lib.sync(self.h), "sync")

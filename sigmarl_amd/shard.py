@@ -68,10 +68,16 @@ class RolloutExchange:
         self.cur, self.t = 0, 0
         self.completed = []  # indices of chunk buffers whose gather has been issued, in order
 
-    def slot(self) -> torch.Tensor:
-        """The ``[B, W]`` row block the NEXT step must be recorded into (pass it to ``SigmaEnv.set_slab``)."""
+    def slot(self, writer_streams=None) -> torch.Tensor:
+        """The ``[B, W]`` row block the NEXT step must be recorded into (pass it to ``SigmaEnv.set_slab``).  ``writer_streams``:
+        the streams whose kernels write the rows when they are not torch's current stream (env shards on their own streams)."""
         if self.t == 0 and self.pending[self.cur] is not None:  # the buffer is about to be overwritten: its gather must be done
-            self.pending[self.cur].wait()
+            if writer_streams:
+                for st in writer_streams:  # Work.wait() orders the CURRENT stream behind the collective, nothing else
+                    with torch.cuda.stream(st):
+                        self.pending[self.cur].wait()
+            else:
+                self.pending[self.cur].wait()
             self.pending[self.cur] = None
         return self.chunks[self.cur][self.t]
 
