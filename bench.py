@@ -174,6 +174,7 @@ def main():
             print(f"[bench] rollout exchange disabled: {exc}", file=sys.stderr)
     pf, pc = env.map.list_first[0], env.map.list_count[0]
     counter = [1]
+    gather_state = {"note": None}
 
     W = N * (env.D + 1) + 1
     act_ptrs = [[acts[q].data_ptr() + k * Bs * N * 2 * 4 for k in range(S)] for q in range(n_act)]
@@ -202,7 +203,14 @@ def main():
             if S > 1 and gather.t == gather.T - 1:  # the chunk is complete: the gather (main stream) follows every shard's last write
                 for st in streams:
                     main_stream.wait_stream(st)
-            gather.advance()
+            try:
+                gather.advance()
+            except Exception as exc:  # noqa: BLE001 -- a failing exchange must not take the benchmark down: keep recording, stop gathering
+                print(f"[bench] rollout gather failed, continuing without the exchange: {exc}", file=sys.stderr)
+                gather.collective = False
+                gather.pending = [None, None]
+                gather_state["note"] = f"gather failed at run time ({type(exc).__name__}); record kept, exchange disabled"
+                gather.t = 0
 
     def finish_chunk():
         if gather is not None:
@@ -272,7 +280,7 @@ def main():
                         f"dt=0.05, obs_dim={env.D}, fused step + device-side reset of finished envs "
                         + ("(one launch)" if fused else "(two launches)" if not args.no_reset else "(resets disabled)") + ((" + rollout record" + (" + gather" if gather.collective else "")) if gather else ""),
             "n_agents": N, "envs_per_gpu": B, "envs_total": B * world, "distance": args.distance, "env_shards_per_gpu": S,
-            "resets_per_step_per_gpu": dones / max(1, args.steps), "rollout_gather": gather_note,
+            "resets_per_step_per_gpu": dones / max(1, args.steps), "rollout_gather": gather_state["note"] or gather_note,
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": (achieved / 8000.0) if achieved else None,

@@ -342,14 +342,15 @@ __device__ inline void scan_mask_task(const DevMap& m, const Smem& s, int task, 
 }
 
 template <bool COLLIDE, bool FASTDIV>
-__device__ inline void pair_scan(const DevMap& m, const sigmaenv_config_t& c, const Smem& s, int slotA, int valid_mask, int lane, bool stale_first, int N) {
+__device__ inline void pair_scan(const DevMap& m, const sigmaenv_config_t& c, const Smem& s, int slotA, int valid_mask, int lane, bool stale_first, int N,
+                                 int rA = -1) {
   // valid_mask: bit 0 = scan agent slotA, bit 1 = scan agent slotA + 1 (an unselected half mirrors the selected one, results dropped)
   const int grp = lane >> 4, ag = grp >> 1, side = grp & 1, gl = lane & 15, hl = lane & 31;
   const bool valid = (valid_mask >> ag) & 1;
   const int sl = slotA + (valid ? ag : (ag ^ 1));
   const int path = s.path[sl];
   const float cgx = s.st[sl * 8], cgy = s.st[sl * 8 + 1];
-  const int rA = slotA % N;  // wavefront-uniform
+  if (rA < 0) rA = slotA % N;  // agent index of slotA (wavefront-uniform; the step kernel tracks it without a division)
   const int rs = rA + (sl - slotA);
   const bool stale = stale_first && (rs == 0 || rs == N);
   const float* qv = stale ? (s.vold + sl * 10) : (s.vnew + sl * 10);
@@ -818,10 +819,20 @@ __global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigm
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);  // wavefront-uniform: the pair bookkeeping of the scan stays on the scalar unit
   if (dbg_skip & 2) {
   } else if (m.nch > 0) {
+    int rA = (2 * wave_u) % N;  // agent index of the pair's first slot, advanced with the pair (scalar unit, no division per pair)
+    const int r_step = (2 * n_waves) % N;
     if (m.fast_div) {
-      for (int pr = wave_u; 2 * pr < t.slots; pr += n_waves) pair_scan<true, true>(m, c, s, 2 * pr, (2 * pr + 1 < t.slots) ? 3 : 1, lane, true, N);
+      for (int pr = wave_u; 2 * pr < t.slots; pr += n_waves) {
+        pair_scan<true, true>(m, c, s, 2 * pr, (2 * pr + 1 < t.slots) ? 3 : 1, lane, true, N, rA);
+        rA += r_step;
+        if (rA >= N) rA -= N;
+      }
     } else {
-      for (int pr = wave_u; 2 * pr < t.slots; pr += n_waves) pair_scan<true, false>(m, c, s, 2 * pr, (2 * pr + 1 < t.slots) ? 3 : 1, lane, true, N);
+      for (int pr = wave_u; 2 * pr < t.slots; pr += n_waves) {
+        pair_scan<true, false>(m, c, s, 2 * pr, (2 * pr + 1 < t.slots) ? 3 : 1, lane, true, N, rA);
+        rA += r_step;
+        if (rA >= N) rA -= N;
+      }
     }
   } else {
     for (int sl = wave; sl < t.slots; sl += n_waves) {
