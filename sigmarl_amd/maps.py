@@ -2,7 +2,8 @@
 
 The tables under ``assets/maps/*.npz`` are the OUTPUT of the reference's map parsers
 (``sigmarl/map_manager.py:13-40`` -> ``parse_xml.py`` / ``parse_osm.py``), dumped by
-``tests/golden/gen/gen_maps.py``.  An own parser for ``cpm.xml`` / ``*.osm`` is SURVEY.md section 8(f) rank 2.
+``tests/golden/gen/gen_maps.py``.  ``sigmarl_amd.mapc`` is the package's own compiler for ``*.osm`` lanelet maps (same polylines
+bit for bit, ``tests/test_mapc.py``); pass its result as ``MapTable(name, table=...)``.  The CPM map (``cpm.xml``) ships as a table.
 
 Path lists (``list_id``): 0 = ``parser.reference_paths``; for the CPM map 1/2/3 =
 ``reference_paths_intersection`` / ``_merge_in`` / ``_merge_out`` (``world_state_rt_sim.py:313-358`` selects by
@@ -21,11 +22,18 @@ ASSET_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets", "
 
 
 class MapTable:
-    def __init__(self, scenario_type: str):
-        path = os.path.join(ASSET_DIR, f"{scenario_type}.npz")
-        if not os.path.exists(path):
-            raise FileNotFoundError(f"no map table for scenario_type={scenario_type!r} ({path})")
-        z = np.load(path)
+    def __init__(self, scenario_type: str, table: dict | None = None):
+        """``table``: a compiled table (``sigmarl_amd.mapc.compile_osm`` / ``compile_scenario``) instead of the shipped ``.npz``."""
+        if table is not None:
+            z = dict(table)
+            z.setdefault("lane_width", z.get("parser_lane_width", 0.25))
+            z.setdefault("default_n_agents", 1)
+            z.setdefault("n_lanelets_all", int(np.max(z["lanelet_ids"])) + 1)
+        else:
+            path = os.path.join(ASSET_DIR, f"{scenario_type}.npz")
+            if not os.path.exists(path):
+                raise FileNotFoundError(f"no map table for scenario_type={scenario_type!r} ({path})")
+            z = np.load(path)
         self.scenario_type = scenario_type
         self.n_paths = int(z["center"].shape[0])
         stride = max(z["center"].shape[1], z["left"].shape[1], z["right"].shape[1])

@@ -405,3 +405,32 @@ def test_sixty_four_agents_one_env_per_workgroup():
         _compare_all(dev, ora, f"N=64 fused step {t}")
     dev.close()
     ora.close()
+
+
+def test_compiled_custom_map_runs_through_both_paths():
+    """A table compiled by sigmarl_amd.mapc (not one of the shipped reference-parser outputs) drives the HIP path and the oracle:
+    interchange_2 compiled with a different lane width (boundaries and coordinates shift), seeded episode with device-side resets."""
+    from sigmarl_amd import mapc
+    from sigmarl_amd.maps import MapTable
+
+    mp = MapTable("interchange_2", table=mapc.compile_scenario("interchange_2", lane_width=0.3))
+    assert not np.array_equal(mp.left, load_map("interchange_2").left)
+    N, B = 4, 12
+    p = Parameters(n_agents=N, scenario_type="interchange_2", is_use_mtv_distance=False, rew_method="distance", dt=0.1, is_apply_mask=False,
+                   is_obs_noise=False, max_steps=8)
+    cfg = make_config(p, mp, B)
+    dev, ora = _hip_env(cfg, mp), ob.OracleEnv(cfg, mp)
+    dev.env.buffer(capi.BUF_DONE).fill_(1)
+    ora.get(capi.BUF_DONE, copy=False)[:] = 1
+    pf, pc = mp.list_first[0], mp.list_count[0]
+    dev.auto_reset(2, 0, pf, pc)
+    ora.auto_reset(2, 0, pf, pc)
+    rng = np.random.default_rng(5)
+    for t in range(10):
+        act = np.stack([rng.uniform(0.0, 1.2, (B, N)), rng.uniform(-0.5, 0.5, (B, N))], axis=-1).astype(np.float32)
+        dev.step_autoreset(act, 2, t + 1, pf, pc)
+        ora.step(act)
+        ora.auto_reset(2, t + 1, pf, pc)
+        _compare_all(dev, ora, f"compiled map step {t}")
+    dev.close()
+    ora.close()
