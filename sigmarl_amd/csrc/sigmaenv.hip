@@ -550,8 +550,8 @@ __device__ inline void observe_tile(const sigmaenv_config_t& c, const Smem& s, c
   // the 1e-5 bar; no mask or index depends on it.  The oracle keeps the reference's formulation.
   const int T1 = NS + 4 * K;
   for (int w = threadIdx.x; w < t.slots * T1; w += blockDim.x) {
-    int sl = w / T1, q = w - sl * T1;
-    int ebase = (sl / N) * N;
+    int sl = fdiv(w, g.mT1), q = w - sl * T1;
+    int ebase = fdiv(sl, g.mN) * N;
     const float* si = s.st + sl * 8;
     float tx, ty;
     int pos;
@@ -579,8 +579,8 @@ __device__ inline void observe_tile(const sigmaenv_config_t& c, const Smem& s, c
     const int w3 = (span - 1) - w0;  // the back of the span carries the third pass
     if (w0 < n2) {
       const int w = w0;
-      int sl = w / T2, q = w - sl * T2;
-      int ebase = (sl / N) * N;
+      int sl = fdiv(w, g.mT2), q = w - sl * T2;
+      int ebase = fdiv(sl, g.mN) * N;
       int sj = (q == 0) ? sl : (ebase + s.near[sl * K + (q - 1)]);
       const float* sjp = s.st + sj * 8;
       float va = norm2(sjp[5], sjp[6]);                      // :444
@@ -696,7 +696,7 @@ __global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigm
 #pragma unroll
     for (int k = 0; k < NS; ++k) spo[k] = gst[k];
     const int loop_flag = m.is_loop[pth];
-    const int4 tm = reinterpret_cast<const int4*>(g.timer)[t.env0 + sl / N];  // step count and counters of the env
+    const int4 tm = reinterpret_cast<const int4*>(g.timer)[t.env0 + fdiv(sl, g.mN)];  // step count and counters of the env
     st[0] = s0.x; st[1] = s0.y; st[2] = s0.z; st[3] = s0.w; st[4] = s1.x; st[5] = s1.y; st[6] = s1.z; st[7] = s1.w;
     bicycle_step(c, st, u.x, u.y, uc);
     TS(6);
@@ -740,7 +740,7 @@ __global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigm
   const int TP = N * (N - 1) / 2;
   const int n_pairs = t.nenv * TP;
   for (int sl = tid; sl < t.slots; sl += blockDim.x) {  // diagonal (helper_scenario.py:1140-1143)
-    const int i = sl % N;
+    const int i = sl - fdiv(sl, g.mN) * N;
     s.dist[sl * DIST_STRIDE(N) + i] = diag;
     g.dist_agents[(t.a0 + sl) * N + i] = diag;
     s.col[sl * COL_STRIDE(N) + i] = 0;
@@ -756,7 +756,7 @@ __global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigm
     int si = 0, sj = 0, i = 0, j = 0;
     bool near = false;
     if (in_range) {
-      const int e = p / TP;
+      const int e = fdiv(p, g.mTP);
       const unsigned ij = s.pidx[p - e * TP];
       i = (int)(ij & 0xFFu); j = (int)(ij >> 8);
       si = e * N + i; sj = e * N + j;
@@ -804,7 +804,8 @@ __global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigm
       const unsigned long long hb = __ballot(hit);
       if (src >= 0 && tt == 0) {
         const uint8_t col = ((hb >> (q * 16)) & 0xFFFFull) ? 1 : 0;
-        const int ja = b_sl - (a_sl / N) * N, jb = a_sl - (a_sl / N) * N;  // column of B in A's row and of A in B's row
+        const int ea = fdiv(a_sl, g.mN) * N;
+        const int ja = b_sl - ea, jb = a_sl - ea;  // column of B in A's row and of A in B's row
         s.col[a_sl * COL_STRIDE(N) + ja] = col;
         s.col[b_sl * COL_STRIDE(N) + jb] = col;
         g.col_agents[(t.a0 + a_sl) * N + ja] = col;
@@ -857,7 +858,7 @@ __global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigm
   if (wave == 0 && !(dbg_skip & 4)) {
     const bool act = tid < t.slots;
     const int sl = act ? tid : 0;
-    const int e = sl / N, i = sl - e * N;
+    const int e = fdiv(sl, g.mN), i = sl - e * N;
     const size_t gi = t.a0 + sl;
     const size_t BN = (size_t)c.n_envs * N;
     int col_a = 0, col_l = 0, goal = 0, entry = 0;
@@ -1019,7 +1020,7 @@ __global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigm
   if (g.slab) {  // rollout record of this step (observation AFTER the step, reward, done), one contiguous row per env
     const int ND = N * t.D, W = ND + N + 1;
     for (int k = tid; k < t.nenv * W; k += blockDim.x) {
-      int e = k / W, r = k - e * W;
+      int e = fdiv(k, g.mW), r = k - e * W;
       float v = (r < ND) ? s.obs[e * ND + r] : ((r < ND + N) ? s.rew[e * N + (r - ND)] : s.rew[G * N + e]);
       g.slab[(size_t)(t.env0 + e) * W + r] = v;
     }
@@ -1780,6 +1781,14 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
   ALLOC(g.reset_mask, (size_t)B * 8);
   ALLOC(g.reset_full, (size_t)B);
   g.slab = nullptr;
+  {
+    auto magic = [](unsigned d) { return d <= 1u ? 0u : (uint32_t)(((1ull << 32) + d - 1ull) / d); };
+    g.mN = magic((unsigned)N);
+    g.mT1 = magic((unsigned)(NS + 4 * K));
+    g.mT2 = magic((unsigned)(K + 1));
+    g.mTP = magic((unsigned)(N * (N - 1) / 2));
+    g.mW = magic((unsigned)(N * (h->D + 1) + 1));
+  }
   g.dbg_ts = nullptr;
   g.dbg_ts2 = nullptr;
   if (const char* e = getenv("SIGMAENV_TIMESTAMPS")) {

@@ -65,6 +65,9 @@ struct DevBufs {
   unsigned long long* reset_mask;  // [B] bit i: agent i needs its derived state rebuilt
   uint8_t* reset_full;             // [B] full-env reset pending
   float* slab;                     // optional rollout record of this step: [B][N*D obs | N reward | 1 done] fp32 (sigmaenv_set_slab)
+  // magic multipliers ceil(2^32 / d) for the divisors the kernels' index arithmetic divides by (fdiv below): agents per env, items per
+  // agent of the two observation passes, unordered pairs per env, floats per rollout record row
+  uint32_t mN, mT1, mT2, mTP, mW;
   unsigned long long* dbg_ts2;     // same for the auto-reset kernel (SIGMAENV_TIMESTAMPS=2)
   unsigned long long* dbg_ts;      // optional [grid][8] shader-clock timestamps at the phase boundaries (SIGMAENV_TIMESTAMPS=1)
 };
@@ -73,6 +76,9 @@ struct DevBufs {
 // accepts; halves the address-coalescer work of the scan compared with two 8-byte loads
 struct __attribute__((packed, aligned(8))) Seg4 { float ax, ay, bx, by; };
 __device__ __forceinline__ Seg4 load_segment(const float2* p, int k) { return *reinterpret_cast<const Seg4*>(p + k); }
+
+// x / d for x * d < 2^32 with m = ceil(2^32 / d) (d = 1: m wraps to 0): two instructions instead of the ~20 of a runtime division
+__device__ __forceinline__ int fdiv(int x, uint32_t m) { return m ? (int)__umulhi((uint32_t)x, m) : x; }
 
 // ---- scalar helpers ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float cr_sin(float x) { return (float)sin((double)x); }
