@@ -275,7 +275,7 @@ __device__ __forceinline__ void mask_stage2(const DevMap& m, const Smem& s, Mask
   const float dg = point_segment(px, py, mt.ax, mt.ay, glx, gly, glx * glx + gly * gly);
   float T = dg;
   if (pl != 0) {
-    const bool stale = stale_first && (sl % N == 0);
+    const bool stale = stale_first && (sl % N == 0);  // (only evaluated for the step kernel: N is a kernel-uniform divisor there)
     const float Rq = stale ? query_radius(s.vold + sl * 10, px, py) : m.rect_radius;
     T = fmaxf(T + 2.0f * Rq, COLLIDE ? m.rect_radius : 0.0f);
   }
@@ -535,13 +535,25 @@ __device__ inline void topk_nearest(const float* Drow, int N, int K, int* out) {
 //   2. relative velocities (self + observed neighbours): angle wrap + cos + sin each
 //   3. normalised distances
 // Rows are assembled in LDS and written out coalesced.  All threads of the block participate.
-__device__ inline void observe_tile(const sigmaenv_config_t& c, const Smem& s, const DevBufs& g, const Tile& t, int ts_base = -1) {
+// env_sel / n_sel: restrict the work to these envs of the tile (the reset tail only refreshes the envs it touched); the loops then run
+// over "virtual" slots v = (position in env_sel) * N + agent, so that the lanes stay densely used.
+__device__ inline void observe_tile(const sigmaenv_config_t& c, const Smem& s, const DevBufs& g, const Tile& t, int ts_base = -1,
+                                    const int* env_sel = nullptr, int n_sel = 0) {
   const int N = t.N, K = t.K, D = t.D;
+  const int n_slots = env_sel ? n_sel * N : t.slots;
+  auto real_slot = [&](int v) {
+    if (!env_sel) return v;
+    const int q = fdiv(v, g.mN);
+    return env_sel[q] * N + (v - q * N);
+  };
 #define TSO(k) do { if (ts_base >= 0 && g.dbg_ts && threadIdx.x == 0) g.dbg_ts[(size_t)blockIdx.x * 16 + ts_base + (k)] = __builtin_readcyclecounter(); } while (0)
   const float n_pos = (float)((double)c.length * 10.0);   // normalizers.pos, road_traffic.py:588-592
   const float n_v = c.max_speed;                            // :596
   const float n_dl = (float)((double)c.lane_width * 3.0);   // :599-601 (distance_lanelet also normalises the agent distances)
-  for (int sl = threadIdx.x; sl < t.slots; sl += blockDim.x) topk_nearest(s.dist + sl * DIST_STRIDE(N), N, K, s.near + sl * K);
+  for (int v = threadIdx.x; v < n_slots; v += blockDim.x) {
+    const int sl = real_slot(v);
+    topk_nearest(s.dist + sl * DIST_STRIDE(N), N, K, s.near + sl * K);
+  }
   TSO(0);
   __syncthreads();
   TSO(1);
@@ -549,8 +561,9 @@ __device__ inline void observe_tile(const sigmaenv_config_t& c, const Smem& s, c
   // agent's cos(psi), sin(psi) (already needed for the vertices): rel = R(-psi_i) (p_j - p_i).  Identical up to ~1e-7, well inside
   // the 1e-5 bar; no mask or index depends on it.  The oracle keeps the reference's formulation.
   const int T1 = NS + 4 * K;
-  for (int w = threadIdx.x; w < t.slots * T1; w += blockDim.x) {
-    int sl = fdiv(w, g.mT1), q = w - sl * T1;
+  for (int w = threadIdx.x; w < n_slots * T1; w += blockDim.x) {
+    const int v = fdiv(w, g.mT1), q = w - v * T1;
+    const int sl = real_slot(v);
     int ebase = fdiv(sl, g.mN) * N;
     const float* si = s.st + sl * 8;
     float tx, ty;
@@ -573,13 +586,14 @@ __device__ inline void observe_tile(const sigmaenv_config_t& c, const Smem& s, c
   // relative velocities (one lane per (agent, self or observed neighbour)) from the front of the block, the per-agent distances
   // from its back, so that both run at the same time when the block is wide enough
   const int T2 = K + 1;
-  const int n2 = t.slots * T2, n3 = t.slots;
+  const int n2 = n_slots * T2, n3 = n_slots;
   const int span = max(n2 + n3, (int)blockDim.x);
   for (int w0 = threadIdx.x; w0 < span; w0 += blockDim.x) {
     const int w3 = (span - 1) - w0;  // the back of the span carries the third pass
     if (w0 < n2) {
       const int w = w0;
-      int sl = fdiv(w, g.mT2), q = w - sl * T2;
+      const int v = fdiv(w, g.mT2), q = w - v * T2;
+      const int sl = real_slot(v);
       int ebase = fdiv(sl, g.mN) * N;
       int sj = (q == 0) ? sl : (ebase + s.near[sl * K + (q - 1)]);
       const float* sjp = s.st + sj * 8;
@@ -594,7 +608,7 @@ __device__ inline void observe_tile(const sigmaenv_config_t& c, const Smem& s, c
         s.obs[sl * D + base + 9] = (va * sr) / n_v;
       }
     } else if (w3 < n3) {
-      const int sl = w3;
+      const int sl = real_slot(w3);
       float ml = INFINITY, mr = INFINITY;
 #pragma unroll
       for (int q = 0; q < 5; ++q) { ml = fminf(ml, s.dleft[sl * 5 + q]); mr = fminf(mr, s.dright[sl * 5 + q]); }
@@ -607,14 +621,23 @@ __device__ inline void observe_tile(const sigmaenv_config_t& c, const Smem& s, c
   TSO(3);
   __syncthreads();
   TSO(4);
-  if ((D & 3) == 0) {  // rows are whole float4s: both the LDS staging area and the tile's slice of g.obs are 16-byte aligned
-    const float4* so4 = reinterpret_cast<const float4*>(s.obs);
-    float4* go4 = reinterpret_cast<float4*>(g.obs + t.a0 * D);
-    for (int k = threadIdx.x; k < t.slots * D / 4; k += blockDim.x) go4[k] = so4[k];
+  if (env_sel) {  // only the rows of the selected envs (they are contiguous per env)
+    const int ND = N * D, NK = N * K;
+    for (int q = 0; q < n_sel; ++q) {
+      const int e = env_sel[q];
+      for (int k = threadIdx.x; k < ND; k += blockDim.x) g.obs[(t.a0 + e * N) * D + k] = s.obs[e * ND + k];
+      for (int k = threadIdx.x; k < NK; k += blockDim.x) g.nearing[(t.a0 + e * N) * K + k] = s.near[e * NK + k];
+    }
   } else {
-    for (int k = threadIdx.x; k < t.slots * D; k += blockDim.x) g.obs[t.a0 * D + k] = s.obs[k];
+    if ((D & 3) == 0) {  // rows are whole float4s: both the LDS staging area and the tile's slice of g.obs are 16-byte aligned
+      const float4* so4 = reinterpret_cast<const float4*>(s.obs);
+      float4* go4 = reinterpret_cast<float4*>(g.obs + t.a0 * D);
+      for (int k = threadIdx.x; k < t.slots * D / 4; k += blockDim.x) go4[k] = so4[k];
+    } else {
+      for (int k = threadIdx.x; k < t.slots * D; k += blockDim.x) g.obs[t.a0 * D + k] = s.obs[k];
+    }
+    for (int k = threadIdx.x; k < t.slots * K; k += blockDim.x) g.nearing[t.a0 * K + k] = s.near[k];
   }
-  for (int k = threadIdx.x; k < t.slots * K; k += blockDim.x) g.nearing[t.a0 * K + k] = s.near[k];
   TSO(5);
 #undef TSO
 }
@@ -1177,8 +1200,8 @@ __device__ inline void reset_finish_body(const sigmaenv_config_t& c, const DevBu
 #define TS2(k) do { if (g.dbg_ts2 && tid == 0) g.dbg_ts2[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
   const float diag = sqrtf(c.world_x_dim * c.world_x_dim + c.world_y_dim * c.world_y_dim);
   for (int p = tid; p < t.slots * N; p += blockDim.x) {
-    int si = p / N, j = p - si * N;
-    int e = si / N;
+    int si = fdiv(p, g.mN), j = p - si * N;
+    int e = fdiv(si, g.mN);
     if (agent_mask[e] == 0ull) continue;
     int sj = e * N + j;
     float d = (si == sj) ? diag : pair_distance(c, s.st, s.vnew, si, sj);
@@ -1204,9 +1227,20 @@ __device__ inline void reset_finish_body(const sigmaenv_config_t& c, const DevBu
     __threadfence_block();
     __syncthreads();
     TS2(5);
-    // with every agent of the tile marked (device-side full-env reset) all inputs of the observation are already in LDS
-    if (with_obs != 2) load_tile_for_observation(s, g, t);
-    observe_tile(c, s, g, t);
+    if (with_obs == 2) {
+      // every input of the observation is in LDS (fused tail / a tile whose envs were all reset): only the touched envs' rows change
+      int* env_sel = const_cast<int*>(full) + MAX_G + 2;  // after s_full, s_any and the step kernel's pair counter
+      if (tid == 0) {
+        int cnt = 0;
+        for (int e = 0; e < t.nenv; ++e) if (agent_mask[e]) env_sel[1 + cnt++] = e;
+        env_sel[0] = cnt;
+      }
+      __syncthreads();
+      observe_tile(c, s, g, t, -1, env_sel + 1, env_sel[0]);
+    } else {
+      load_tile_for_observation(s, g, t);
+      observe_tile(c, s, g, t);
+    }
     TS2(6);
   }
 #undef TS2
@@ -1819,7 +1853,7 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
     int v = atoi(e);
     if (v >= 64 && v <= 512 && v % 64 == 0) h->reset_block = v;
   }
-  h->smem_bytes = ((Smem::bytes(h->G * N, N, K, h->D) + 15) & ~(size_t)15) + MAX_G * 8 + MAX_G * 4 + 16;
+  h->smem_bytes = ((Smem::bytes(h->G * N, N, K, h->D) + 15) & ~(size_t)15) + MAX_G * 8 + MAX_G * 4 + 16 + (MAX_G + 1) * 4;  // masks, flags, counters, env list
   if (h->smem_bytes > 64 * 1024) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem_bytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_observe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem_bytes);
