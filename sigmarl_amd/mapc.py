@@ -1,10 +1,11 @@
-"""Map compiler: OSM lanelet maps -> the reference-path tables the environment step consumes.
+"""Map compiler: lanelet maps -> the reference-path tables the environment step consumes.
 
-Replaces, for the ``*.osm`` scenarios, the reference's ``ParseOSM`` (``sigmarl/parse_osm.py:37-336``) + the part of
-``MapManager`` the scenario uses (``sigmarl/map_manager.py:13-40``): the product no longer needs the reference's parser OUTPUT
-for such a map, only the map itself (an ``.osm`` file in JOSM's format, or the node / way lists extracted from one) and the
-scenario's specification (lane width, scale, lanelet id lists of the reference paths -- ``sigmarl/constants.py:SCENARIOS``, shipped
-as ``assets/maps/scenarios.json``).
+Replaces the reference's ``ParseOSM`` (``sigmarl/parse_osm.py:37-336``, the 16 JOSM ``*.osm`` scenarios) and ``ParseXML``
+(``sigmarl/parse_xml.py:24-907``, the CPM lab's CommonRoad map) + the part of ``MapManager`` the scenario uses
+(``sigmarl/map_manager.py:13-40``): the product no longer needs the reference's parser OUTPUT for a map, only the map itself (the file,
+or the point lists extracted from one) and the scenario's specification (lane width, scale, lanelet id lists of the reference paths,
+groups of lanelets sharing their outer boundaries -- ``sigmarl/constants.py:SCENARIOS`` and the tables in ``parse_xml.py``, shipped as
+``assets/maps/scenarios.json``).
 
 The arithmetic follows the reference's tensor code one fp32 operation at a time, so the compiled polylines are BIT-IDENTICAL to the
 tables the reference's parser produced (``tests/test_mapc.py`` checks every shipped OSM scenario); the centre-line yaw goes through
@@ -165,11 +166,125 @@ def _pack(paths: List[dict], parser_lane_width: float) -> dict:
     return out
 
 
+# ---- CPM map (CommonRoad XML lanelets), parse_xml.py ---------------------------------------------------------------------------------
+@dataclass
+class LaneletSource:
+    """Left / right bound points of every lanelet of a CommonRoad XML map as parsed (float64); lanelet ids start at 1."""
+    lanelet_id: np.ndarray  # [L] int32
+    left_off: np.ndarray    # [L + 1]
+    right_off: np.ndarray   # [L + 1]
+    left: np.ndarray        # [*, 2] float64
+    right: np.ndarray       # [*, 2] float64
+
+
+def read_commonroad_xml(path: str) -> LaneletSource:
+    root = ET.parse(path).getroot()
+    ids, off_l, off_r, pl, pr = [], [0], [0], [], []
+    for child in root:
+        if child.tag != "lanelet":
+            continue
+        ids.append(int(child.get("id")))
+        for tag, pts, off in (("leftBound", pl, off_l), ("rightBound", pr, off_r)):
+            for point in child.find(tag).findall("point"):
+                pts.append((float(point.find("x").text), float(point.find("y").text)))
+            off.append(len(pts))
+    return LaneletSource(np.array(ids, np.int32), np.array(off_l, np.int64), np.array(off_r, np.int64), np.array(pl, np.float64).reshape(-1, 2),
+                         np.array(pr, np.float64).reshape(-1, 2))
+
+
+def load_lanelet_source(name: str = "cpm") -> LaneletSource:
+    d = np.load(os.path.join(_ASSETS, "src", name + ".npz"))
+    return LaneletSource(d["lanelet_id"], d["left_off"], d["right_off"], d["left"], d["right"])
+
+
+def _dist2(a: np.ndarray, b: np.ndarray) -> np.float32:
+    d = (a - b).astype(f32)
+    return _norm2(d[0], d[1])
+
+
+def _linspace01(steps: int) -> np.ndarray:
+    """``torch.linspace(0, 1, steps)`` in fp32: the first half counts up from the start, the second half down from the end."""
+    step = f32(f32(1) - f32(0)) / f32(steps - 1)
+    half = steps // 2
+    return np.array([f32(0) + step * f32(i) if i < half else f32(1) - step * f32(steps - 1 - i) for i in range(steps)], f32)
+
+
+def _lerp_block(start: np.ndarray, end: np.ndarray, overlap: int) -> np.ndarray:
+    t = _linspace01(2 * overlap)[:, None]
+    return ((f32(1) - t).astype(f32) * start[None, :]).astype(f32) + (t * end[None, :]).astype(f32)  # (1 - t) * start + t * end
+
+
+def _smooth_concatenate(a: np.ndarray, b: np.ndarray, overlap: int = 4) -> np.ndarray:
+    """``ParseXML.smooth_concatenate`` (parse_xml.py:832-871): the last `overlap` points of a and the first `overlap` points of b are
+    replaced by a straight interpolation between a[-overlap] and b[overlap - 1]."""
+    return np.concatenate([a[:-overlap], _lerp_block(a[-overlap], b[overlap - 1], overlap).astype(f32), b[overlap:]], axis=0)
+
+
+def _smooth_loop_boundary(bd: np.ndarray, overlap: int = 4) -> np.ndarray:
+    """``ParseXML.smooth_loop_boundary`` (parse_xml.py:873-907), incl. the closing point appended at the end."""
+    inter = _lerp_block(bd[-overlap], bd[overlap - 1], overlap).astype(f32)
+    out = bd.copy()
+    out[:overlap] = inter[overlap:]
+    out[-overlap:] = inter[:overlap]
+    return np.concatenate([out, out[:1]], axis=0)
+
+
+def compile_lanelet_paths(src: LaneletSource, paths: List[List[int]], list_id: List[int], shared_groups: List[List[int]]) -> dict:
+    """Reference paths of a CommonRoad lanelet map (``ParseXML._get_reference_path``, parse_xml.py:605-797): per path the lanelets'
+    own boundaries are chained (a repeated connection point is dropped), the centre line is their mean, and the SHARED boundaries --
+    left bound of the leftmost and right bound of the rightmost lanelet of the road the lanelet belongs to -- are chained with a
+    smoothed transition where they do not connect, and smoothed across the seam of a loop."""
+    lane = {}
+    for k, lid in enumerate(src.lanelet_id):
+        lane[int(lid)] = (src.left[src.left_off[k]: src.left_off[k + 1]].astype(f32), src.right[src.right_off[k]: src.right_off[k + 1]].astype(f32))
+    TH = f32(1e-4)
+    out_paths = []
+    for ids in paths:
+        lb = rb = lbs = rbs = None
+        for lid in ids:
+            grp = next(g for g in shared_groups if lid in g)
+            l, r = lane[lid]
+            ls, rs = lane[grp[0]][0], lane[grp[-1]][1]
+            if lb is None:
+                lb, rb, lbs, rbs = l, r, ls, rs
+                continue
+            lb = np.concatenate([lb, l[1:] if _dist2(lb[-1], l[0]) < TH else l], axis=0)
+            lbs = np.concatenate([lbs, ls[1:]], axis=0) if _dist2(lbs[-1], ls[0]) < TH else _smooth_concatenate(lbs, ls)
+            rb = np.concatenate([rb, r[1:] if _dist2(rb[-1], r[0]) < TH else r], axis=0)
+            rbs = np.concatenate([rbs, rs[1:]], axis=0) if _dist2(rbs[-1], rs[0]) < TH else _smooth_concatenate(rbs, rs)
+        center = ((lb + rb).astype(f32) / f32(2)).astype(f32)
+        is_loop = bool(_dist2(center[0], center[-1]) <= TH)
+        if is_loop:
+            if _dist2(lbs[0], lbs[-1]) > f32(0.1):
+                lbs = _smooth_loop_boundary(lbs)
+            if _dist2(rbs[0], rbs[-1]) > f32(0.1):
+                rbs = _smooth_loop_boundary(rbs)
+        out_paths.append({"center": center, "yaw": _yaw(center), "left": lbs.astype(f32), "right": rbs.astype(f32), "is_loop": is_loop,
+                          "lanelet_ids": list(ids)})
+    out = _pack(out_paths, 0.0)
+    out["list_id"] = np.array(list_id, np.int32)
+    local = np.zeros(len(paths), np.int32)
+    seen: Dict[int, int] = {}
+    for i, li in enumerate(list_id):
+        local[i] = seen.get(li, 0)
+        seen[li] = local[i] + 1
+    out["local_id"] = local
+    return out
+
+
 def compile_scenario(scenario_type: str, lane_width: float = 0.25, osm_path: Optional[str] = None) -> dict:
     """Compile one of the named scenarios (``assets/maps/scenarios.json``) from its shipped node / way lists, or from ``osm_path``."""
     spec = scenario_specs()[scenario_type]
-    if not spec["map_path"].endswith(".osm"):
-        raise NotImplementedError(f"{scenario_type}: only OSM lanelet maps are compiled here; the CPM map ships as a table (assets/maps/{scenario_type}.npz)")
+    if not spec["map_path"].endswith(".osm"):  # the CPM map: CommonRoad XML; the world size is fixed by the lab (parse_xml.py:51-58)
+        src = read_commonroad_xml(osm_path) if osm_path else load_lanelet_source("cpm")
+        out = compile_lanelet_paths(src, spec["paths"], spec["list_id"], spec["shared_boundary_groups"])
+        out["world_x_dim"] = np.float64(spec["x_dim_min"] + spec["x_dim_max"])
+        out["world_y_dim"] = np.float64(spec["y_dim_min"] + spec["y_dim_max"])
+        out["parser_lane_width"] = np.float64(lane_width)
+        out["lane_width"] = np.float64(spec["lane_width"])
+        out["default_n_agents"] = np.int32(spec["n_agents"])
+        out["n_lanelets_all"] = np.int32(len(src.lanelet_id))
+        return out
     src = read_osm(osm_path) if osm_path else load_source(scenario_type)
     out = compile_osm(src, spec["reference_paths_ids"], lane_width, float(spec["scale"]))
     out["lane_width"] = np.float64(spec["lane_width"])

@@ -61,3 +61,48 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+# Lanelets of the CPM map that share their outer boundaries (adjacent lanes of one road; first entry = leftmost lane, last entry =
+# rightmost lane): map metadata of the reference's CPM parser (parse_xml.py:417-466), needed for the "shared" boundaries.
+CPM_SHARED_BOUNDARY_GROUPS = [
+    [4, 3, 22], [6, 5, 23], [8, 7], [60, 59], [58, 57, 75], [56, 55, 74], [54, 53], [80, 79], [82, 81, 100], [84, 83, 101], [86, 85],
+    [34, 33], [32, 31, 49], [30, 29, 48], [28, 27], [2, 1],
+    [13, 14], [15, 16], [9, 10], [11, 12], [63, 64], [61, 62], [67, 68], [65, 66], [91, 92], [93, 94], [87, 88], [89, 90],
+    [37, 38], [35, 36], [41, 42], [39, 40],
+    [25, 18], [26, 17], [52, 43], [72, 73], [51, 44], [50, 45], [102, 97], [20, 21], [103, 96], [104, 95], [78, 69], [46, 47],
+    [77, 70], [76, 71], [24, 19], [98, 99],
+]
+
+
+def cpm_sources():
+    """The CPM map (CommonRoad XML): left / right bound points of every lanelet as parsed (float64), plus the lanelet sequences of the
+    72 reference paths as the reference's parser lists them (read back from its OUTPUT, assets/maps/cpm_entire.npz: `lanelet_IDs`)."""
+    root = ET.parse(os.path.join(REF_MAPS, "cpm.xml")).getroot()
+    ids, off_l, off_r, pl, pr = [], [0], [0], [], []
+    for child in root:
+        if child.tag != "lanelet":
+            continue
+        ids.append(int(child.get("id")))
+        for tag, pts, off in (("leftBound", pl, off_l), ("rightBound", pr, off_r)):
+            b = child.find(tag)
+            for point in b.findall("point"):
+                pts.append((float(point.find("x").text), float(point.find("y").text)))
+            off.append(len(pts))
+    np.savez_compressed(os.path.join(OUT, "src", "cpm.npz"), lanelet_id=np.array(ids, np.int32), left_off=np.array(off_l, np.int64),
+                        right_off=np.array(off_r, np.int64), left=np.array(pl, np.float64), right=np.array(pr, np.float64))
+    tab = np.load(os.path.join(OUT, "cpm_entire.npz"))
+    paths = [[int(v) for v in tab["lanelet_ids"][i, : tab["n_lanelet_ids"][i]]] for i in range(tab["lanelet_ids"].shape[0])]
+    with open(os.path.join(OUT, "scenarios.json")) as f:
+        specs = json.load(f)
+    for name in ("cpm_entire", "cpm_mixed"):
+        specs[name]["paths"] = paths
+        specs[name]["list_id"] = [int(v) for v in tab["list_id"]]
+        specs[name]["shared_boundary_groups"] = CPM_SHARED_BOUNDARY_GROUPS
+    with open(os.path.join(OUT, "scenarios.json"), "w") as f:
+        json.dump(specs, f, indent=1, sort_keys=True)
+    print("cpm:", len(ids), "lanelets,", len(paths), "paths")
+
+
+if __name__ == "__main__":
+    cpm_sources()

@@ -8,6 +8,7 @@ from sigmarl_amd import mapc
 from sigmarl_amd.maps import MapTable
 
 OSM_SCENARIOS = sorted(k for k, v in mapc.scenario_specs().items() if v["map_path"].endswith(".osm"))
+ALL_SCENARIOS = sorted(mapc.scenario_specs())
 EXACT = ("center", "left", "right", "n_center", "n_left", "n_right", "n_yaw", "is_loop", "lanelet_ids", "n_lanelet_ids", "list_id", "local_id")
 
 
@@ -15,10 +16,11 @@ def _ulp_diff(a, b):
     return np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64))
 
 
-@pytest.mark.parametrize("scen", OSM_SCENARIOS)
+@pytest.mark.parametrize("scen", ALL_SCENARIOS)
 def test_compiled_table_equals_reference_parser_output(scen):
-    """Polylines, counts, loop flags, lanelet ids and world size bit-identical to ParseOSM's output (assets/maps/<scen>.npz, written by
-    tests/golden/gen/gen_maps.py from the reference); yaw within 1 ulp (correctly rounded atan2 here, SLEEF in the reference)."""
+    """Polylines (incl. the CPM map's smoothed shared boundaries), counts, loop flags, lanelet ids, path lists and world size
+    bit-identical to ParseOSM's / ParseXML's output (assets/maps/<scen>.npz, written by tests/golden/gen/gen_maps.py from the
+    reference); yaw within 1 ulp (correctly rounded atan2 here, SLEEF in the reference)."""
     out = mapc.compile_scenario(scen, lane_width=0.25)
     ref = np.load(os.path.join(os.path.dirname(mapc.__file__), "assets", "maps", scen + ".npz"))
     for k in EXACT:
@@ -26,8 +28,9 @@ def test_compiled_table_equals_reference_parser_output(scen):
     assert _ulp_diff(out["yaw"], ref["yaw"]).max() <= 1
     assert float(out["world_x_dim"]) == float(ref["world_x_dim"]) and float(out["world_y_dim"]) == float(ref["world_y_dim"])
     assert float(out["lane_width"]) == float(ref["lane_width"]) and int(out["default_n_agents"]) == int(ref["default_n_agents"])
+    assert int(out["n_lanelets_all"]) == int(ref["n_lanelets_all"]) if "n_lanelets_all" in out else True
     mt = MapTable(scen, table=out)   # and it is accepted where the shipped table is
-    assert mt.n_paths == ref["center"].shape[0] and mt.list_count[0] == mt.n_paths
+    assert mt.n_paths == ref["center"].shape[0] and sum(mt.list_count.values()) == mt.n_paths
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/sigmarl/scenarios/assets/maps"), reason="raw .osm files only exist next to the reference")
@@ -73,3 +76,11 @@ def test_hand_made_map(tmp_path):
     np.testing.assert_allclose(t["left"][0, 2:4] - c[2:4], [[-w / 2, 0]] * 2, atol=1e-6)
     np.testing.assert_allclose(t["yaw"][0, :3], [0, 0, np.pi / 2], atol=1e-6)
     assert abs(float(t["world_x_dim"]) - ((4 + m + w / 2) + m)) < 1e-4  # max x (right boundary of the vertical leg) + min x
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/sigmarl/scenarios/assets/maps/cpm.xml"), reason="cpm.xml only exists next to the reference")
+def test_commonroad_reader_matches_the_extracted_source():
+    raw = mapc.read_commonroad_xml("/root/reference/sigmarl/scenarios/assets/maps/cpm.xml")
+    src = mapc.load_lanelet_source("cpm")
+    for f in ("lanelet_id", "left_off", "right_off", "left", "right"):
+        assert np.array_equal(getattr(raw, f), getattr(src, f)), f
