@@ -89,6 +89,10 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="diagnostic: no rollout record (and no gather to the learner rank for N > 1)")
     ap.add_argument("--streams", type=int, default=2, help="env shards per GPU, each stepped by its own handle on its own HIP stream "
                     "(envs are independent: same total work per step, the shards' latency-bound phases overlap the others' scan)")
+    ap.add_argument("--exchange", choices=["alltoall", "gather"], default="alltoall",
+                    help="N > 1: how the rollout buffer is concatenated.  alltoall: distributed over the ranks by time slices (every rank "
+                         "receives 1/N of the steps of ALL envs -- a data-parallel learner; the record crosses xGMI once, over all links); "
+                         "gather: everything to rank 0 (the 7 links into one GPU bound the rate)")
     ap.add_argument("--chunk-steps", type=int, default=32, help="steps per rollout chunk gathered to the learner rank (N > 1)")
     ap.add_argument("--force-dist", action="store_true", help="diagnostic: init RCCL and run the gather even with one rank")
     args = ap.parse_args()
@@ -152,7 +156,8 @@ def main():
     gather_note = "disabled by --no-gather"
     if not args.no_gather:
         try:  # the rollout exchange must never take the benchmark down: fall back to "no gather" and say so in the JSON line
-            gather = RolloutExchange(B, N, env.D, args.chunk_steps, device, force_collective=args.force_dist)
+            ex_mode = args.exchange if args.chunk_steps % max(1, world) == 0 else "gather"
+            gather = RolloutExchange(B, N, env.D, args.chunk_steps, device, force_collective=args.force_dist, mode=ex_mode)
             slot0 = gather.slot()
             for k, e in enumerate(envs):
                 e.set_slab(slot0[k * Bs:(k + 1) * Bs])
@@ -165,7 +170,9 @@ def main():
             for k, e in enumerate(envs):
                 e.auto_reset(seed=seed * 64 + k, counter=0, path_first=env.map.list_first[0], path_count=env.map.list_count[0])
             gather_note = (f"step kernel records (obs, reward, done) into a [{args.chunk_steps}, B, {N * (env.D + 1) + 1}] chunk buffer"
-                           + ("; one async gather per chunk to rank 0, double buffered" if gather.collective else " (single GPU: no exchange)"))
+                           + ((f"; one async all-to-all per chunk (rank r receives steps [r T/N, (r+1) T/N) of every rank's chunk), double buffered"
+                               if gather.mode == "alltoall" else "; one async gather per chunk to rank 0, double buffered")
+                              if gather.collective else " (single GPU: no exchange)"))
         except Exception as exc:  # noqa: BLE001
             gather = None
             for e in envs:
@@ -278,7 +285,7 @@ def main():
         "config": {
             "workload": f"cpm_entire map, {N} agents x {B} envs per GPU ({B * world} envs total), {args.distance} distance, rew_method=distance, "
                         f"dt=0.05, obs_dim={env.D}, fused step + device-side reset of finished envs "
-                        + ("(one launch)" if fused else "(two launches)" if not args.no_reset else "(resets disabled)") + ((" + rollout record" + (" + gather" if gather.collective else "")) if gather else ""),
+                        + ("(one launch)" if fused else "(two launches)" if not args.no_reset else "(resets disabled)") + ((" + rollout record" + ((" + " + gather.mode) if gather.collective else "")) if gather else ""),
             "n_agents": N, "envs_per_gpu": B, "envs_total": B * world, "distance": args.distance, "env_shards_per_gpu": S,
             "resets_per_step_per_gpu": dones / max(1, args.steps), "rollout_gather": gather_state["note"] or gather_note,
         },

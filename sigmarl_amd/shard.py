@@ -48,10 +48,19 @@ def unpack_slab(slab: torch.Tensor, N: int, D: int):
 
 
 class RolloutExchange:
-    """Double-buffered rollout chunks ``[T, B, W]`` + one asynchronous gather per chunk to ``dst`` (the learner rank)."""
+    """Double-buffered rollout chunks ``[T, B, W]`` + one asynchronous collective per chunk.
+
+    mode "gather":   the chunk of every rank goes to ``dst`` (ONE learner rank holds the concatenated buffer).  The learner's 7 links
+                     take the whole node's record: at 145 GB/s per producing rank (0.06 ms per step) they are the bottleneck.
+    mode "alltoall": the concatenated buffer is distributed over the ranks BY TIME SLICES (a data-parallel learner: rank r receives
+                     steps [r T/W, (r+1) T/W) of every rank's chunk, i.e. ALL envs of the node for 1/W of the steps).  The same
+                     bytes cross xGMI once, but over all 56 directed links instead of the 7 into one GPU."""
 
     def __init__(self, local_envs: int, n_agents: int, obs_dim: int, chunk_steps: int, device, dst: int = 0, group=None,
-                 force_collective: bool = False):
+                 force_collective: bool = False, mode: str = "gather"):
+        if mode not in ("gather", "alltoall"):
+            raise ValueError("mode must be 'gather' or 'alltoall'")
+        self.mode = mode
         self.group = group
         self.force = bool(force_collective)  # issue the collective even with one rank (exercises the RCCL path on a 1-GPU box)
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -62,7 +71,12 @@ class RolloutExchange:
         shape = (self.T, local_envs, slab_width(n_agents, obs_dim))
         self.chunks = [torch.empty(shape, dtype=torch.float32, device=device) for _ in range(2)]
         self.recv = None
-        if self.rank == dst and self.collective:
+        if self.collective and mode == "alltoall":
+            if self.T % self.world:
+                raise ValueError(f"alltoall exchange: chunk_steps ({self.T}) must be a multiple of the world size ({self.world})")
+            # [source rank, steps of my time slice, envs of the source rank, W]
+            self.recv = [torch.empty((self.world, self.T // self.world) + shape[1:], dtype=torch.float32, device=device) for _ in range(2)]
+        elif self.rank == dst and self.collective:
             self.recv = [[torch.empty(shape, dtype=torch.float32, device=device) for _ in range(self.world)] for _ in range(2)]
         self.pending = [None, None]
         self.cur, self.t = 0, 0
@@ -91,7 +105,9 @@ class RolloutExchange:
         if self.t == 0:
             return
         k = self.cur
-        if self.collective:
+        if self.collective and self.mode == "alltoall":
+            self.pending[k] = dist.all_to_all_single(self.recv[k].view(-1), self.chunks[k].view(-1), group=self.group, async_op=True)
+        elif self.collective:
             self.pending[k] = dist.gather(self.chunks[k], self.recv[k] if self.rank == self.dst else None, dst=self.dst, group=self.group,
                                           async_op=True)
         self.completed.append(k)
@@ -105,7 +121,17 @@ class RolloutExchange:
                 self.pending[k] = None
 
     def gathered(self, k):
-        """On the learner rank: per-rank chunk buffers ``[T, B_r, W]`` of buffer k (after ``wait_all``)."""
+        """mode "gather", on the learner rank: per-rank chunk buffers ``[T, B_r, W]`` of buffer k (after ``wait_all``)."""
         if not self.collective:
             return [self.chunks[k]]
+        if self.mode == "alltoall":
+            raise RuntimeError("alltoall exchange: use time_slice(k)")
         return self.recv[k] if self.rank == self.dst else None
+
+    def time_slice(self, k):
+        """mode "alltoall": this rank's share of buffer k (after ``wait_all``): ``[T / W, W * B, W_row]`` -- steps
+        ``[rank T/W, (rank+1) T/W)`` of the chunk for the envs of ALL ranks (ranks own contiguous env ranges, in rank order)."""
+        if not self.collective:
+            return self.chunks[k]
+        r = self.recv[k]  # [source rank, T / W, B, W_row]
+        return r.permute(1, 0, 2, 3).reshape(r.shape[1], r.shape[0] * r.shape[2], r.shape[3])

@@ -193,6 +193,24 @@ if rank == 0:
             assert np.array_equal(obs[q].numpy(), ref[t][0]) and np.array_equal(rew[q].numpy(), ref[t][1]) and np.array_equal(done[q].numpy(), ref[t][2])
             t += 1
     assert t == T
+# the same rollout through the all-to-all exchange: rank r ends up with steps [r T/W, (r+1) T/W) of the chunk for ALL envs
+env2 = make(b0, b1)
+full2 = make(0, TOTAL)
+ex2 = RolloutExchange(b1 - b0, N, env2.D, 2, "cpu", mode="alltoall")
+rng = np.random.default_rng(0)
+ref2 = []
+for t in range(2):
+    act = np.stack([rng.uniform(0, 1, (TOTAL, N)), rng.uniform(-0.2, 0.2, (TOTAL, N))], -1).astype(np.float32)
+    env2.step(act[b0:b1])
+    pack_slab(torch.from_numpy(env2.get(capi.BUF_OBS)), torch.from_numpy(env2.get(capi.BUF_REWARD)), torch.from_numpy(env2.get(capi.BUF_DONE)), out=ex2.slot())
+    ex2.advance()
+    full2.step(act)
+    ref2.append((full2.get(capi.BUF_OBS), full2.get(capi.BUF_REWARD), full2.get(capi.BUF_DONE).astype(bool)))
+ex2.wait_all()
+mine = ex2.time_slice(ex2.completed[0])          # [1, TOTAL, W]: step `rank` of the chunk, every env of both ranks
+obs, rew, done = unpack_slab(mine, N, env2.D)
+assert tuple(obs.shape[:2]) == (1, TOTAL)
+assert np.array_equal(obs[0].numpy(), ref2[rank][0]) and np.array_equal(rew[0].numpy(), ref2[rank][1]) and np.array_equal(done[0].numpy(), ref2[rank][2])
 dist.barrier()
 if rank == 0: print("SHARD_OK")
 dist.destroy_process_group()
