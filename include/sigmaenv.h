@@ -190,6 +190,31 @@ int sigmaenv_sync(sigmaenv_t* h);
  * since the previous call; n_launches receives the count.  Profiling aid for bench.py. */
 int sigmaenv_step_time_ms(sigmaenv_t* h, double* avg_ms, int32_t* n_launches);
 
+/* ---- policy in the loop ------------------------------------------------------------------------------
+ * The actor of sigmarl/modules/decision_making_module.py:34-82 (torchrl MultiAgentMLP: Linear(D,256) Tanh Linear(256,256) Tanh
+ * Linear(256,256) Tanh Linear(256,4), shared by all agents; NormalParamExtractor "biased_softplus_1.0"; TanhNormal between low and high)
+ * as one MFMA kernel (bf16 weights / activations, fp32 accumulate), so that a rollout of T steps runs without the host in the loop. */
+typedef struct sigmaenv_actor sigmaenv_actor_t;
+
+/* w_l / b_l: HOST pointers, torch.nn.Linear layout (w_l row-major [out, in], fp32); low / high: action bounds, 2 floats each
+ * (VMAS: -/+ u_range = max_speed, max_steering, helper_common.py:382-430). */
+int sigmaenv_actor_create(int32_t obs_dim, const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
+                          const float* w4, const float* b4, const float* low, const float* high, sigmaenv_actor_t** out);
+void sigmaenv_actor_destroy(sigmaenv_actor_t* a);
+
+/* actions := policy(observation) for every agent row.  obs: device f32 [B*N, obs_dim] or NULL for the handle's SIGMAENV_BUF_OBS;
+ * actions: device f32 [B,N,2]; log_prob (optional) device f32 [B,N]; loc_scale (optional) device f32 [B,N,4] = loc0, loc1, scale0,
+ * scale1.  deterministic != 0: action = squash(loc).  seed / counter select the counter-based random stream (draws 7000, 7001). */
+int sigmaenv_actor_forward(sigmaenv_t* h, sigmaenv_actor_t* a, const float* obs, float* actions, float* log_prob, float* loc_scale, uint64_t seed,
+                           uint64_t counter, int32_t deterministic);
+
+/* n_steps x (sigmaenv_actor_forward; sigmaenv_step_autoreset) enqueued back to back (SyncDataCollectorCustom.rollout,
+ * sigmarl/helper_training.py:687-788, without its per-step Python): actions_buf device f32 [B,N,2] scratch; optional records:
+ * slab_base device f32 [n_steps, B, N*(D+1)+1], logp_base device f32 [n_steps, B, N], actions_rec device f32 [n_steps, B, N, 2].
+ * Step t uses the random-stream counter counter0 + t for both the policy sample and the resets. */
+int sigmaenv_rollout(sigmaenv_t* h, sigmaenv_actor_t* a, int32_t n_steps, float* actions_buf, float* slab_base, float* logp_base, float* actions_rec,
+                     uint64_t seed, uint64_t counter0, int32_t path_first, int32_t path_count, int32_t deterministic);
+
 #ifdef __cplusplus
 }
 #endif

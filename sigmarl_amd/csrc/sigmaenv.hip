@@ -2032,3 +2032,4 @@ extern "C" int sigmaenv_step_time_ms(sigmaenv_t* h, double* avg_ms, int32_t* n_l
   return SIGMAENV_OK;
 }
 
+#include "sigmaenv_actor.inc"

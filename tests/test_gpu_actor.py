@@ -1,0 +1,130 @@
+"""The on-device actor (MFMA kernel) against torch.nn in fp32 and against a bf16-emulating restatement; rollouts without the host."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf16(a):
+    """round-to-nearest-even fp32 -> bf16 -> fp32 (numpy)"""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32)
+
+
+def _emulated(mlp, obs):
+    """What the kernel computes: bf16 inputs / weights / hidden activations, fp32 accumulation (the summation order inside the matrix
+    cores differs, hence the tolerance)."""
+    import torch
+    lin = [m for m in mlp.modules() if isinstance(m, torch.nn.Linear)]
+    x = _bf16(obs)
+    for k, m in enumerate(lin):
+        w, b = _bf16(m.weight.detach().numpy()), m.bias.detach().numpy().astype(np.float32)
+        x = (x.astype(np.float64) @ w.T.astype(np.float64) + b).astype(np.float32)
+        if k < 3:
+            x = _bf16(np.tanh(x))
+    return x
+
+
+def _setup(B=64, N=16, seed=0):
+    import torch
+    from sigmarl_amd.actor import Actor, make_mlp
+    from sigmarl_amd.env import SigmaEnv
+    from sigmarl_amd.params import Parameters
+
+    torch.manual_seed(seed)
+    env = SigmaEnv(Parameters(n_agents=N, scenario_type="cpm_entire", is_use_mtv_distance=False, is_apply_mask=False, is_obs_noise=False), n_envs=B,
+                   device="cuda:0")
+    env.reset_random(seed=3)
+    mlp = make_mlp(env.D)
+    with torch.no_grad():  # larger weights than the default init so that tanh saturates somewhere and the last layer matters
+        for m in mlp:
+            if isinstance(m, torch.nn.Linear):
+                m.weight.mul_(1.7)
+                m.bias.uniform_(-0.3, 0.3)
+    actor = Actor(mlp, low=[-1.0, -0.6], high=[1.0, 0.6])
+    return torch, env, mlp, actor
+
+
+def test_actor_matches_torch_and_the_bf16_restatement():
+    torch, env, mlp, actor = _setup(B=70, N=16)   # 1120 rows: not a multiple of the 256 rows of a workgroup
+    R = env.B * env.N
+    obs = (torch.rand((R, env.D), device="cuda") * 2 - 1) * 1.5
+    act = torch.zeros((env.B, env.N, 2), device="cuda")
+    ls = torch.zeros((env.B, env.N, 4), device="cuda")
+    lp = torch.zeros((env.B, env.N), device="cuda")
+    actor.forward(env, act, lp, ls, obs=obs, deterministic=True)
+    env.sync()
+    ls_h = ls.reshape(R, 4).cpu().numpy()
+    out_emul = _emulated(mlp, obs.cpu().numpy())
+    with torch.no_grad():
+        out_f32 = mlp(obs.cpu()).numpy()
+    bias = np.log(np.e - 1.0)
+    sp = lambda v: np.maximum(np.log1p(np.exp(v + bias)), 1e-4)  # noqa: E731
+    # loc and scale against the bf16-emulating restatement (tolerance: fp32 accumulation order + an occasional flipped bf16 rounding)
+    assert np.abs(ls_h[:, :2] - out_emul[:, :2]).max() <= 2e-2
+    assert np.abs(ls_h[:, 2:] - sp(out_emul[:, 2:])).max() <= 2e-2
+    assert np.abs(ls_h[:, :2] - out_emul[:, :2]).mean() <= 2e-3
+    # ... and against the fp32 network (bf16 inference error)
+    assert np.abs(ls_h[:, :2] - out_f32[:, :2]).max() <= 0.15 and np.abs(ls_h[:, :2] - out_f32[:, :2]).mean() <= 2e-2
+    # deterministic action = squash(loc) between low and high
+    a = act.reshape(R, 2).cpu().numpy()
+    exp = np.tanh(ls_h[:, :2]) * np.array([1.0, 0.6], np.float32)
+    assert np.abs(a - exp).max() <= 1e-5
+    env.close()
+    actor.close()
+
+
+def test_sampling_statistics_and_log_prob():
+    torch, env, mlp, actor = _setup(B=256, N=16)
+    R = env.B * env.N
+    obs = torch.zeros((R, env.D), device="cuda")  # same input everywhere: every row samples from the same distribution
+    act = torch.zeros((env.B, env.N, 2), device="cuda")
+    ls = torch.zeros((env.B, env.N, 4), device="cuda")
+    lp = torch.zeros((env.B, env.N), device="cuda")
+    actor.forward(env, act, lp, ls, obs=obs, seed=5, counter=1)
+    act2 = torch.zeros_like(act)
+    actor.forward(env, act2, None, None, obs=obs, seed=5, counter=1)
+    act3 = torch.zeros_like(act)
+    actor.forward(env, act3, None, None, obs=obs, seed=5, counter=2)
+    env.sync()
+    assert torch.equal(act, act2) and not torch.equal(act, act3)       # counter-based: reproducible, and fresh per counter
+    loc, sc = ls[0, 0, :2].cpu().numpy(), ls[0, 0, 2:].cpu().numpy()
+    half = np.array([1.0, 0.6], np.float32)
+    y = (act.reshape(R, 2).cpu().numpy() / half).clip(-0.999999, 0.999999)
+    x = np.arctanh(y)
+    z = (x - loc) / sc                                                    # recovered standard normals
+    assert abs(z.mean()) < 0.05 and abs(z.std() - 1.0) < 0.05 and abs(np.corrcoef(z[:, 0], z[:, 1])[0, 1]) < 0.05
+    ref_lp = (-0.5 * z * z - np.log(sc) - 0.5 * np.log(2 * np.pi) - np.log(1 - y * y + 1e-6) - np.log(half)).sum(1)
+    assert np.abs(lp.reshape(R).cpu().numpy() - ref_lp).max() <= 5e-3
+    env.close()
+    actor.close()
+
+
+def test_rollout_without_the_host_equals_stepwise_calls():
+    """sigmaenv_rollout == the same T steps issued one by one (policy, then the fused step / record / reset)."""
+    from sigmarl_amd.shard import slab_width
+    torch, env, mlp, actor = _setup(B=96, N=16, seed=1)
+    torch2, env2, _, _ = _setup(B=96, N=16, seed=1)
+    actor2 = __import__("sigmarl_amd.actor", fromlist=["Actor"]).Actor(mlp, low=[-1.0, -0.6], high=[1.0, 0.6])
+    T, W = 6, slab_width(env.N, env.D)
+    slab = torch.zeros((T, env.B, W), device="cuda")
+    lp = torch.zeros((T, env.B, env.N), device="cuda")
+    acts = torch.zeros((T, env.B, env.N, 2), device="cuda")
+    actor.rollout(env, T, slab=slab, log_prob=lp, actions=acts, seed=9, counter0=100)
+    env.sync()
+    a = torch.zeros((env2.B, env2.N, 2), device="cuda")
+    slab2 = torch.zeros_like(slab)
+    for t in range(T):
+        actor2.forward(env2, a, seed=9, counter=100 + t)
+        env2.set_slab(slab2[t])
+        env2.step_autoreset(a, seed=9, counter=100 + t)
+        env2.sync()
+        assert torch.equal(a, acts[t])
+    assert torch.equal(slab, slab2)
+    assert torch.equal(env.obs, env2.obs) and torch.equal(env.state, env2.state)
+    assert torch.isfinite(lp).all() and float(slab[..., -1].sum()) >= 0
+    for e in (env, env2):
+        e.close()
+    actor.close()
+    actor2.close()

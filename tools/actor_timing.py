@@ -1,0 +1,39 @@
+#!/usr/bin/env python
+"""Timing / accuracy of the on-device actor and of a whole rollout (policy + fused step) at the bench size."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from sigmarl_amd.actor import Actor, make_mlp
+from sigmarl_amd.env import SigmaEnv
+from sigmarl_amd.params import Parameters
+
+B, N = int(os.environ.get("B", 4096)), 16
+env = SigmaEnv(Parameters(n_agents=N, scenario_type="cpm_entire", dt=0.05, is_use_mtv_distance=False, rew_method="distance", is_apply_mask=False,
+                          is_obs_noise=False, max_steps=128), n_envs=B, device="cuda:0")
+env.reset_random(seed=1)
+torch.manual_seed(0)
+mlp = make_mlp(env.D)
+actor = Actor(mlp, low=[-1.0, -0.6], high=[1.0, 0.6])
+act = torch.zeros((B, N, 2), device="cuda")
+lp = torch.zeros((B, N), device="cuda")
+ls = torch.zeros((B, N, 4), device="cuda")
+actor.forward(env, act, lp, ls)
+env.sync()
+with torch.no_grad():
+    ref = mlp(env.obs.reshape(-1, env.D).cpu()).numpy()
+got = ls.reshape(-1, 4).cpu().numpy()
+print("loc vs torch fp32: max %.3e mean %.3e" % (np.abs(got[:, :2] - ref[:, :2]).max(), np.abs(got[:, :2] - ref[:, :2]).mean()))
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+stream = torch.cuda.current_stream()
+torch.cuda.synchronize()
+s.record()
+for t in range(200):
+    actor.forward(env, act, lp, None, seed=1, counter=t)
+e.record(); torch.cuda.synchronize()
+print("actor forward: %.2f us per call (%d rows)" % (s.elapsed_time(e) / 200 * 1e3, B * N))
+T = 256
+for name, kw in (("rollout (policy + step)", {}),):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    actor.rollout(env, T, seed=1, counter0=1000)
+    env.sync(); el = time.perf_counter() - t0
+    print("%s: %.4f ms per step, %.4g agent-env-steps/s" % (name, el / T * 1e3, B * N * T / el))
