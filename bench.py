@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="diagnostic: no rollout record (and no gather to the learner rank for N > 1)")
     ap.add_argument("--streams", type=int, default=2, help="env shards per GPU, each stepped by its own handle on its own HIP stream "
                     "(envs are independent: same total work per step, the shards' latency-bound phases overlap the others' scan)")
+    ap.add_argument("--policy", action="store_true", help="widening (SURVEY 8f-3): the actor MLP runs on the device before every step "
+                    "(sigmaenv_actor_forward, MFMA bf16) instead of replaying precomputed actions; reported in config.policy")
     ap.add_argument("--exchange", choices=["alltoall", "gather"], default="alltoall",
                     help="N > 1: how the rollout buffer is concatenated.  alltoall: distributed over the ranks by time slices (every rank "
                          "receives 1/N of the steps of ALL envs -- a data-parallel learner; the record crosses xGMI once, over all links); "
@@ -183,6 +185,15 @@ def main():
     counter = [1]
     gather_state = {"note": None}
 
+    actors, act_bufs = [], []
+    if args.policy:
+        from sigmarl_amd.actor import Actor, make_mlp
+        torch.manual_seed(0)
+        mlp = make_mlp(env.D)
+        for k, e in enumerate(envs):
+            with torch.cuda.stream(streams[k]):
+                actors.append(Actor(mlp, low=[-1.0, -0.6109], high=[1.0, 0.6109]))  # -/+ (max_speed, max_steering)
+                act_bufs.append(torch.zeros((Bs, N, 2), dtype=torch.float32, device=device))
     W = N * (env.D + 1) + 1
     act_ptrs = [[acts[q].data_ptr() + k * Bs * N * 2 * 4 for k in range(S)] for q in range(n_act)]
     shard_seeds = [seed * 64 + k for k in range(S)]
@@ -196,7 +207,11 @@ def main():
                 e.set_slab_ptr(base + k * Bs * W * 4)
         ap = act_ptrs[t % n_act]
         cnt = counter[0]
-        if fused:  # one launch per shard: the step, its record, then the device-side reset of the finished envs of the tile
+        if fused and args.policy:  # policy on device, then the fused step on the actions it wrote
+            for k, e in enumerate(envs):
+                actors[k].forward(e, act_bufs[k], seed=shard_seeds[k], counter=cnt)
+                e.step_autoreset_ptr(act_bufs[k].data_ptr(), shard_seeds[k], cnt, pf, pc)
+        elif fused:  # one launch per shard: the step, its record, then the device-side reset of the finished envs of the tile
             for k, e in enumerate(envs):
                 e.step_autoreset_ptr(ap[k], shard_seeds[k], cnt, pf, pc)
         else:
@@ -287,6 +302,8 @@ def main():
                         f"dt=0.05, obs_dim={env.D}, fused step + device-side reset of finished envs "
                         + ("(one launch)" if fused else "(two launches)" if not args.no_reset else "(resets disabled)") + ((" + rollout record" + ((" + " + gather.mode) if gather.collective else "")) if gather else ""),
             "n_agents": N, "envs_per_gpu": B, "envs_total": B * world, "distance": args.distance, "env_shards_per_gpu": S,
+            "policy": ("actor MLP 32-256-256-256-4 (bf16 MFMA, TanhNormal sample) on device before every step" if args.policy
+                       else "none in the timed region (precomputed actions resident in HBM)"),
             "resets_per_step_per_gpu": dones / max(1, args.steps), "rollout_gather": gather_state["note"] or gather_note,
         },
         "roofline": {
