@@ -133,12 +133,12 @@ def main():
                      is_apply_mask=False, is_obs_noise=False, max_steps=128, num_vmas_envs=B)
     # env shards of this GPU: S handles of B / S envs, each on its own HIP stream (no cross-env dependency anywhere in the path)
     # (only when every shard still fills the GPU's CUs with whole tiles; small batches are launch-bound and stay in one piece)
-    S = args.streams if (args.streams >= 1 and B % max(1, args.streams) == 0 and (B // max(1, args.streams)) * N >= 64 * 512) else 1
+    S = args.streams if (args.streams >= 1 and B % max(1, args.streams) == 0 and (B // max(1, args.streams)) * N >= 64 * int(os.environ.get("BENCH_MIN_TILES", "512"))) else 1
     Bs = B // S
     main_stream = torch.cuda.current_stream(device)
     # alternate priorities: the runtime maps streams to a few hardware queues, and two shard streams that land on the same queue
     # (observed once RCCL has created its own streams) would run their kernels back to back instead of side by side
-    streams = [main_stream] if S == 1 else [torch.cuda.Stream(device, priority=-(k % 2)) for k in range(S)]
+    streams = [main_stream] if S == 1 else [torch.cuda.Stream(device, priority=(0 if os.environ.get("BENCH_PRIO") == "none" else -(k % 2))) for k in range(S)]
     seed = 1000 + rank
     envs = []
     for k in range(S):
@@ -199,21 +199,36 @@ def main():
     shard_seeds = [seed * 64 + k for k in range(S)]
     fused = not (args.no_reset or args.separate_reset)
 
+    import ctypes as C
+    HArr, PArr, SArr = C.c_void_p * S, C.c_void_p * S, C.c_uint64 * S
+    h_arr = HArr(*[e.h for e in envs])
+    seed_arr = SArr(*shard_seeds)
+    act_arrs = [PArr(*ap_) for ap_ in act_ptrs]
+    slab_arr = PArr()
+    many = envs[0].lib.step_autoreset_many
+
     def one_step(t):
+        base = 0
         if gather is not None:
             slot = gather.slot(streams if S > 1 else None)  # orders the shard streams behind the gather that still reads this buffer
             base = slot.data_ptr()
-            for k, e in enumerate(envs):
-                e.set_slab_ptr(base + k * Bs * W * 4)
         ap = act_ptrs[t % n_act]
         cnt = counter[0]
+        if fused and not args.policy:  # ONE binding call: every shard's record target + fused step / record / reset launch
+            for k in range(S):
+                slab_arr[k] = (base + k * Bs * W * 4) if base else None
+            rc = many(h_arr, S, act_arrs[t % n_act], slab_arr if base else None, seed_arr, cnt, pf, pc)
+            if rc != 0:
+                raise RuntimeError(f"sigmaenv_step_autoreset_many failed with code {rc}")
+        elif base:
+            for k, e in enumerate(envs):
+                e.set_slab_ptr(base + k * Bs * W * 4)
         if fused and args.policy:  # policy on device, then the fused step on the actions it wrote
             for k, e in enumerate(envs):
                 actors[k].forward(e, act_bufs[k], seed=shard_seeds[k], counter=cnt)
                 e.step_autoreset_ptr(act_bufs[k].data_ptr(), shard_seeds[k], cnt, pf, pc)
-        elif fused:  # one launch per shard: the step, its record, then the device-side reset of the finished envs of the tile
-            for k, e in enumerate(envs):
-                e.step_autoreset_ptr(ap[k], shard_seeds[k], cnt, pf, pc)
+        elif fused:
+            pass  # done above
         else:
             a = acts[t % n_act]
             for k, e in enumerate(envs):

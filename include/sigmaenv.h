@@ -175,6 +175,11 @@ int sigmaenv_auto_reset(sigmaenv_t* h, uint64_t seed, uint64_t counter, int32_t 
  * observation is only visible in the slab -- SIGMAENV_BUF_OBS holds the post-reset observation when the call returns. */
 int sigmaenv_step_autoreset(sigmaenv_t* h, const float* actions, uint64_t seed, uint64_t counter, int32_t path_first, int32_t path_count);
 
+/* sigmaenv_step_autoreset for n handles in one call (env shards of one GPU, each on its own stream): handle k records into
+ * slab_ptrs[k] (array may be NULL: record targets unchanged) and steps on actions[k] with seeds[k]. */
+int sigmaenv_step_autoreset_many(sigmaenv_t** hs, int32_t n, const float* const* actions, float* const* slab_ptrs, const uint64_t* seeds,
+                                 uint64_t counter, int32_t path_first, int32_t path_count);
+
 int sigmaenv_get(sigmaenv_t* h, sigmaenv_buf_t which, void** dev_ptr, size_t* bytes);
 
 /* Rollout slab (wire format of the learner-boundary exchange): when dev_ptr != NULL every following sigmaenv_step also writes

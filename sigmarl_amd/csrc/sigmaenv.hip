@@ -1960,6 +1960,21 @@ extern "C" int sigmaenv_step_autoreset(sigmaenv_t* h, const float* actions, uint
   return launch_step(h, actions, seed, counter, path_first, path_count);
 }
 
+// One call for several handles (env shards of one GPU on their own streams): slab_ptrs[k] (may be NULL) becomes handle k's record
+// target, then its fused step + reset is enqueued.  Saves the per-call host overhead of a binding that steps shards one by one.
+extern "C" int sigmaenv_step_autoreset_many(sigmaenv_t** hs, int32_t n, const float* const* actions, float* const* slab_ptrs, const uint64_t* seeds,
+                                            uint64_t counter, int32_t path_first, int32_t path_count) {
+  if (!hs || !actions || !seeds || n < 1) return SIGMAENV_EINVAL;
+  for (int k = 0; k < n; ++k) {
+    sigmaenv* h = hs[k];
+    if (!h || path_first < 0 || path_count < 1 || path_first + path_count > h->n_paths) return SIGMAENV_EINVAL;
+    if (slab_ptrs) h->buf.slab = slab_ptrs[k];
+    const int rc = launch_step(h, actions[k], seeds[k], counter, path_first, path_count);
+    if (rc) return rc;
+  }
+  return SIGMAENV_OK;
+}
+
 extern "C" int sigmaenv_observe(sigmaenv_t* h) {
   if (!h) return SIGMAENV_EINVAL;
   hipLaunchKernelGGL(sigmaenv_observe_kernel, dim3(h->grid), dim3(h->block), h->smem_bytes, h->stream, h->cfg, h->buf, h->G);
