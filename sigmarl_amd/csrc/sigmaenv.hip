@@ -187,14 +187,6 @@ __device__ inline void agent_scan_full(const DevMap& m, const sigmaenv_config_t&
 // So every segment whose computed distance can equal or beat the running minimum, and every segment that can hit the
 // rectangle, is still evaluated with the very same arithmetic; ties still resolve to the lowest index.
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float guess_distance(const float* __restrict__ poly, int n, int cp_guess, float px, float py) {
-  int k = cp_guess - 1;
-  k = k < 0 ? 0 : (k > n - 2 ? n - 2 : k);
-  const Seg4 sg = load_segment(reinterpret_cast<const float2*>(poly), k);
-  float lx = sg.bx - sg.ax, ly = sg.by - sg.ay;
-  return point_segment(px, py, sg.ax, sg.ay, lx, ly, lx * lx + ly * ly);
-}
-
 // exact radius of the corner-query points around the centre (used for agent 0, whose query points are last step's vertices)
 __device__ __forceinline__ float query_radius(const float* qv, float cgx, float cgy) {
   float R = 0.0f;

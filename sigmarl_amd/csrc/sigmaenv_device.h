@@ -85,7 +85,6 @@ __device__ __forceinline__ float cr_sin(float x) { return (float)sin((double)x);
 __device__ __forceinline__ float cr_cos(float x) { return (float)cos((double)x); }
 __device__ __forceinline__ float cr_tan(float x) { return (float)tan((double)x); }
 __device__ __forceinline__ float cr_atan(float x) { return (float)atan((double)x); }
-__device__ __forceinline__ float cr_atan2(float y, float x) { return (float)atan2((double)y, (double)x); }
 __device__ __forceinline__ void cr_sincos(float x, float& s, float& c) {
   double ds, dc;
   sincos((double)x, &ds, &dc);
@@ -241,22 +240,6 @@ __device__ __forceinline__ bool edge_hits_segment(const Edge& e, float x2a, floa
   bool C2 = ((wa - S2) * (wb - S2)) < 0.0f;
   return C1 && C2;
 }
-// interX for two closed rectangles (5 points each)
-__device__ inline bool interx_rect_rect(const float* va, const float* vb) {
-  bool hit = false;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    Edge e = make_edge(va[2 * i], va[2 * i + 1], va[2 * i + 2], va[2 * i + 3]);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float x2a = vb[2 * j], y2a = vb[2 * j + 1], x2b = vb[2 * j + 2], y2b = vb[2 * j + 3];
-      float dx2 = x2b - x2a, dy2 = y2b - y2a;
-      float S2 = dx2 * y2a - dy2 * x2a;
-      hit |= edge_hits_segment(e, x2a, y2a, x2b, y2b, dx2, dy2, S2);
-    }
-  }
-  return hit;
-}
 // interX of a closed rectangle against one 2-point segment (entry / exit), world_state_rt_sim.py:413-424
 __device__ inline bool interx_rect_seg(const float* v, float x2a, float y2a, float x2b, float y2b) {
   float dx2 = x2b - x2a, dy2 = y2b - y2a;
@@ -340,15 +323,6 @@ __device__ inline void short_term_path(const float* center, int n, bool is_loop,
   }
 }
 
-// ---- ego-view transform (helper_scenario.py:1241-1273) -------------------------------------------------------------
-__device__ __forceinline__ void ego_transform(float pix, float piy, float rot_i, float pjx, float pjy, float& ox, float& oy) {
-  float dx = pjx - pix, dy = pjy - piy;
-  float ab = norm2(dx, dy);
-  float rr = cr_atan2(dy, dx) - rot_i;
-  ox = cr_cos(rr) * ab;
-  oy = cr_sin(rr) * ab;
-}
-
 // ---- wave-level (64 lanes) reductions -------------------------------------------------------------------------------
 // lexicographic (distance, index) minimum: torch.min returns the first minimal index (helper_scenario.py:883)
 __device__ __forceinline__ void wave_argmin(float& d, int& k) {
@@ -360,37 +334,8 @@ __device__ __forceinline__ void wave_argmin(float& d, int& k) {
   }
 }
 
-// DPP lane permutations inside rows of 16 lanes (no LDS crossbar): quad_perm[1,0,3,2], quad_perm[2,3,0,1], row_half_mirror,
-// row_mirror.  Applying a commutative/associative combine over these four patterns leaves the full 16-lane result in every lane.
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-template <int CTRL>
-__device__ __forceinline__ int dpp_i(int v) {
-  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
-}
-__device__ __forceinline__ float row16_min(float v) {
-  v = fminf(v, dpp_f<0xB1>(v));
-  v = fminf(v, dpp_f<0x4E>(v));
-  v = fminf(v, dpp_f<0x141>(v));
-  v = fminf(v, dpp_f<0x140>(v));
-  return v;
-}
-#define SIGMA_ARGMIN_STEP(CTRL)                                   \
-  {                                                               \
-    float od = dpp_f<CTRL>(d);                                    \
-    int ok = dpp_i<CTRL>(k);                                      \
-    if (od < d || (od == d && ok < k)) { d = od; k = ok; }        \
-  }
-// lexicographic (distance, index) minimum over each row of 16 lanes
-__device__ __forceinline__ void row16_argmin(float& d, int& k) {
-  SIGMA_ARGMIN_STEP(0xB1)
-  SIGMA_ARGMIN_STEP(0x4E)
-  SIGMA_ARGMIN_STEP(0x141)
-  SIGMA_ARGMIN_STEP(0x140)
-}
-
+// Row-of-16 reductions through DPP lane permutations (no LDS crossbar): quad_perm[1,0,3,2], quad_perm[2,3,0,1], row_half_mirror,
+// row_mirror -- a commutative / associative combine over these four patterns leaves the full 16-lane result in every lane.
 // Six row-of-16 minima at once with the DPP operand folded into v_min_f32 (one instruction per step and value instead of
 // v_mov_dpp + canonicalise + v_min).  The six chains are interleaved step-major, so that a value is read through DPP five
 // instructions after the VALU write that produced it (the hardware needs two wait states there); the leading s_nop covers the
