@@ -476,3 +476,29 @@ def test_soak_fused_launch_vs_oracle(mtv, rew):
     assert n_diff <= 64
     dev.close()
     ora.close()
+
+
+@pytest.mark.parametrize("scen,N", [("pseudo_distance_example", 1), ("cpm_entire", 1), ("cpm_entire", 3)])
+def test_single_agent_and_odd_observation_width(scen, N):
+    """N = 1: no neighbours (K = 0, obs_dim = 10: the scalar row-store path), 64 envs per workgroup, no agent pairs at all."""
+    B = 9
+    p = Parameters(n_agents=N, scenario_type=scen, is_use_mtv_distance=False, rew_method="distance", dt=0.1, is_apply_mask=False, is_obs_noise=False,
+                   max_steps=6, n_nearing_agents_observed=min(2, N - 1))
+    mp = load_map(scen)
+    cfg = make_config(p, mp, B)
+    dev, ora = _hip_env(cfg, mp), ob.OracleEnv(cfg, mp)
+    dev.env.buffer(capi.BUF_DONE).fill_(1)
+    ora.get(capi.BUF_DONE, copy=False)[:] = 1
+    pf, pc = mp.list_first[0], mp.list_count[0]
+    dev.auto_reset(2, 0, pf, pc)
+    ora.auto_reset(2, 0, pf, pc)
+    rng = np.random.default_rng(1)
+    for t in range(10):
+        act = np.stack([rng.uniform(0, 1.2, (B, N)), rng.uniform(-0.5, 0.5, (B, N))], -1).astype(np.float32)
+        dev.step_autoreset(act, 2, t + 1, pf, pc)
+        ora.step(act)
+        ora.auto_reset(2, t + 1, pf, pc)
+        _compare_all(dev, ora, f"{scen} N={N} step {t}")
+    assert dev.env.D == 4 + 6 + 11 * min(2, N - 1)
+    dev.close()
+    ora.close()
