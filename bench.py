@@ -103,6 +103,7 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
 
+    os.environ.setdefault("SIGMAENV_TIMING_STRIDE", "32")  # HIP-event bracket around every 32nd step launch (each bracket costs a few microseconds)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the HIP runtime starts: enough hardware queues for the shard + RCCL streams
     import torch
     import torch.distributed as dist
