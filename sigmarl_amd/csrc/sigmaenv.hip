@@ -1040,10 +1040,24 @@ __global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigm
   if (!(dbg_skip & 8)) observe_tile(c, s, g, t, 8);
   if (slab) {  // rollout record of this step (observation AFTER the step, reward, done), one contiguous row per env
     const int ND = N * t.D, W = ND + N + 1;
-    for (int k = tid; k < t.nenv * W; k += blockDim.x) {
-      int e = fdiv(k, g.mW), r = k - e * W;
-      float v = (r < ND) ? s.obs[e * ND + r] : ((r < ND + N) ? s.rew[e * N + (r - ND)] : s.rew[G * N + e]);
-      slab[(size_t)(t.env0 + e) * W + r] = v;
+    if ((ND & 3) == 0) {
+      // observation part: whole float4s out of the (16-byte aligned) LDS rows, 16-byte stores at the row's 4-byte alignment
+      const int Q = ND >> 2;  // float4s per env
+      for (int k = tid; k < t.nenv * Q; k += blockDim.x) {
+        const int e = k / Q, q = k - e * Q;  // Q is a power-of-two multiple for the default widths; the division is per float4, not per float
+        const float4 v = reinterpret_cast<const float4*>(s.obs + e * ND)[q];
+        *reinterpret_cast<F4u*>(slab + (size_t)(t.env0 + e) * W + 4 * q) = F4u{v.x, v.y, v.z, v.w};
+      }
+      for (int k = tid; k < t.nenv * (N + 1); k += blockDim.x) {  // rewards and the done flag
+        const int e = k / (N + 1), r = k - e * (N + 1);
+        slab[(size_t)(t.env0 + e) * W + ND + r] = (r < N) ? s.rew[e * N + r] : s.rew[G * N + e];
+      }
+    } else {
+      for (int k = tid; k < t.nenv * W; k += blockDim.x) {
+        int e = fdiv(k, g.mW), r = k - e * W;
+        float v = (r < ND) ? s.obs[e * ND + r] : ((r < ND + N) ? s.rew[e * N + (r - ND)] : s.rew[G * N + e]);
+        slab[(size_t)(t.env0 + e) * W + r] = v;
+      }
     }
   }
   TS(5);

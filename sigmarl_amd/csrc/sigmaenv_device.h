@@ -80,6 +80,10 @@ __device__ __forceinline__ Seg4 load_segment(const float2* p, int k) { return *r
 // x / d for x * d < 2^32 with m = ceil(2^32 / d) (d = 1: m wraps to 0): two instructions instead of the ~20 of a runtime division
 __device__ __forceinline__ int fdiv(int x, uint32_t m) { return m ? (int)__umulhi((uint32_t)x, m) : x; }
 
+// four consecutive floats stored with ONE 16-byte store at 4-byte alignment (global memory accepts it): rows of the rollout record
+// have an odd number of floats
+struct __attribute__((packed, aligned(4))) F4u { float x, y, z, w; };
+
 // ---- scalar helpers ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float cr_sin(float x) { return (float)sin((double)x); }
 __device__ __forceinline__ float cr_cos(float x) { return (float)cos((double)x); }
