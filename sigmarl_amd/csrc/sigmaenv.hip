@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "sigmaenv_device.h"
@@ -361,8 +362,11 @@ __device__ inline void pair_scan(const DevMap& m, const sigmaenv_config_t& c, co
   float cd = INFINITY, bd0 = INFINITY, bs0 = INFINITY, bs1 = INFINITY, bs2 = INFINITY, bs3 = INFINITY;
   int ck = 0, bk = 0;
   bool h = false;
-  // one loop for both polylines so that the centre-line and boundary segment loads of a pass are in flight together
-  for (int it = 0; __any(it * 32 < cnt_c || it * 16 < cnt_b); ++it) {
+  // One pass covers 32 centre-line and 16 boundary segments per agent (side): both polylines in one pass, so that their segment
+  // loads are in flight together.  Nearly every scan is ONE pass; the first pass therefore assigns its results instead of merging them
+  // into the running minima (FIRST), the rare further passes merge.
+  auto pass = [&](int it, auto first_tag) {
+    constexpr bool FIRST = decltype(first_tag)::value;
     const int jc = it * 32 + hl, jb = it * 16 + gl;
     const int qc = jc / SIGMAENV_CHUNK, qb = jb / SIGMAENV_CHUNK;
     const int chc = (jc < cnt_c) ? (qc < CAND_LIST ? (int)clc[qc] : nth_set_bit64(mc, qc)) : -1;
@@ -376,7 +380,7 @@ __device__ inline void pair_scan(const DevMap& m, const sigmaenv_config_t& c, co
       float lx = cb.x - ca.x, ly = cb.y - ca.y;
       float len2 = lx * lx + ly * ly;
       float d = point_segment_t<FASTDIV>(cgx, cgy, ca.x, ca.y, lx, ly, len2, FASTDIV ? shared_rcp(len2) : 0.0f);
-      if (d < cd || (d == cd && kc < ck)) { cd = d; ck = kc; }
+      if (FIRST || d < cd || (d == cd && kc < ck)) { cd = d; ck = kc; }
     }
     float d0 = INFINITY;
     if (do_b) {
@@ -384,11 +388,13 @@ __device__ inline void pair_scan(const DevMap& m, const sigmaenv_config_t& c, co
       float len2 = lx * lx + ly * ly;
       const float rcp = FASTDIV ? shared_rcp(len2) : 0.0f;
       d0 = point_segment_t<FASTDIV>(cgx, cgy, ba.x, ba.y, lx, ly, len2, rcp);
-      if (d0 < bd0 || (d0 == bd0 && kb < bk)) { bd0 = d0; bk = kb; }
-      bs0 = fminf(bs0, point_segment_sq_t<FASTDIV>(q0x, q0y, ba.x, ba.y, lx, ly, len2, rcp));
-      bs1 = fminf(bs1, point_segment_sq_t<FASTDIV>(q1x, q1y, ba.x, ba.y, lx, ly, len2, rcp));
-      bs2 = fminf(bs2, point_segment_sq_t<FASTDIV>(q2x, q2y, ba.x, ba.y, lx, ly, len2, rcp));
-      bs3 = fminf(bs3, point_segment_sq_t<FASTDIV>(q3x, q3y, ba.x, ba.y, lx, ly, len2, rcp));
+      if (FIRST || d0 < bd0 || (d0 == bd0 && kb < bk)) { bd0 = d0; bk = kb; }
+      const float v0 = point_segment_sq_t<FASTDIV>(q0x, q0y, ba.x, ba.y, lx, ly, len2, rcp);
+      const float v1 = point_segment_sq_t<FASTDIV>(q1x, q1y, ba.x, ba.y, lx, ly, len2, rcp);
+      const float v2 = point_segment_sq_t<FASTDIV>(q2x, q2y, ba.x, ba.y, lx, ly, len2, rcp);
+      const float v3 = point_segment_sq_t<FASTDIV>(q3x, q3y, ba.x, ba.y, lx, ly, len2, rcp);
+      if (FIRST) { bs0 = v0; bs1 = v1; bs2 = v2; bs3 = v3; }
+      else { bs0 = fminf(bs0, v0); bs1 = fminf(bs1, v1); bs2 = fminf(bs2, v2); bs3 = fminf(bs3, v3); }
     }
     if (COLLIDE) {
       // Only a segment within the rectangle's circumradius of the (new) centre can cross an edge (same argument as the pruning,
@@ -412,7 +418,9 @@ __device__ inline void pair_scan(const DevMap& m, const sigmaenv_config_t& c, co
         }
       }
     }
-  }
+  };
+  pass(0, std::true_type{});
+  for (int it = 1; __any(it * 32 < cnt_c || it * 16 < cnt_b); ++it) pass(it, std::false_type{});
   // ---- reductions: DPP inside the rows of 16 lanes; the centre line needs one cross-row step.  The lexicographic
   // (distance, index) minimum is taken as: minimum distance first, then the lowest index among the lanes that hold it.
   {
