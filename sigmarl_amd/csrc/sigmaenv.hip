@@ -550,9 +550,47 @@ __device__ inline void observe_tile(const sigmaenv_config_t& c, const Smem& s, c
   const float n_pos = (float)((double)c.length * 10.0);   // normalizers.pos, road_traffic.py:588-592
   const float n_v = c.max_speed;                            // :596
   const float n_dl = (float)((double)c.lane_width * 3.0);   // :599-601 (distance_lanelet also normalises the agent distances)
-  for (int v = threadIdx.x; v < n_slots; v += blockDim.x) {
-    const int sl = real_slot(v);
-    topk_nearest(s.dist + sl * DIST_STRIDE(N), N, K, s.near + sl * K);
+  if (K == 2 && n_slots * 4 <= (int)blockDim.x) {
+    // Two nearest of every agent with FOUR lanes per agent (a quad): lane q scans the candidates q, q + 4, q + 8, ... in increasing
+    // order, then the quads merge their (distance, index)-sorted pairs through DPP quad permutations.  Same result as the selection
+    // loop (ascending distance, lowest index on ties, unconditional first entries), a quarter of its dependent chain.
+    const int tid = threadIdx.x, qd = tid & 3, v = tid >> 2;
+    const bool act = v < n_slots;
+    const int sl = act ? real_slot(v) : 0;
+    const float* row = s.dist + sl * DIST_STRIDE(N);
+    float b0 = INFINITY, b1 = INFINITY;
+    int i0 = 0x7FFFFFFF, i1 = 0x7FFFFFFF;  // "no entry": loses every index tie; replaced by the first real entry unconditionally
+    for (int j = qd; j < N; j += 4) {
+      const float d = row[j];
+      if (i0 == 0x7FFFFFFF || d < b0) { b1 = b0; i1 = i0; b0 = d; i0 = j; }
+      else if (i1 == 0x7FFFFFFF || d < b1) { b1 = d; i1 = j; }
+    }
+    auto less = [](float da, int ia, float db, int ib) {  // (d, i) sorts before (d', i'); an empty entry never sorts first
+      if (ia == 0x7FFFFFFF) return false;
+      if (ib == 0x7FFFFFFF) return true;
+      return da < db || (!(db < da) && ia < ib);
+    };
+#define SIGMA_QUAD(x, CTRL) __builtin_amdgcn_update_dpp(0, (x), (CTRL), 0xF, 0xF, true)
+#define SIGMA_TOP2_MERGE(CTRL)                                                                      \
+  {                                                                                                 \
+    const float c0 = __int_as_float(SIGMA_QUAD(__float_as_int(b0), CTRL)), c1 = __int_as_float(SIGMA_QUAD(__float_as_int(b1), CTRL)); \
+    const int k0 = SIGMA_QUAD(i0, CTRL), k1 = SIGMA_QUAD(i1, CTRL);                                 \
+    const bool mine = less(b0, i0, c0, k0);                                                        \
+    const float f0 = mine ? b0 : c0, sa = mine ? b1 : b0, sb = mine ? c0 : c1;                       \
+    const int g0 = mine ? i0 : k0, ga = mine ? i1 : i0, gb = mine ? k0 : k1;                        \
+    const bool second_a = less(sa, ga, sb, gb);                                                    \
+    b0 = f0; i0 = g0; b1 = second_a ? sa : sb; i1 = second_a ? ga : gb;                             \
+  }
+    SIGMA_TOP2_MERGE(0xB1)  // quad_perm [1,0,3,2]
+    SIGMA_TOP2_MERGE(0x4E)  // quad_perm [2,3,0,1]
+#undef SIGMA_TOP2_MERGE
+#undef SIGMA_QUAD
+    if (act && qd == 0) { s.near[sl * K] = i0; s.near[sl * K + 1] = i1; }
+  } else {
+    for (int v = threadIdx.x; v < n_slots; v += blockDim.x) {
+      const int sl = real_slot(v);
+      topk_nearest(s.dist + sl * DIST_STRIDE(N), N, K, s.near + sl * K);
+    }
   }
   TSO(0);
   __syncthreads();
