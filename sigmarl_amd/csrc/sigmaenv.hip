@@ -714,14 +714,9 @@ __device__ inline void auto_reset_tile(const sigmaenv_config_t& c, const DevMap&
 #ifndef STEP_MIN_WAVES
 #define STEP_MIN_WAVES 4  // <= 128 VGPRs: 4 workgroups per CU resident, 16 workgroups per CU at 16x4096 = 4 full rounds
 #endif
-__global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigmaenv_config_t c, const DevMap* __restrict__ mp, const DevBufs* __restrict__ gp,
-                                                                              const float* __restrict__ actions, int G, int dbg_skip, uint64_t seed, uint64_t counter,
-                                                                              int path_first, int path_count, float* __restrict__ slab) {
-  // The map and buffer tables (~60 pointers) are read from device memory where they are used instead of arriving as by-value kernel
-  // arguments: as arguments they are all loaded into scalar registers at entry, exceed the scalar register file and get spilled into
-  // vector lanes, and every later use costs a v_readlane on the vector unit -- the unit this kernel is bound by.
-  const DevMap& m = *mp;
-  const DevBufs& g = *gp;
+__global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigmaenv_config_t c, DevMap m, DevBufs g, const float* __restrict__ actions, int G, int dbg_skip,
+                                                                              uint64_t seed, uint64_t counter, int path_first, int path_count,
+                                                                              float* __restrict__ slab) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const Tile t(c, G);
   const int N = t.N;
@@ -1615,8 +1610,6 @@ struct sigmaenv {
   int B = 0, N = 0, K = 0, D = 0, P = 0, n_paths = 0;
   DevMap map{};
   DevBufs buf{};
-  DevMap* d_map = nullptr;   // device copies of the two tables (the step kernel reads them through pointers)
-  DevBufs* d_buf = nullptr;
   std::vector<void*> allocs;
   size_t smem_bytes = 0;
   int block = 256;
@@ -1920,15 +1913,6 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_reset_derive_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem_bytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_auto_reset_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem_bytes);
   }
-  {  // device copies of the (now final) map and buffer tables for the step kernel
-    void* pm = nullptr;
-    void* pb = nullptr;
-    if (dev_alloc(h, &pm, sizeof(DevMap)) || dev_alloc(h, &pb, sizeof(DevBufs))) { sigmaenv_destroy(h); return SIGMAENV_ENOMEM; }
-    h->d_map = static_cast<DevMap*>(pm);
-    h->d_buf = static_cast<DevBufs*>(pb);
-    if (hipMemcpyAsync(h->d_map, &h->map, sizeof(DevMap), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
-        hipMemcpyAsync(h->d_buf, &h->buf, sizeof(DevBufs), hipMemcpyHostToDevice, h->stream) != hipSuccess) { sigmaenv_destroy(h); return SIGMAENV_EHIP; }
-  }
   if (hipStreamSynchronize(h->stream) != hipSuccess) { sigmaenv_destroy(h); return SIGMAENV_EHIP; }
   *out = h;
   return SIGMAENV_OK;
@@ -1998,8 +1982,8 @@ static int launch_step(sigmaenv* h, const float* actions, uint64_t seed, uint64_
     h->ev_used.push_back(slot);
     HIPCHK(h, hipEventRecord(h->ev_pool[slot].first, h->stream));
   }
-  hipLaunchKernelGGL(sigmaenv_step_kernel, dim3(h->grid), dim3(h->block), h->smem_bytes, h->stream, h->cfg, h->d_map, h->d_buf, actions, h->G, h->dbg_skip,
-                     seed, counter, path_first, path_count, h->buf.slab);
+  hipLaunchKernelGGL(sigmaenv_step_kernel, dim3(h->grid), dim3(h->block), h->smem_bytes, h->stream, h->cfg, h->map, h->buf, actions, h->G,
+                     h->dbg_skip, seed, counter, path_first, path_count, h->buf.slab);
   HIPCHK(h, hipGetLastError());
   if (slot >= 0) HIPCHK(h, hipEventRecord(h->ev_pool[slot].second, h->stream));
   return SIGMAENV_OK;
