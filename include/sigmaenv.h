@@ -60,11 +60,14 @@ extern "C" {
 #define SIGMAENV_REW_TTC 2          /* "ttc" in rew_method */
 #define SIGMAENV_REW_EXACT_SPARSE 4 /* rew_method == "sparse" */
 #define SIGMAENV_REW_HAS_SPARSE 8   /* "sparse" in rew_method */
+#define SIGMAENV_REW_CBF 16         /* "cbf" in rew_method with Parameters.is_solve_qp == False: the step adds the three margin
+                                     * channels written by sigmaenv_cbf_rewards (road_traffic.py:1112-1151) */
 
 #define SIGMAENV_N_SHORT_TERM 3     /* n_points_short_term (config.json:27) */
 #define SIGMAENV_MAX_NEARING 4      /* n_nearing_agents_observed <= 4 (default 2) */
 #define SIGMAENV_MAX_AGENTS 64
 #define SIGMAENV_N_REWARD_INFO 12   /* RewardInfo fields, helper_scenario.py:101-114 */
+#define SIGMAENV_CBF_MAX_CIRCLES 4  /* Parameters.n_circles_approximate_vehicle <= 4 (default 3) */
 
 typedef struct sigmaenv_config {
   int32_t abi_version;   /* SIGMAENV_ABI_VERSION */
@@ -219,6 +222,39 @@ int sigmaenv_actor_forward(sigmaenv_t* h, sigmaenv_actor_t* a, const float* obs,
  * Step t uses the random-stream counter counter0 + t for both the policy sample and the resets. */
 int sigmaenv_rollout(sigmaenv_t* h, sigmaenv_actor_t* a, int32_t n_steps, float* actions_buf, float* slab_base, float* logp_base, float* actions_rec,
                      uint64_t seed, uint64_t counter0, int32_t path_first, int32_t path_count, int32_t deterministic);
+
+/* ---- QP-free CBF margin reward ---------------------------------------------------------------------------
+ * CBFQP.update_qp with Parameters.is_solve_qp == False (sigmarl/cbf_qp.py:2534-2560): the nominal CBF constraint margins of every
+ * env (compute_nominal_cbf_constraint_margins :2562-2760 -- lane margins from the pseudo distance to both boundaries and its
+ * finite-difference gradient / Hessian, sigmarl/pseudo_distance.py:69-242 + cbf_qp.py:575-665; pair margins between the covering
+ * circles of every two vehicles :2688-2754; second-order Taylor CBF coefficients :2283-2489) and the three reward channels derived
+ * from them (compute_cbf_violation_rewards_from_margins :2762-2804), for all envs in one launch instead of one Python object per
+ * env (helper_training.py:1620-1627).  Nominal controller "rl" (:2605-2615), no observation noise. */
+typedef struct sigmaenv_cbf_config {
+  int32_t n_circles;        /* Parameters.n_circles_approximate_vehicle, 1..SIGMAENV_CBF_MAX_CIRCLES */
+  int32_t reserved;
+  double dt_taylor;         /* cbf_qp.py:370-371: 2 * Parameters.dt */
+  double lambda_ttcbf;      /* :404 (0.5) */
+  double h_nom;             /* Parameters.h_nom */
+  double fd_step;           /* :372-373 (0.02), finite-difference stencil of the pseudo distance */
+  double safety_buffer;     /* :403 (0) */
+  double circle_radius;     /* RectangleCircleApproximation.radius, sigmarl/rectangle_approximation.py:45-56 */
+  double circle_x[SIGMAENV_CBF_MAX_CIRCLES]; /* centres along the length axis (y = 0), :58-70 */
+  double l_r, l_wb;         /* constants.py:634-635 (compute_dstate_2nd_time, cbf_qp.py:667-695) */
+  float min_speed, min_steering; /* constants.py:637-640; the maxima, acceleration and steering-rate limits come from the env config */
+  float reserved2[2];
+} sigmaenv_cbf_config_t;
+
+/* seg_left / seg_right: HOST pointers f32 [n_paths, seg_stride, 5] = per boundary segment (cos, sin, m_b, m_t, length): the
+ * map-only part of PseudoDistance.get_pseudo_distance (pseudo_distance.py:43-56,94-103,174-177), for the paths of the map the
+ * handle was created with.  Copied to the device. */
+int sigmaenv_cbf_attach(sigmaenv_t* h, const sigmaenv_cbf_config_t* cfg, const float* seg_left, const float* seg_right, int32_t seg_stride);
+
+/* actions: DEVICE f32 [B,N,2], the policy's action (target speed, target steering) the step is about to receive.  Writes rows 5
+ * (rew_near_left_lane), 6 (rew_near_right_lane) and 4 (rew_near_other_agents) of SIGMAENV_BUF_REWARD_INFO, which the next
+ * sigmaenv_step adds to the reward when SIGMAENV_REW_CBF is set.  margins: optional DEVICE f64 buffer receiving
+ * lane_left [B,N,C], lane_right [B,N,C], pair [B,N,N,C,C] (entries with i < j), back to back; NULL to skip. */
+int sigmaenv_cbf_rewards(sigmaenv_t* h, const float* actions, double* margins);
 
 #ifdef __cplusplus
 }

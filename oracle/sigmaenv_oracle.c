@@ -46,6 +46,9 @@ typedef struct sigmaenv_oracle {
   float *reward, *reward_info, *obs, *action;
   int32_t *path, *closest, *nearing, *timer;
   uint8_t *col_agents, *col_flags, *done;
+  sigmaenv_cbf_config_t cbf;    /* sigmaenv_oracle_cbf_attach */
+  float *seg_left, *seg_right;  /* [n_paths][seg_stride][5] */
+  int seg_stride;
   char err[256];
 } oracle_t;
 
@@ -402,6 +405,13 @@ static float agent_reward(oracle_t* o, int b, int i, float* near_other_out, int*
       rew += p; rew += pen_lane;
       if (c->rew_flags & SIGMAENV_REW_HAS_SPARSE) { rew += pca; rew += pcl; }
     }
+    if (c->rew_flags & SIGMAENV_REW_CBF) {                                           /* :1112-1151, is_solve_qp == False */
+      size_t BNn = (size_t)o->B * N;
+      const float* RI = o->reward_info;                              /* written by CBFQP.update_qp before the step */
+      float cbf_rew = ((RI[5 * BNn + bi] + RI[6 * BNn + bi]) + RI[4 * BNn + bi]) / 3.0f;   /* :1141-1146 */
+      rew += cbf_rew;
+      if (c->rew_flags & SIGMAENV_REW_HAS_SPARSE) { rew += pca; rew += pcl; }
+    }
   }
   *goal_out = reward_goal; *pca_out = pca; *pcl_out = pcl;
   return clampf(rew, -1.0f, 1.0f);                               /* :1249 */
@@ -707,7 +717,8 @@ void sigmaenv_oracle_destroy(oracle_t* o) {
   if (!o) return;
   void* ptrs[] = {o->center, o->left, o->right, o->yaw, o->n_center, o->n_left, o->n_right, o->is_loop, o->state, o->prev_pos,
                   o->vertices, o->short_term, o->dist_ref, o->dist_left, o->dist_right, o->dist_bound, o->dist_agents, o->reward,
-                  o->reward_info, o->obs, o->action, o->path, o->closest, o->nearing, o->timer, o->col_agents, o->col_flags, o->done};
+                  o->reward_info, o->obs, o->action, o->path, o->closest, o->nearing, o->timer, o->col_agents, o->col_flags, o->done,
+                  o->seg_left, o->seg_right};
   for (size_t k = 0; k < sizeof(ptrs) / sizeof(ptrs[0]); ++k) free(ptrs[k]);
   free(o);
 }
@@ -885,3 +896,5 @@ void sigmaenv_oracle_fn_ego(int n, const float* pi, const float* roti, int m, co
 void sigmaenv_oracle_fn_wrap(int n, const float* a, float* out) {
   for (int k = 0; k < n; ++k) out[k] = angle_eliminate_two_pi(a[k]);
 }
+
+#include "sigmaenv_cbf_oracle.inc"

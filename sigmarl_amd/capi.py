@@ -16,7 +16,8 @@ import os
 
 ABI_VERSION = 1
 DIST_C2C, DIST_MTV = 0, 1
-REW_DISTANCE, REW_TTC, REW_EXACT_SPARSE, REW_HAS_SPARSE = 1, 2, 4, 8
+REW_DISTANCE, REW_TTC, REW_EXACT_SPARSE, REW_HAS_SPARSE, REW_CBF = 1, 2, 4, 8, 16
+CBF_MAX_CIRCLES = 4
 N_SHORT_TERM = 3
 MAX_NEARING = 4
 N_REWARD_INFO = 12
@@ -58,6 +59,18 @@ class Map(C.Structure):
     ]
 
 
+class CbfConfig(C.Structure):
+    """``sigmaenv_cbf_config_t``."""
+
+    _fields_ = [
+        ("n_circles", C.c_int32), ("reserved", C.c_int32),
+        ("dt_taylor", C.c_double), ("lambda_ttcbf", C.c_double), ("h_nom", C.c_double), ("fd_step", C.c_double),
+        ("safety_buffer", C.c_double), ("circle_radius", C.c_double), ("circle_x", C.c_double * CBF_MAX_CIRCLES),
+        ("l_r", C.c_double), ("l_wb", C.c_double), ("min_speed", C.c_float), ("min_steering", C.c_float),
+        ("reserved2", C.c_float * 2),
+    ]
+
+
 # vehicle constants of the reference, sigmarl/constants.py:628-647
 AGENTS = {
     "width": 0.107, "length": 0.22, "l_f": 0.075, "l_r": 0.075, "l_wb": 0.15,
@@ -68,11 +81,14 @@ AGENTS = {
 }
 
 
-def rew_flags_from_method(rew_method: str) -> int:
+def rew_flags_from_method(rew_method: str, is_solve_qp: bool = True) -> int:
     """Decode ``Parameters.rew_method`` the way sigmarl/scenarios/road_traffic.py:1056-1151 tests the string."""
-    if "cbf" in rew_method:
-        raise ValueError("rew_method containing 'cbf' needs the CBF-QP path (SURVEY.md section 8 config 5): not built")
     f = 0
+    if "cbf" in rew_method:
+        if is_solve_qp:
+            raise ValueError("rew_method containing 'cbf' with is_solve_qp=True needs the CBF-QP solver (SURVEY.md section 8 config 5): "
+                             "not built; the QP-free margin reward (is_solve_qp=False) is")
+        f |= REW_CBF
     if "distance" in rew_method:
         f |= REW_DISTANCE
     if "ttc" in rew_method:
@@ -102,6 +118,8 @@ _SIGS = {
     "auto_reset": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32]),
     "get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "sync": (C.c_int, [C.c_void_p]),
+    "cbf_attach": (C.c_int, [C.c_void_p, C.POINTER(CbfConfig), C.c_void_p, C.c_void_p, C.c_int32]),
+    "cbf_rewards": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 _PRODUCT_ONLY = {
     "step_time_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),

@@ -1009,6 +1009,12 @@ __global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigm
           rew += p; rew += pen_lane;
           if (c.rew_flags & SIGMAENV_REW_HAS_SPARSE) { rew += pca; rew += pcl; }
         }
+        if (c.rew_flags & SIGMAENV_REW_CBF) {                        // :1112-1151 with is_solve_qp == False
+          // the three margin channels CBFQP.update_qp wrote before this step (sigmaenv_cbf_rewards)
+          const float cbf_rew = ((g.reward_info[5 * BN + gi] + g.reward_info[6 * BN + gi]) + g.reward_info[4 * BN + gi]) / 3.0f;
+          rew += cbf_rew;
+          if (c.rew_flags & SIGMAENV_REW_HAS_SPARSE) { rew += pca; rew += pcl; }
+        }
       }
       TS(14);
       float r = clampf(rew, -1.0f, 1.0f);                            // :1249
@@ -1629,6 +1635,10 @@ struct sigmaenv {
   bool timing = false;
   int timing_stride = 8;
   unsigned long long launch_count = 0;
+  // QP-free CBF margin reward (sigmaenv_cbf.inc)
+  sigmaenv_cbf_config_t cbf_cfg{};
+  void *cbf_seg4 = nullptr, *cbf_segl = nullptr;
+  int cbf_seg_stride = 0;
   std::string err;
 };
 
@@ -2084,3 +2094,4 @@ extern "C" int sigmaenv_step_time_ms(sigmaenv_t* h, double* avg_ms, int32_t* n_l
 }
 
 #include "sigmaenv_actor.inc"
+#include "sigmaenv_cbf.inc"

@@ -183,6 +183,45 @@ class SigmaEnv:
     def observe(self):
         self._chk(self.lib.observe(self.h), "observe")
 
+    # ---- QP-free CBF margin reward (sigmarl/cbf_qp.py:2534-2804) ------------------------------------------------------
+    def cbf_attach(self, cbf_cfg=None, seg_left=None, seg_right=None):
+        """Uploads the pseudo-distance segment tables of the env's map and the CBF constants.  Defaults: ``make_cbf_config`` of
+        the env's parameters and ``load_segment_tables`` of its map."""
+        from . import cbf
+
+        if cbf_cfg is None:
+            cbf_cfg = cbf.make_cbf_config(self.parameters)
+        if seg_left is None or seg_right is None:
+            seg_left, seg_right = cbf.load_segment_tables(self.map)
+        seg_left = np.ascontiguousarray(seg_left, np.float32)
+        seg_right = np.ascontiguousarray(seg_right, np.float32)
+        assert seg_left.shape == seg_right.shape and seg_left.shape[0] == self.map.n_paths and seg_left.shape[2] == cbf.SEG_FIELDS
+        self.cbf_cfg = cbf_cfg
+        with torch.cuda.device(self.device):
+            self._chk(self.lib.cbf_attach(self.h, C.byref(cbf_cfg), seg_left.ctypes.data_as(C.c_void_p), seg_right.ctypes.data_as(C.c_void_p),
+                                          int(seg_left.shape[1])), "cbf_attach")
+
+    def cbf_margin_count(self) -> int:
+        if getattr(self, "cbf_cfg", None) is None:
+            raise RuntimeError("sigmaenv cbf: cbf_attach has not been called")
+        Cc = int(self.cbf_cfg.n_circles)
+        return 2 * self.B * self.N * Cc + self.B * self.N * self.N * Cc * Cc
+
+    def cbf_rewards(self, actions: torch.Tensor, margins: torch.Tensor | None = None):
+        """``CBFQP.update_qp`` (``is_solve_qp=False``) for every env: writes rew_near_left_lane / rew_near_right_lane /
+        rew_near_other_agents of ``BUF_REWARD_INFO``; the next ``step`` adds them when ``rew_method`` contains "cbf".
+        ``margins``: optional float64 CUDA tensor with ``cbf_margin_count()`` elements (lane_left, lane_right, pair)."""
+        if not (isinstance(actions, torch.Tensor) and actions.is_cuda and actions.dtype == torch.float32 and actions.is_contiguous()):
+            raise TypeError("actions must be a contiguous float32 CUDA tensor")
+        if tuple(actions.shape) != (self.B, self.N, 2):
+            raise ValueError(f"actions must have shape {(self.B, self.N, 2)}, got {tuple(actions.shape)}")
+        mp = None
+        if margins is not None:
+            if not (margins.is_cuda and margins.dtype == torch.float64 and margins.is_contiguous() and margins.numel() == self.cbf_margin_count()):
+                raise TypeError("margins must be a contiguous float64 CUDA tensor with cbf_margin_count() elements")
+            mp = C.c_void_p(margins.data_ptr())
+        self._chk(self.lib.cbf_rewards(self.h, C.c_void_p(actions.data_ptr()), mp), "cbf_rewards")
+
     def step_autoreset(self, actions: torch.Tensor, seed: int = 0, counter: int | None = None, path_first: int | None = None,
                        path_count: int | None = None):
         """``step`` + ``auto_reset`` in one launch (same end state); the terminal observation goes to the slab only."""
@@ -254,6 +293,9 @@ class SigmaEnv:
         self.auto_reset(seed=seed)
 
 
+from .cbf import split_cbf_margins  # noqa: E402
+
+
 class NumpyAdapter:
     """Host-array facade over ``SigmaEnv`` with the interface of ``tests/oracle_binding.OracleEnv`` (used by the parity tests)."""
 
@@ -271,6 +313,16 @@ class NumpyAdapter:
 
     def observe(self):
         self.env.observe()
+
+    def cbf_attach(self, cbf_cfg, seg_left, seg_right):
+        self.env.cbf_attach(cbf_cfg, seg_left, seg_right)
+
+    def cbf_rewards(self, actions, want_margins=True):
+        a = torch.as_tensor(np.ascontiguousarray(actions, np.float32).reshape(self.B, self.N, 2)).to(self.env.device)
+        m = torch.full((self.env.cbf_margin_count(),), float("nan"), dtype=torch.float64, device=self.env.device) if want_margins else None
+        self.env.cbf_rewards(a, m)
+        self.env.sync()
+        return None if m is None else split_cbf_margins(m.cpu().numpy(), self.B, self.N, int(self.env.cbf_cfg.n_circles))
 
     def auto_reset(self, seed, counter, path_first, path_count):
         self.env.auto_reset(seed, counter, path_first, path_count)

@@ -35,6 +35,8 @@ class MapTable:
                 raise FileNotFoundError(f"no map table for scenario_type={scenario_type!r} ({path})")
             z = np.load(path)
         self.scenario_type = scenario_type
+        self.name = scenario_type
+        self.from_asset = table is None  # the shipped table (pseudo-distance segment assets exist for these only)
         self.n_paths = int(z["center"].shape[0])
         stride = max(z["center"].shape[1], z["left"].shape[1], z["right"].shape[1])
         self.stride = int(stride)

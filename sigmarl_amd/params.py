@@ -107,8 +107,18 @@ def check_supported(p: Parameters) -> None:
         bad.append("reset_agent_fixed_duration>0")
     if p.is_challenging_initial_state_buffer:
         bad.append("is_challenging_initial_state_buffer=True")
-    if p.is_using_cbf_testing or p.is_using_cbf_training:
-        bad.append("CBF-QP safety filter (BASELINE config 5)")
+    if p.is_using_cbf_testing:
+        bad.append("CBF-QP safety filter at test time (BASELINE config 5)")
+    if p.is_using_cbf_training or "cbf" in p.rew_method:
+        # only the QP-free margin reward of CBFQP.update_qp is built (sigmarl/cbf_qp.py:2534-2560)
+        if p.is_solve_qp:
+            bad.append("CBF-QP solver (is_solve_qp=True); the QP-free margin reward needs is_solve_qp=False")
+        if p.is_grouping_agents:
+            bad.append("is_grouping_agents=True")
+        if p.nom_controller_type != "rl":
+            bad.append(f"nom_controller_type={p.nom_controller_type!r} (only 'rl')")
+        if not 1 <= int(p.n_circles_approximate_vehicle) <= capi.CBF_MAX_CIRCLES:
+            bad.append(f"n_circles_approximate_vehicle={p.n_circles_approximate_vehicle}")
     if bad:
         raise NotImplementedError("sigmarl_amd: unsupported configuration for the fused environment step: " + "; ".join(bad))
 
@@ -133,7 +143,7 @@ def make_config(p: Parameters, map_table, n_envs: int, make_world_scenario_type:
     c.n_envs = int(n_envs)
     c.n_agents = n_agents
     c.distance_type = capi.DIST_MTV if mtv else capi.DIST_C2C
-    c.rew_flags = capi.rew_flags_from_method(p.rew_method)
+    c.rew_flags = capi.rew_flags_from_method(p.rew_method, bool(p.is_solve_qp))
     c.is_testing_mode = int(bool(p.is_testing_mode))
     c.has_entry_exit = int(p.scenario_type != "cpm_entire")
     c.max_steps = int(p.max_steps)

@@ -105,7 +105,50 @@ def follow_policy(obs, gen, B, N, mode):
     return torch.stack([v, s], dim=-1).to(torch.float32)
 
 
-def run_traj(name, T, B, seed, mode_pattern, no_reset=False, **pkw):
+class CbfHook:
+    """Runs the reference's QP-free CBF margin path before every env step, as ``cbf_constrained_centralized_policy`` does after
+    the policy (helper_training.py:1620-1627 -> cbf_qp.py:2534-2560), and records inputs, margins and the three reward channels."""
+
+    def __init__(self, env, B, N):
+        import types
+        from sigmarl.cbf_qp import CBFQP
+
+        self.env, self.B, self.N = env, B, N
+        fake = types.SimpleNamespace(base_env=types.SimpleNamespace(scenario_name=env.scenario))
+        self.ctl = [CBFQP(env=fake, env_idx=e) for e in range(B)]
+        self.C = int(env.scenario.parameters.n_circles_approximate_vehicle)
+
+    def meta(self):
+        c = self.ctl[0]
+        return dict(cbf_circle_radius=float(c.circle_radius), cbf_centers=[float(x) for x, _ in c.rec_cir_approx.centers],
+                    cbf_dt_taylor=float(c.dt_taylor), cbf_lambda=float(c.lambda_ttcbf), cbf_h_nom=float(c.parameters.h_nom),
+                    cbf_fd_step=float(c.dx), cbf_n_circles=self.C, numpy_version=np.__version__, torch_version=torch.__version__)
+
+    def __call__(self, act):
+        env, B, N, C = self.env, self.B, self.N, self.C
+        sc = env.scenario
+        ag = env.world.agents
+        td = {("agents", "info", "path_id"): sc.world_state.ref_paths_agent_related.path_id.clone(), ("agents", "action"): act.clone()}
+        rec = {
+            "cbf_in_state": np_(torch.stack([torch.cat([a.state.pos, a.state.rot, a.state.speed, a.state.steering], dim=-1) for a in ag], dim=1)),
+            "cbf_in_path": np_(td[("agents", "info", "path_id")]).astype(np.int32),
+        }
+        L = np.zeros((B, N, C)); R = np.zeros((B, N, C)); P = np.full((B, N, N, C, C), np.nan)
+        for e in range(B):
+            c = self.ctl[e]
+            c.time_pseudo_dis = 0
+            m = c.compute_nominal_cbf_constraint_margins(td)
+            L[e], R[e] = m["lane_L_margin"], m["lane_R_margin"]
+            for (i, j, ci, cj), g in m["pair_margin"].items():
+                P[e, i, j, ci, cj] = g
+            c.update_qp(td)  # writes reward_info.rew_near_{left_lane,right_lane,other_agents}[e]
+        rec["cbf_lane_left"], rec["cbf_lane_right"], rec["cbf_pair"] = L, R, P
+        ri = sc.reward_info
+        rec["cbf_rew"] = np.stack([np_(ri.rew_near_left_lane), np_(ri.rew_near_right_lane), np_(ri.rew_near_other_agents)], axis=0)
+        return rec
+
+
+def run_traj(name, T, B, seed, mode_pattern, no_reset=False, hook=None, **pkw):
     torch.manual_seed(seed)
     gen = torch.Generator().manual_seed(seed + 1000)
     kw = dict(
@@ -147,16 +190,19 @@ def run_traj(name, T, B, seed, mode_pattern, no_reset=False, **pkw):
     obs = env.observe()
     out = {}
     out.update(snapshot(env, "init_", with_obs=obs))
+    hook_obj = CbfHook(env, B, N) if hook == "cbf" else None
     steps = []
     for t in range(T):
         cur_step[0] = t
         act = follow_policy(obs, gen, B, N, mode)
+        hook_rec = hook_obj(act) if hook_obj is not None else {}
         env.set_actions(act)
         env.world.step()
         rew = [sc.reward(a).clone() for a in env.world.agents]
         obs = [sc.observation(a).clone() for a in env.world.agents]
         info = [refshim.TorchUtils.recursive_clone(sc.info(a)) for a in env.world.agents]
         rec = {"act": np_(act)}
+        rec.update(hook_rec)
         rec.update(snapshot(env, "post_", with_obs=obs, rew=rew))
         rec["post_act_clamped"] = np_(torch.stack([a.action.u for a in env.world.agents], dim=1))
         for key in ["rot", "distance_left_b", "distance_right_b", "is_collision_with_agents", "rew_total", "rew_near_other_agents", "rew_collide_lane"]:
@@ -198,6 +244,8 @@ def run_traj(name, T, B, seed, mode_pattern, no_reset=False, **pkw):
         n_col_agents=int(out["post_col_agents"].any(-1).sum()), n_col_lane=int(out["post_col_lane"].sum()),
         n_exit=int(out["post_col_exit"].sum()), n_entry=int(out["post_col_entry"].sum()),
     ))
+    if hook_obj is not None:
+        meta.update(hook_obj.meta())
     out["meta_json"] = np.asarray(json.dumps(meta))
     path = os.path.join(OUT, f"traj_{name}.npz")
     np.savez_compressed(path, **out)
@@ -350,6 +398,82 @@ def gen_functions():
     print("interX vs interX_original agreement on sampled cases:", agree)
 
 
+def gen_cbf_functions():
+    """Function-level goldens of the CBF margin path: PseudoDistance.get_distance (fp16 bit patterns) on many points, and
+    compute_nominal_cbf_constraint_margins / compute_cbf_violation_rewards_from_margins on directly set states (CPM, 16 agents)."""
+    import types
+    from sigmarl.cbf_qp import CBFQP
+
+    g = torch.Generator().manual_seed(31)
+    out = {}
+    B, N = 48, 16
+    p = Parameters(n_agents=N, scenario_type="cpm_entire", is_obs_noise=False, is_apply_mask=False, num_vmas_envs=B, dt=0.05,
+                   is_using_cbf_training=True, is_solve_qp=False, rew_method="cbf", is_challenging_initial_state_buffer=False)
+    env = refshim.RefEnv(p, B)
+    sc = env.scenario
+    pd = sc.map_pseudo_distance
+    paths = sc.map.parser.reference_paths
+    # P1: get_distance on points scattered around the centre lines (incl. far outside the lane)
+    q_pts, q_path, q_l, q_r = [], [], [], []
+    for pid in [0, 3, 11, 17, 26, 39]:
+        cl = paths[pid]["center_line"]
+        M = 1500
+        idx = torch.randint(0, cl.shape[0], (M,), generator=g)
+        spread = torch.where(torch.rand(M, 1, generator=g) < 0.85, torch.tensor(0.12), torch.tensor(0.6))
+        pts = (cl[idx] + (torch.rand(M, 2, generator=g) - 0.5) * 2 * spread).to(torch.float32)
+        dl, dr = pd.get_distance(pid, pts)
+        q_pts.append(np_(pts)); q_path.append(np.full(M, pid, np.int32))
+        q_l.append(dl.view(np.uint16).copy()); q_r.append(dr.view(np.uint16).copy())
+    out["p1_pts"], out["p1_path"] = np.concatenate(q_pts), np.concatenate(q_path)
+    out["p1_left_f16"], out["p1_right_f16"] = np.concatenate(q_l), np.concatenate(q_r)
+    # P2: margins on directly set states
+    ag = env.world.agents
+    path_id = torch.randint(0, len(paths), (B, N), generator=g)
+    state = torch.zeros(B, N, 5)
+    for b in range(B):
+        for i in range(N):
+            rp = paths[int(path_id[b, i])]
+            cl, yaw = rp["center_line"], rp["center_line_yaw"].reshape(-1)
+            k = int(torch.randint(1, cl.shape[0] - 1, (1,), generator=g))
+            off = (torch.rand(2, generator=g) - 0.5) * (0.08 if b % 4 else 0.2)
+            state[b, i, 0:2] = cl[k] + off
+            state[b, i, 2] = yaw[min(k, yaw.shape[0] - 1)] + (torch.rand(1, generator=g) - 0.5) * (0.6 if b % 3 else 2.5)
+            state[b, i, 3] = torch.rand(1, generator=g) * 1.2 - 0.2
+            state[b, i, 4] = (torch.rand(1, generator=g) - 0.5) * 1.0
+    # a few deliberately close pairs (pair-margin violations)
+    for b in range(0, B, 2):
+        state[b, 1, 0:2] = state[b, 0, 0:2] + torch.tensor([0.11, 0.05])
+        state[b, 1, 2] = state[b, 0, 2] + 0.4
+        path_id[b, 1] = path_id[b, 0]
+    state = state.to(torch.float32)
+    for i, a in enumerate(ag):
+        a.state.pos = state[:, i, 0:2].clone(); a.state.rot = state[:, i, 2:3].clone()
+        a.state.speed = state[:, i, 3:4].clone(); a.state.steering = state[:, i, 4:5].clone()
+    act = torch.stack([torch.rand(B, N, generator=g) * 1.8 - 0.6, (torch.rand(B, N, generator=g) - 0.5) * 1.4], dim=-1).to(torch.float32)
+    td = {("agents", "info", "path_id"): path_id.clone(), ("agents", "action"): act.clone()}
+    fake = types.SimpleNamespace(base_env=types.SimpleNamespace(scenario_name=sc))
+    C = int(p.n_circles_approximate_vehicle)
+    L = np.zeros((B, N, C)); R = np.zeros((B, N, C)); P = np.full((B, N, N, C, C), np.nan)
+    for e in range(B):
+        c = CBFQP(env=fake, env_idx=e)
+        c.time_pseudo_dis = 0
+        m = c.compute_nominal_cbf_constraint_margins(td)
+        L[e], R[e] = m["lane_L_margin"], m["lane_R_margin"]
+        for (i, j, ci, cj), gval in m["pair_margin"].items():
+            P[e, i, j, ci, cj] = gval
+        c.update_qp(td)
+    ri = sc.reward_info
+    out["p2_state"], out["p2_path"], out["p2_act"] = np_(state), np_(path_id).astype(np.int32), np_(act)
+    out["p2_lane_left"], out["p2_lane_right"], out["p2_pair"] = L, R, P
+    out["p2_rew"] = np.stack([np_(ri.rew_near_left_lane), np_(ri.rew_near_right_lane), np_(ri.rew_near_other_agents)], axis=0)
+    out["meta_json"] = np.asarray(json.dumps(dict(B=B, N=N, dt=p.dt, h_nom=p.h_nom, n_circles=C, scenario_type="cpm_entire",
+                                                  numpy_version=np.__version__, torch_version=torch.__version__)))
+    path = os.path.join(OUT, "cbf_functions.npz")
+    np.savez_compressed(path, **out)
+    print("cbf_functions", f"{os.path.getsize(path)/1e6:.2f} MB", "neg L/R/P", int((L < 0).sum()), int((R < 0).sum()), int((P < 0).sum()),
+          "rew nonzero", (out["p2_rew"] != 0).sum(axis=(1, 2)), "1000s", int((out["p1_left_f16"] == np.float16(1000).view(np.uint16)).sum()))
+
+
 TRAJS = {
     "cpm16_c2c": dict(T=32, B=4, seed=11, mode_pattern=[1, 0, 1, 1], n_agents=16, scenario_type="cpm_entire", dt=0.05,
                       is_use_mtv_distance=False, rew_method="distance"),
@@ -366,12 +490,19 @@ TRAJS = {
                              dt=0.1, is_use_mtv_distance=True, rew_method="distance_sparse"),
     "cpmmixed4_c2c": dict(T=48, B=4, seed=15, mode_pattern=[1, 0, 1, 1], n_agents=4, scenario_type="cpm_mixed", dt=0.05,
                           is_use_mtv_distance=False, rew_method="sparse", cpm_scenario_probabilities=[1.0, 0.0, 0.0]),
+    # rew_method "cbf" with the QP-free margin reward (is_solve_qp=False): cbf_qp.py:2534-2804 run before every step
+    "cpm16_cbf": dict(T=12, B=2, seed=21, mode_pattern=[1, 0], hook="cbf", n_agents=16, scenario_type="cpm_entire", dt=0.05,
+                      is_use_mtv_distance=False, rew_method="cbf", is_using_cbf_training=True, is_solve_qp=False),
+    "intersection4_cbf": dict(T=48, B=3, seed=22, mode_pattern=[1, 1, 0], hook="cbf", n_agents=4, scenario_type="intersection_1", dt=0.1,
+                              is_use_mtv_distance=True, rew_method="cbf_sparse", is_using_cbf_training=True, is_solve_qp=False),
 }
 
 if __name__ == "__main__":
-    names = sys.argv[1:] or (["functions"] + list(TRAJS))
+    names = sys.argv[1:] or (["functions", "cbf_functions"] + list(TRAJS))
     for nme in names:
         if nme == "functions":
             gen_functions()
+        elif nme == "cbf_functions":
+            gen_cbf_functions()
         else:
             run_traj(nme, **TRAJS[nme])

@@ -7,6 +7,8 @@ one documented exception (5e-5): the reference's formulation projects world coor
 import ctypes as C
 import os
 
+import json
+
 import numpy as np
 import pytest
 
@@ -140,9 +142,86 @@ def test_trajectory(name):
     rep = tr.replay(env, z, meta, mp)
     env.close()
     assert rep.total_mismatch() == 0, str(rep)  # masks, indices, counters, done: bit-exact
+    assert rep.cbf_ok(), str(rep)
     for key, err in rep.max_abs.items():
         tol = MTV_TOL if (meta["is_use_mtv_distance"] and key in ("dist_agents", "obs", "reward", "rew_total", "rew_near_other_agents")) else FTOL
         assert err <= tol, (key, err, str(rep))
+
+
+def _cbf_fixture():
+    z = np.load(os.path.join(tr.GOLDEN_DIR, "cbf_functions.npz"))
+    return z, json.loads(str(z["meta_json"]))
+
+
+def test_pseudo_distance_f16_bit_exact():
+    """PseudoDistance.get_distance (sigmarl/pseudo_distance.py:204-242): fp16 bit patterns of 9000 points x 2 boundaries."""
+    from sigmarl_amd import cbf
+
+    z, _ = _cbf_fixture()
+    mp = load_map("cpm_entire")
+    seg_l, seg_r = cbf.load_segment_tables(mp)
+    lib = ob.load_oracle()
+    for pid in np.unique(z["p1_path"]):
+        m = z["p1_path"] == pid
+        pts = np.ascontiguousarray(z["p1_pts"][m])
+        for poly, n, seg, want in ((mp.left, mp.n_left, seg_l, z["p1_left_f16"][m]), (mp.right, mp.n_right, seg_r, z["p1_right_f16"][m])):
+            out = np.zeros(len(pts), np.uint16)
+            lib.fn_pseudo_distance(len(pts), ob.ptr(pts), ob.ptr(np.ascontiguousarray(poly[pid])), ob.ptr(np.ascontiguousarray(seg[pid])),
+                                   int(n[pid]), ob.ptr(out))
+            assert np.array_equal(out, want), (int(pid), int((out != want).sum()))
+
+
+def cbf_case_env(make_env, z, meta):
+    """Env with the directly set states of the ``p2`` case of cbf_functions.npz (shared with the GPU test)."""
+    from sigmarl_amd import cbf
+    from sigmarl_amd.params import Parameters, make_config
+
+    B, N = meta["B"], meta["N"]
+    mp = load_map("cpm_entire")
+    p = Parameters(n_agents=N, scenario_type="cpm_entire", dt=meta["dt"], rew_method="cbf", is_solve_qp=False, is_using_cbf_training=True,
+                   h_nom=meta["h_nom"], is_obs_noise=False, is_apply_mask=False)
+    env = make_env(make_config(p, mp, B), mp)
+    seg_l, seg_r = cbf.load_segment_tables(mp)
+    env.cbf_attach(cbf.make_cbf_config(p), seg_l, seg_r)
+    st8 = np.zeros((B, N, 8), np.float32)
+    st8[..., :5] = z["p2_state"]
+    ids = np.zeros((B, N, 4), np.int32)
+    ids[..., 0] = z["p2_path"]
+    ids[..., 2] = z["p2_path"]
+    env.reset(np.repeat(np.arange(B), N), np.tile(np.arange(N), B), ids.reshape(-1, 4), st8.reshape(-1, 8), 1)
+    return env
+
+
+def test_cbf_margins_on_set_states():
+    """compute_nominal_cbf_constraint_margins + compute_cbf_violation_rewards_from_margins (sigmarl/cbf_qp.py:2562-2804) on 48 x 16
+    directly set vehicle states, incl. close pairs and agents far off their lane."""
+    z, meta = _cbf_fixture()
+    env = cbf_case_env(ob.OracleEnv, z, meta)
+    lane_l, lane_r, pair = env.cbf_rewards(z["p2_act"])
+    rep = tr.Report()
+    rep.cbf("lane_left", lane_l, z["p2_lane_left"])
+    rep.cbf("lane_right", lane_r, z["p2_lane_right"])
+    rep.cbf("pair", pair, z["p2_pair"])
+    ri = env.get(capi.BUF_REWARD_INFO)
+    rep.cbf("rew", np.stack([ri[5], ri[6], ri[4]]), z["p2_rew"])
+    env.close()
+    assert rep.cbf_ok(), str(rep)
+    assert (z["p2_pair"] < 0).sum() > 100 and (z["p2_lane_left"] < 0).sum() > 100  # the case exercises violations
+
+
+def test_own_segment_tables_close_to_reference_tables():
+    """sigmarl_amd.cbf.segment_tables (numpy) against the shipped tables (the reference's torch ops): identical lengths, angles within an ulp."""
+    from sigmarl_amd import cbf
+
+    mp = load_map("intersection_1")
+    seg_l, _ = cbf.load_segment_tables(mp)
+    for p in range(mp.n_paths):
+        n = int(mp.n_left[p])
+        own = cbf.segment_tables(mp.left[p, :n])
+        ref = seg_l[p, : n - 1]
+        assert np.array_equal(own[:, 4], ref[:, 4])
+        assert np.abs(own[:, :2] - ref[:, :2]).max() <= 1.2e-7
+        assert np.abs(own[:, 2:4] - ref[:, 2:4]).max() <= 1e-5
 
 
 def test_trajectory_fixtures_cover_events():

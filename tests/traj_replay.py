@@ -16,7 +16,15 @@ from sigmarl_amd.params import Parameters, make_config
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
-TRAJ_NAMES = ["cpm16_c2c", "cpm16_mtv", "intersection4_c2c", "onramp6_mtv", "cpm16_c2c_noreset", "cpm8_mtv_noreset", "cpmmixed4_c2c"]
+TRAJ_NAMES = ["cpm16_c2c", "cpm16_mtv", "intersection4_c2c", "onramp6_mtv", "cpm16_c2c_noreset", "cpm8_mtv_noreset", "cpmmixed4_c2c",
+              "cpm16_cbf", "intersection4_cbf"]
+# The reference rounds the pseudo distance to fp16 and differentiates it numerically (pseudo_distance.py:118, cbf_qp.py:624-644): a
+# one-ulp difference in a float32 circle centre (torch's SLEEF cos/sin vs the correctly rounded ones of oracle and HIP path) can flip
+# an fp16 rounding and move a margin by up to ~5e-3.  Against the reference goldens the CBF quantities are therefore checked as:
+# all but a fraction CBF_OUTLIER_FRAC within CBF_TOL (scaled by max(1, |value|)), every entry within CBF_OUTLIER_TOL.
+CBF_TOL = 2e-6
+CBF_OUTLIER_TOL = 2e-2
+CBF_OUTLIER_FRAC = 2e-3
 
 
 def load_fixture(name):
@@ -27,7 +35,7 @@ def load_fixture(name):
 
 def params_from_meta(meta) -> Parameters:
     keys = ["n_agents", "dt", "scenario_type", "is_use_mtv_distance", "rew_method", "is_testing_mode", "max_steps",
-            "is_obs_noise", "is_apply_mask", "cpm_scenario_probabilities"]
+            "is_obs_noise", "is_apply_mask", "cpm_scenario_probabilities", "is_using_cbf_training", "is_solve_qp"]
     kw = {k: meta[k] for k in keys if k in meta}
     return Parameters(**kw)
 
@@ -48,6 +56,7 @@ class Report:
         self.max_abs = {}
         self.mismatch = {}
         self.count = {}
+        self.cbf_bad, self.cbf_count, self.cbf_worst = {}, {}, {}
 
     def f(self, key, got, want):
         got = np.asarray(got, np.float64)
@@ -64,6 +73,22 @@ class Report:
         self.mismatch[key] = self.mismatch.get(key, 0) + int((got.astype(np.int64) != want.astype(np.int64)).sum())
         self.count[key] = self.count.get(key, 0) + int(got.size)
 
+    def cbf(self, key, got, want):
+        """CBF margins / rewards against the reference: counts entries beyond CBF_TOL, tracks the worst one."""
+        got = np.asarray(got, np.float64)
+        want = np.asarray(want, np.float64)
+        m = ~np.isnan(want)
+        d = np.abs(got[m] - want[m]) / np.maximum(1.0, np.abs(want[m]))
+        self.cbf_bad[key] = self.cbf_bad.get(key, 0) + int((d > CBF_TOL).sum())
+        self.cbf_count[key] = self.cbf_count.get(key, 0) + int(d.size)
+        self.cbf_worst[key] = max(self.cbf_worst.get(key, 0.0), float(d.max()) if d.size else 0.0)
+
+    def cbf_ok(self):
+        for k, n in self.cbf_count.items():
+            if self.cbf_worst[k] > CBF_OUTLIER_TOL or self.cbf_bad[k] > max(1, int(CBF_OUTLIER_FRAC * n)):
+                return False
+        return True
+
     def worst_float(self):
         return max(self.max_abs.values()) if self.max_abs else 0.0
 
@@ -73,7 +98,8 @@ class Report:
     def __str__(self):
         fl = ", ".join(f"{k}={v:.2e}" for k, v in sorted(self.max_abs.items(), key=lambda kv: -kv[1])[:8])
         mm = ", ".join(f"{k}={v}/{self.count[k]}" for k, v in self.mismatch.items() if v)
-        return f"max|err|: {fl} | mismatches: {mm or 'none'}"
+        cb = ", ".join(f"{k}: {self.cbf_bad[k]}/{n} beyond {CBF_TOL:g}, worst {self.cbf_worst[k]:.2e}" for k, n in self.cbf_count.items())
+        return f"max|err|: {fl} | mismatches: {mm or 'none'}" + (f" | cbf: {cb}" if cb else "")
 
 
 def compare_snapshot(rep: Report, env, z, prefix, t, envs=None, with_reward=False, with_obs=True):
@@ -164,7 +190,20 @@ def replay(env, z, meta, mp, steps=None, check_next=True) -> Report:
     T = int(meta["T"]) if steps is None else min(int(steps), int(meta["T"]))
     apply_initial_reset(env, z, mp)
     compare_snapshot(rep, env, z, "init_", None)
+    with_cbf = "cbf_in_state" in z.files
+    if with_cbf:
+        from sigmarl_amd import cbf
+
+        seg_l, seg_r = cbf.load_segment_tables(mp)
+        env.cbf_attach(cbf.make_cbf_config(params_from_meta(meta)), seg_l, seg_r)
     for t in range(T):
+        if with_cbf:  # CBFQP.update_qp runs after the policy, before the env step (helper_training.py:1620-1627)
+            lane_l, lane_r, pair = env.cbf_rewards(z["act"][t])
+            rep.cbf("cbf_lane_left", lane_l, z["cbf_lane_left"][t])
+            rep.cbf("cbf_lane_right", lane_r, z["cbf_lane_right"][t])
+            rep.cbf("cbf_pair", pair, z["cbf_pair"][t])
+            ri = env.get(capi.BUF_REWARD_INFO)
+            rep.cbf("cbf_rew", np.stack([ri[5], ri[6], ri[4]]), z["cbf_rew"][t])
         env.step(z["act"][t])
         compare_snapshot(rep, env, z, "post_", t, with_reward=True)
         rep.i("done", env.get(capi.BUF_DONE), z["done"][t])
