@@ -140,6 +140,19 @@ def test_cbf_own_segment_tables_on_compiled_map():
     ora.close()
 
 
+def test_cbf_full_scan_fallback_matches(monkeypatch):
+    """Without the chunk boxes (SIGMAENV_PRUNE=0) the kernel scans every segment: same margins as the pruned scan and the oracle."""
+    z, meta = _cbf_fixture()
+    monkeypatch.setenv("SIGMAENV_PRUNE", "0")
+    dev = cbf_case_env(_hip_env, z, meta)
+    monkeypatch.delenv("SIGMAENV_PRUNE")
+    ora = cbf_case_env(ob.OracleEnv, z, meta)
+    _cmp_margins(dev.cbf_rewards(z["p2_act"]), ora.cbf_rewards(z["p2_act"]), "full scan")
+    _cmp_rewards(dev, ora, "full scan")
+    dev.close()
+    ora.close()
+
+
 def test_cbf_requires_attach_and_rejects_qp():
     mp = load_map("cpm_entire")
     with pytest.raises(NotImplementedError):
