@@ -368,6 +368,15 @@ __device__ __forceinline__ void row16_min2_i32(int& a, int& b) {
                : "+v"(a), "+v"(b));
 }
 
+__device__ __forceinline__ void row16_or2_u32(unsigned& a, unsigned& b) {
+  asm volatile("s_nop 1\n\t"
+               SIGMA_DPP_ROW2("v_or_b32_dpp", "quad_perm:[1,0,3,2]")
+               SIGMA_DPP_ROW2("v_or_b32_dpp", "quad_perm:[2,3,0,1]")
+               SIGMA_DPP_ROW2("v_or_b32_dpp", "row_half_mirror")
+               SIGMA_DPP_ROW2("v_or_b32_dpp", "row_mirror")
+               : "+v"(a), "+v"(b));
+}
+
 // counter-based RNG (specification shared with the oracle): 32-bit multiplicative mix + murmur3 finalisers over (seed, counter, env, agent, draw)
 __device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint64_t counter, uint32_t env, uint32_t agent, uint32_t draw) {
   uint32_t h = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9E3779B9u);
