@@ -108,3 +108,53 @@ def split_cbf_margins(flat: np.ndarray, B: int, N: int, Cc: int):
     """(lane_left [B,N,C], lane_right [B,N,C], pair [B,N,N,C,C]) views of the flat margin record of ``sigmaenv_cbf_rewards``."""
     n1 = B * N * Cc
     return flat[:n1].reshape(B, N, Cc), flat[n1:2 * n1].reshape(B, N, Cc), flat[2 * n1:].reshape(B, N, N, Cc, Cc)
+
+
+class CBFQP:
+    """Mirror of ``sigmarl.cbf_qp.CBFQP`` for the QP-free margin reward (reference ``cbf_qp.py:325-364, 2534-2560``).
+
+    The reference builds one controller per env (``mappo_cavs.py:583``) and loops over them every step
+    (``helper_training.py:1620-1627``); here ONE launch serves the whole batch.  ``CBFQP(env=env)`` is the batched controller;
+    ``CBFQP(env=env, env_idx=e)`` keeps the reference's constructor so that a caller's list of per-env controllers still works: the
+    controller of env 0 launches for every env, the others are no-ops.  ``env`` is the object the reference passes: anything with
+    ``env.base_env.scenario_name`` being the ``sigmarl_amd`` scenario (or the scenario itself).
+    """
+
+    def __init__(self, env=None, env_idx: int | None = None, agent_idx: int | None = None, **kwargs):
+        sc = env
+        if hasattr(sc, "base_env"):
+            sc = sc.base_env.scenario_name
+        self.scenario = sc
+        self.env = env
+        self.env_idx = env_idx
+        self.agent_idx = agent_idx
+        self.parameters = sc.parameters
+        if self.parameters.is_solve_qp or self.parameters.is_grouping_agents:
+            raise NotImplementedError("sigmarl_amd.cbf.CBFQP: only the QP-free margin reward (is_solve_qp=False, no grouping) is built")
+        self.time_pseudo_dis = 0
+        self.cbf_solving_t = []
+        if getattr(sc.env, "cbf_cfg", None) is None:
+            sc.env.cbf_attach(make_cbf_config(self.parameters))
+
+    def update_qp(self, tensordict):
+        """``tensordict[("agents", "action")]``: the policy's actions [B, N, 2] (a mapping with that key, or the tensor itself)."""
+        self.time_pseudo_dis = 0
+        if self.env_idx not in (None, 0):
+            return
+        act = tensordict[("agents", "action")] if not hasattr(tensordict, "is_cuda") else tensordict
+        self.scenario.env.cbf_rewards(act.contiguous())
+
+
+def cbf_constrained_centralized_policy(tensordict, policy, cbf_controllers):
+    """``cbf_constrained_centralized_policy`` of the reference (``sigmarl/helper_training.py:1604-1635``): policy, then the CBF update."""
+    import time
+
+    t0 = time.time()
+    policy(tensordict)
+    time_rl = time.time() - t0
+    t0 = time.time()
+    time_pseudo_dis = 0
+    for c in cbf_controllers:
+        c.update_qp(tensordict)
+        time_pseudo_dis += c.time_pseudo_dis
+    return time_rl, time.time() - t0, time_pseudo_dis, tensordict

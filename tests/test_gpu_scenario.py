@@ -98,6 +98,39 @@ def test_scenario_matches_plain_env_on_golden_prefix():
     sc.env.close()
 
 
+def test_cbf_margin_reward_through_the_surface():
+    """rew_method "cbf_sparse" with the QP-free margin reward: CBFQP.update_qp (one launch for the batch) before every VMAS step
+    reproduces the reference's rewards (golden traj_intersection4_cbf: is_solve_qp=False, mtv distances)."""
+    import torch
+    from sigmarl_amd.cbf import CBFQP, cbf_constrained_centralized_policy
+    from sigmarl_amd.env import NumpyAdapter
+    from sigmarl_amd.scenario import make_scenario
+
+    z, meta = tr.load_fixture("intersection4_cbf")
+    p = tr.params_from_meta(meta)
+    assert p.rew_method == "cbf_sparse" and not p.is_solve_qp
+    sc = make_scenario(p)
+    sc.env_make_world(meta["B"], "cuda:0", n_agents=meta["n_agents"])
+    ad = NumpyAdapter(sc.env)
+    tr.apply_initial_reset(ad, z, sc.map)
+    controllers = [CBFQP(env=sc, env_idx=e) for e in range(meta["B"])]  # the reference's per-env list (mappo_cavs.py:583)
+    n_cbf = 0
+    for t in range(meta["T"]):
+        act = torch.as_tensor(z["act"][t]).cuda()
+        td = {}
+        cbf_constrained_centralized_policy(td, lambda d: d.__setitem__(("agents", "action"), act), controllers)
+        ch = torch.stack([sc.reward_info.rew_near_left_lane, sc.reward_info.rew_near_right_lane, sc.reward_info.rew_near_other_agents]).cpu().numpy()
+        assert np.abs(ch - z["cbf_rew"][t]).max() <= 1e-5
+        n_cbf += int((ch != 0).sum())
+        obs, rew, done, info = _vmas_step(sc, act)
+        assert np.abs(torch.stack(rew, 1).cpu().numpy() - z["post_reward"][t]).max() <= 5e-5  # mtv tolerance (see test_gpu_parity)
+        assert np.array_equal(done.cpu().numpy(), z["done"][t])
+        if tr.apply_events(ad, z, sc.map, t):
+            ad.observe()
+    assert n_cbf > 100
+    sc.env.close()
+
+
 @pytest.mark.parametrize("scen,N,testing", [("intersection_1", 4, False), ("on_ramp_1", 4, False), ("cpm_entire", 4, True)])
 def test_host_driven_agent_resets(scen, N, testing):
     """Non-loop maps / testing mode: done() performs the per-agent resets (torch RNG) the reference performs there.
