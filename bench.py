@@ -91,6 +91,8 @@ def main():
                     "(envs are independent: same total work per step, the shards' latency-bound phases overlap the others' scan)")
     ap.add_argument("--policy", action="store_true", help="widening (SURVEY 8f-3): the actor MLP runs on the device before every step "
                     "(sigmaenv_actor_forward, MFMA bf16) instead of replaying precomputed actions; reported in config.policy")
+    ap.add_argument("--cbf", action="store_true", help="widening (SURVEY 8f-4): rew_method='cbf' with the QP-free CBF margin reward "
+                    "(sigmaenv_cbf_rewards before every step); reported in config.cbf")
     ap.add_argument("--exchange", choices=["alltoall", "gather"], default="alltoall",
                     help="N > 1: how the rollout buffer is concatenated.  alltoall: distributed over the ranks by time slices (every rank "
                          "receives 1/N of the steps of ALL envs -- a data-parallel learner; the record crosses xGMI once, over all links); "
@@ -132,6 +134,8 @@ def main():
     B, N = args.envs_per_gpu, args.agents
     params_kw = dict(n_agents=N, scenario_type="cpm_entire", dt=0.05, is_use_mtv_distance=(args.distance == "mtv"), rew_method="distance",
                      is_apply_mask=False, is_obs_noise=False, max_steps=128, num_vmas_envs=B)
+    if args.cbf:
+        params_kw.update(rew_method="cbf", is_solve_qp=False, is_using_cbf_training=True)
     # env shards of this GPU: S handles of B / S envs, each on its own HIP stream (no cross-env dependency anywhere in the path)
     # (only when every shard still fills the GPU's CUs with whole tiles; small batches are launch-bound and stay in one piece)
     S = args.streams if (args.streams >= 1 and B % max(1, args.streams) == 0 and (B // max(1, args.streams)) * N >= 64 * int(os.environ.get("BENCH_MIN_TILES", "512"))) else 1
@@ -147,6 +151,8 @@ def main():
             kw = dict(params_kw, num_vmas_envs=Bs)
             e = SigmaEnv(Parameters(**kw), n_envs=Bs, device=device, envs_per_group=(max(1, 64 // N) if S > 1 else 0))
             e.reset_random(seed=seed * 64 + k)
+            if args.cbf:
+                e.cbf_attach()
             envs.append(e)
     env = envs[0]
     gen = torch.Generator(device=device).manual_seed(seed)
@@ -215,7 +221,7 @@ def main():
             base = slot.data_ptr()
         ap = act_ptrs[t % n_act]
         cnt = counter[0]
-        if fused and not args.policy:  # ONE binding call: every shard's record target + fused step / record / reset launch
+        if fused and not args.policy and not args.cbf:  # ONE binding call: every shard's record target + fused step / record / reset launch
             for k in range(S):
                 slab_arr[k] = (base + k * Bs * W * 4) if base else None
             rc = many(h_arr, S, act_arrs[t % n_act], slab_arr if base else None, seed_arr, cnt, pf, pc)
@@ -228,6 +234,11 @@ def main():
             for k, e in enumerate(envs):
                 actors[k].forward(e, act_bufs[k], seed=shard_seeds[k], counter=cnt)
                 e.step_autoreset_ptr(act_bufs[k].data_ptr(), shard_seeds[k], cnt, pf, pc)
+        elif fused and args.cbf:  # margin rewards of the action about to be applied, then the fused step that consumes them
+            a = acts[t % n_act]
+            for k, e in enumerate(envs):
+                e.cbf_rewards(a[k * Bs:(k + 1) * Bs])
+                e.step_autoreset_ptr(ap[k], shard_seeds[k], cnt, pf, pc)
         elif fused:
             pass  # done above
         else:
@@ -314,12 +325,14 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {
-            "workload": f"cpm_entire map, {N} agents x {B} envs per GPU ({B * world} envs total), {args.distance} distance, rew_method=distance, "
+            "workload": f"cpm_entire map, {N} agents x {B} envs per GPU ({B * world} envs total), {args.distance} distance, rew_method={params_kw['rew_method']}, "
                         f"dt=0.05, obs_dim={env.D}, fused step + device-side reset of finished envs "
                         + ("(one launch)" if fused else "(two launches)" if not args.no_reset else "(resets disabled)") + ((" + rollout record" + ((" + " + gather.mode) if gather.collective else "")) if gather else ""),
             "n_agents": N, "envs_per_gpu": B, "envs_total": B * world, "distance": args.distance, "env_shards_per_gpu": S,
             "policy": ("actor MLP 32-256-256-256-4 (bf16 MFMA, TanhNormal sample) on device before every step" if args.policy
                        else "none in the timed region (precomputed actions resident in HBM)"),
+            **({"cbf": "QP-free CBF margin reward (sigmaenv_cbf_rewards: 3 circles per vehicle, 9-point fp16 pseudo-distance stencils to both "
+                       "boundaries, float64 margins) launched before every step"} if args.cbf else {}),
             "resets_per_step_per_gpu": dones / max(1, args.steps), "rollout_gather": gather_state["note"] or gather_note,
         },
         "roofline": {
