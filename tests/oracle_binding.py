@@ -21,8 +21,8 @@ _f32p = C.POINTER(C.c_float)
 
 
 def build_oracle(force: bool = False) -> str:
-    src = os.path.join(ORACLE_DIR, "sigmaenv_oracle.c")
-    if force or not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("sigmaenv_oracle.c", "sigmaenv_cbf_oracle.inc")] + [os.path.join(ROOT, "include", "sigmaenv.h")]
+    if force or not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-B", "libsigmaenv_oracle.so"], stdout=subprocess.DEVNULL)
     return ORACLE_SO
 
