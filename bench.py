@@ -233,6 +233,8 @@ def main():
         if fused and args.policy:  # policy on device, then the fused step on the actions it wrote
             for k, e in enumerate(envs):
                 actors[k].forward(e, act_bufs[k], seed=shard_seeds[k], counter=cnt)
+                if args.cbf:
+                    e.cbf_rewards(act_bufs[k])
                 e.step_autoreset_ptr(act_bufs[k].data_ptr(), shard_seeds[k], cnt, pf, pc)
         elif fused and args.cbf:  # margin rewards of the action about to be applied, then the fused step that consumes them
             a = acts[t % n_act]

@@ -26,15 +26,15 @@ def _emulated(mlp, obs):
     return x
 
 
-def _setup(B=64, N=16, seed=0):
+def _setup(B=64, N=16, seed=0, **pkw):
     import torch
     from sigmarl_amd.actor import Actor, make_mlp
     from sigmarl_amd.env import SigmaEnv
     from sigmarl_amd.params import Parameters
 
     torch.manual_seed(seed)
-    env = SigmaEnv(Parameters(n_agents=N, scenario_type="cpm_entire", is_use_mtv_distance=False, is_apply_mask=False, is_obs_noise=False), n_envs=B,
-                   device="cuda:0")
+    env = SigmaEnv(Parameters(n_agents=N, scenario_type="cpm_entire", is_use_mtv_distance=False, is_apply_mask=False, is_obs_noise=False, **pkw),
+                   n_envs=B, device="cuda:0")
     env.reset_random(seed=3)
     mlp = make_mlp(env.D)
     with torch.no_grad():  # larger weights than the default init so that tanh saturates somewhere and the last layer matters
@@ -124,6 +124,38 @@ def test_rollout_without_the_host_equals_stepwise_calls():
     assert torch.equal(slab, slab2)
     assert torch.equal(env.obs, env2.obs) and torch.equal(env.state, env2.state)
     assert torch.isfinite(lp).all() and float(slab[..., -1].sum()) >= 0
+    for e in (env, env2):
+        e.close()
+    actor.close()
+    actor2.close()
+
+
+def test_rollout_with_cbf_margin_reward_equals_stepwise_calls():
+    """rew_method "cbf": sigmaenv_rollout runs policy -> CBF margin launch -> fused step per step, like the calls issued one by one."""
+    from sigmarl_amd import capi
+    from sigmarl_amd.shard import slab_width
+    kw = dict(rew_method="cbf_sparse", is_solve_qp=False, is_using_cbf_training=True)
+    torch, env, mlp, actor = _setup(B=48, N=16, seed=2, **kw)
+    _, env2, _, _ = _setup(B=48, N=16, seed=2, **kw)
+    actor2 = __import__("sigmarl_amd.actor", fromlist=["Actor"]).Actor(mlp, low=[-1.0, -0.6], high=[1.0, 0.6])
+    for e in (env, env2):
+        e.cbf_attach()
+    T, W = 5, slab_width(env.N, env.D)
+    slab, slab2 = torch.zeros((T, env.B, W), device="cuda"), torch.zeros((T, env.B, W), device="cuda")
+    actor.rollout(env, T, slab=slab, seed=4, counter0=50)
+    env.sync()
+    a = torch.zeros((env2.B, env2.N, 2), device="cuda")
+    seen = 0
+    for t in range(T):
+        actor2.forward(env2, a, seed=4, counter=50 + t)
+        env2.cbf_rewards(a)
+        env2.set_slab(slab2[t])
+        env2.step_autoreset(a, seed=4, counter=50 + t)
+        env2.sync()
+        seen += int((env2.buffer(capi.BUF_REWARD_INFO)[4:7] != 0).sum())
+    assert seen > 0  # the margin channels were non-trivial
+    assert torch.equal(slab, slab2)
+    assert torch.equal(env.buffer(capi.BUF_REWARD_INFO), env2.buffer(capi.BUF_REWARD_INFO)) and torch.equal(env.state, env2.state)
     for e in (env, env2):
         e.close()
     actor.close()
