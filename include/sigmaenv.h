@@ -231,10 +231,11 @@ int sigmaenv_rollout(sigmaenv_t* h, sigmaenv_actor_t* a, int32_t n_steps, float*
  * finite-difference gradient / Hessian, sigmarl/pseudo_distance.py:69-242 + cbf_qp.py:575-665; pair margins between the covering
  * circles of every two vehicles :2688-2754; second-order Taylor CBF coefficients :2283-2489) and the three reward channels derived
  * from them (compute_cbf_violation_rewards_from_margins :2762-2804), for all envs in one launch instead of one Python object per
- * env (helper_training.py:1620-1627).  Nominal controller "rl" (:2605-2615), no observation noise. */
+ * env (helper_training.py:1620-1627).  Nominal controllers "rl" (:2605-2615, the policy's action) and "clf" (:2616-2628, a P controller
+ * towards the third short-term reference point); no observation noise. */
 typedef struct sigmaenv_cbf_config {
   int32_t n_circles;        /* Parameters.n_circles_approximate_vehicle, 1..SIGMAENV_CBF_MAX_CIRCLES */
-  int32_t reserved;
+  int32_t nominal;          /* Parameters.nom_controller_type: 0 = "rl" (cbf_qp.py:2605-2615), 1 = "clf" (:2616-2628) */
   double dt_taylor;         /* cbf_qp.py:370-371: 2 * Parameters.dt */
   double lambda_ttcbf;      /* :404 (0.5) */
   double h_nom;             /* Parameters.h_nom */
@@ -245,6 +246,7 @@ typedef struct sigmaenv_cbf_config {
   double l_r, l_wb;         /* constants.py:634-635 (compute_dstate_2nd_time, cbf_qp.py:667-695) */
   float min_speed, min_steering; /* constants.py:637-640; the maxima, acceleration and steering-rate limits come from the env config */
   float reserved2[2];
+  double k_clf_speed, k_clf_heading, ref_speed; /* "clf" nominal controller, cbf_qp.py:408-417 (defaults 1, 1, 1 m/s) */
 } sigmaenv_cbf_config_t;
 
 /* seg_left / seg_right: HOST pointers f32 [n_paths, seg_stride, 5] = per boundary segment (cos, sin, m_b, m_t, length): the

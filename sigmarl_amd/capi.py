@@ -63,11 +63,11 @@ class CbfConfig(C.Structure):
     """``sigmaenv_cbf_config_t``."""
 
     _fields_ = [
-        ("n_circles", C.c_int32), ("reserved", C.c_int32),
+        ("n_circles", C.c_int32), ("nominal", C.c_int32),
         ("dt_taylor", C.c_double), ("lambda_ttcbf", C.c_double), ("h_nom", C.c_double), ("fd_step", C.c_double),
         ("safety_buffer", C.c_double), ("circle_radius", C.c_double), ("circle_x", C.c_double * CBF_MAX_CIRCLES),
         ("l_r", C.c_double), ("l_wb", C.c_double), ("min_speed", C.c_float), ("min_steering", C.c_float),
-        ("reserved2", C.c_float * 2),
+        ("reserved2", C.c_float * 2), ("k_clf_speed", C.c_double), ("k_clf_heading", C.c_double), ("ref_speed", C.c_double),
     ]
 
 

@@ -115,8 +115,8 @@ def check_supported(p: Parameters) -> None:
             bad.append("CBF-QP solver (is_solve_qp=True); the QP-free margin reward needs is_solve_qp=False")
         if p.is_grouping_agents:
             bad.append("is_grouping_agents=True")
-        if p.nom_controller_type != "rl":
-            bad.append(f"nom_controller_type={p.nom_controller_type!r} (only 'rl')")
+        if p.nom_controller_type not in ("rl", "clf"):
+            bad.append(f"nom_controller_type={p.nom_controller_type!r}")
         if not 1 <= int(p.n_circles_approximate_vehicle) <= capi.CBF_MAX_CIRCLES:
             bad.append(f"n_circles_approximate_vehicle={p.n_circles_approximate_vehicle}")
     if bad:

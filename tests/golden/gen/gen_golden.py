@@ -128,7 +128,8 @@ class CbfHook:
         env, B, N, C = self.env, self.B, self.N, self.C
         sc = env.scenario
         ag = env.world.agents
-        td = {("agents", "info", "path_id"): sc.world_state.ref_paths_agent_related.path_id.clone(), ("agents", "action"): act.clone()}
+        td = {("agents", "info", "path_id"): sc.world_state.ref_paths_agent_related.path_id.clone(), ("agents", "action"): act.clone(),
+              ("agents", "info", "ref"): sc.world_state.ref_paths_agent_related.short_term.reshape(B, N, -1).clone()}
         rec = {
             "cbf_in_state": np_(torch.stack([torch.cat([a.state.pos, a.state.rot, a.state.speed, a.state.steering], dim=-1) for a in ag], dim=1)),
             "cbf_in_path": np_(td[("agents", "info", "path_id")]).astype(np.int32),
@@ -495,6 +496,9 @@ TRAJS = {
                       is_use_mtv_distance=False, rew_method="cbf", is_using_cbf_training=True, is_solve_qp=False),
     "intersection4_cbf": dict(T=48, B=3, seed=22, mode_pattern=[1, 1, 0], hook="cbf", n_agents=4, scenario_type="intersection_1", dt=0.1,
                               is_use_mtv_distance=True, rew_method="cbf_sparse", is_using_cbf_training=True, is_solve_qp=False),
+    # "clf" nominal controller (cbf_qp.py:2616-2628): the margins are evaluated at a P controller's action instead of the policy's
+    "onramp4_cbf_clf": dict(T=24, B=3, seed=23, mode_pattern=[1, 0, 1], hook="cbf", n_agents=4, scenario_type="on_ramp_1", dt=0.05,
+                            is_use_mtv_distance=False, rew_method="cbf", is_using_cbf_training=True, is_solve_qp=False, nom_controller_type="clf"),
 }
 
 if __name__ == "__main__":

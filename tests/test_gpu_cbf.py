@@ -63,22 +63,23 @@ def test_cbf_set_states_vs_oracle_and_reference():
 
 
 CASES = [
-    # scenario, N, B, circles, rew_method, dt, steps
-    ("cpm_entire", 16, 40, 3, "cbf", 0.05, 8),
-    ("cpm_entire", 5, 33, 2, "cbf_sparse", 0.1, 8),     # ragged sizes, two circles
-    ("intersection_1", 4, 24, 4, "cbf", 0.1, 10),        # non-loop map, four circles
-    ("on_ramp_1", 6, 17, 1, "cbf_sparse", 0.05, 8),      # one circle: the centre only
-    ("cpm_entire", 32, 6, 3, "cbf", 0.05, 4),
+    # scenario, N, B, circles, rew_method, dt, steps, nominal controller
+    ("cpm_entire", 16, 40, 3, "cbf", 0.05, 8, "rl"),
+    ("cpm_entire", 5, 33, 2, "cbf_sparse", 0.1, 8, "rl"),     # ragged sizes, two circles
+    ("intersection_1", 4, 24, 4, "cbf", 0.1, 10, "rl"),        # non-loop map, four circles
+    ("on_ramp_1", 6, 17, 1, "cbf_sparse", 0.05, 8, "rl"),      # one circle: the centre only
+    ("cpm_entire", 32, 6, 3, "cbf", 0.05, 4, "rl"),
+    ("cpm_entire", 8, 21, 3, "cbf", 0.05, 8, "clf"),           # margins at the CLF controller's action
 ]
 
 
-@pytest.mark.parametrize("scen,N,B,Cc,rew,dt,steps", CASES)
-def test_cbf_rollout_vs_oracle(scen, N, B, Cc, rew, dt, steps):
+@pytest.mark.parametrize("scen,N,B,Cc,rew,dt,steps,nom", CASES)
+def test_cbf_rollout_vs_oracle(scen, N, B, Cc, rew, dt, steps, nom):
     """Seeded rollouts with the margin rewards computed before every step and consumed by the step's reward (rew_method "cbf...")."""
     from test_gpu_parity import _compare_all
 
     p = Parameters(n_agents=N, scenario_type=scen, rew_method=rew, dt=dt, is_solve_qp=False, is_using_cbf_training=True, is_apply_mask=False,
-                   is_obs_noise=False, max_steps=6, n_circles_approximate_vehicle=Cc, is_use_mtv_distance=False)
+                   is_obs_noise=False, max_steps=6, n_circles_approximate_vehicle=Cc, is_use_mtv_distance=False, nom_controller_type=nom)
     mp = load_map(scen)
     cfg = make_config(p, mp, B)
     assert cfg.rew_flags & capi.REW_CBF
