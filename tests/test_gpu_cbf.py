@@ -114,6 +114,43 @@ def test_cbf_rollout_vs_oracle(scen, N, B, Cc, rew, dt, steps, nom):
     ora.close()
 
 
+def test_cbf_full_size_sample_vs_oracle():
+    """BASELINE size (16 agents x 4096 envs): after a few steps the reward channels of the first and the last 96 envs equal the oracle's
+    on the same states; every channel of every env is finite and in [-1, 0]."""
+    import torch
+    from sigmarl_amd.env import SigmaEnv
+
+    B, N, S = 4096, 16, 96
+    p = Parameters(n_agents=N, scenario_type="cpm_entire", rew_method="cbf", dt=0.05, is_solve_qp=False, is_using_cbf_training=True,
+                   is_apply_mask=False, is_obs_noise=False, is_use_mtv_distance=False)
+    env = SigmaEnv(p, n_envs=B, device="cuda:0")
+    env.reset_random(seed=11)
+    env.cbf_attach()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for t in range(6):
+        act = torch.stack([torch.rand(B, N, generator=g, device="cuda") * 1.4 - 0.2, torch.rand(B, N, generator=g, device="cuda") * 1.0 - 0.5], -1).contiguous()
+        env.cbf_rewards(act)
+        if t < 5:
+            env.step_autoreset(act, seed=2)
+    env.sync()
+    ch = env.buffer(capi.BUF_REWARD_INFO)[4:7]
+    assert torch.isfinite(ch).all() and float(ch.min()) >= -1.0 and float(ch.max()) <= 0.0
+    assert int((ch < 0).sum()) > 1000
+    mp = env.map
+    seg_l, seg_r = cbf.load_segment_tables(mp)
+    for lo in (0, B - S):
+        ora = ob.OracleEnv(make_config(p, mp, S), mp)
+        ora.cbf_attach(cbf.make_cbf_config(p), seg_l, seg_r)
+        st = env.buffer(capi.BUF_STATE)[lo:lo + S].cpu().numpy()
+        pa = env.buffer(capi.BUF_PATH)[lo:lo + S].cpu().numpy()
+        ora.reset(np.repeat(np.arange(S), N), np.tile(np.arange(N), S), pa.reshape(-1, 4), st.reshape(-1, 8), 1)
+        ora.cbf_rewards(act[lo:lo + S].cpu().numpy(), want_margins=False)
+        d = np.abs(ch[:, lo:lo + S].cpu().numpy() - ora.get(capi.BUF_REWARD_INFO)[4:7])
+        assert d.max() <= REW_TOL, (lo, d.max())
+        ora.close()
+    env.close()
+
+
 def test_cbf_own_segment_tables_on_compiled_map():
     """A map without a shipped table asset (compiled by sigmarl_amd.mapc): the tables come from sigmarl_amd.cbf.segment_tables."""
     from sigmarl_amd import mapc
