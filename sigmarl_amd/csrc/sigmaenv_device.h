@@ -368,6 +368,14 @@ __device__ __forceinline__ void row16_min2_i32(int& a, int& b) {
                : "+v"(a), "+v"(b));
 }
 
+__device__ __forceinline__ void row16_max2(float& a, float& b) {
+  asm volatile("s_nop 1\n\t"
+               SIGMA_DPP_ROW2("v_max_f32_dpp", "quad_perm:[1,0,3,2]")
+               SIGMA_DPP_ROW2("v_max_f32_dpp", "quad_perm:[2,3,0,1]")
+               SIGMA_DPP_ROW2("v_max_f32_dpp", "row_half_mirror")
+               SIGMA_DPP_ROW2("v_max_f32_dpp", "row_mirror")
+               : "+v"(a), "+v"(b));
+}
 __device__ __forceinline__ void row16_or2_u32(unsigned& a, unsigned& b) {
   asm volatile("s_nop 1\n\t"
                SIGMA_DPP_ROW2("v_or_b32_dpp", "quad_perm:[1,0,3,2]")
