@@ -247,6 +247,12 @@ typedef struct sigmaenv_cbf_config {
   float min_speed, min_steering; /* constants.py:637-640; the maxima, acceleration and steering-rate limits come from the env config */
   float reserved2[2];
   double k_clf_speed, k_clf_heading, ref_speed; /* "clf" nominal controller, cbf_qp.py:408-417 (defaults 1, 1, 1 m/s) */
+  /* centralized CBF-QP (sigmaenv_cbf_qp), cbf_qp.py:409-433, 914-927 */
+  double qp_w_acc, qp_w_steer;   /* nom_weight = diag(10, 1): tracking cost sum ((u - u_nom) @ nom_weight)^2 */
+  double qp_w_lane, qp_w_pair;   /* lane_slack_weight, pair_slack_weight (1e9) */
+  double qp_w_clf;               /* w_clf_relax (1) */
+  double qp_w_lambda;            /* lambda_weight (1e3) when Parameters.adaptive_lambda, else 0 (:924-927) */
+  double lam_clf;                /* lam_clf (2) */
 } sigmaenv_cbf_config_t;
 
 /* seg_left / seg_right: HOST pointers f32 [n_paths, seg_stride, 5] = per boundary segment (cos, sin, m_b, m_t, length): the
@@ -259,6 +265,22 @@ int sigmaenv_cbf_attach(sigmaenv_t* h, const sigmaenv_cbf_config_t* cfg, const f
  * sigmaenv_step adds to the reward when SIGMAENV_REW_CBF is set.  margins: optional DEVICE f64 buffer receiving
  * lane_left [B,N,C], lane_right [B,N,C], pair [B,N,N,C,C] (entries with i < j), back to back; NULL to skip. */
 int sigmaenv_cbf_rewards(sigmaenv_t* h, const float* actions, double* margins);
+
+/* The centralized CBF-QP safety filter of every env (CBFQP.update_centralized_cbf_qp with Parameters.is_solve_qp,
+ * sigmarl/cbf_qp.py:733-1019 problem, :1019-1400 data + solve): per env
+ *     min  sum_i |(u_i - u_nom_i) W|^2 + w_lane |s_lane|^2 + w_pair |s_pair|^2 + w_clf (|s_head|^2 + |s_speed|^2) [+ w_lambda |lambda|^2]
+ *     s.t. a_min <= u_i0 <= a_max, rate_min <= u_i1 <= rate_max, s >= 0, 0 <= lambda <= 1,
+ *          lane (i, c, side):      A u_i + b0 + h lambda >= -s          (ttcbf_lane_affine_coeffs, adaptive branch :2341-2369)
+ *          pair (i < j, ci, cj):   A_i u_i + A_j u_j + b0 + h lambda >= -s   (ttcbf_pair_affine_coeffs :2406-2447)
+ *          CLF (i):  -e_head u_i1 + lam_clf e_head^2 / 2 <= s_head,  -e_speed u_i0 + lam_clf e_speed^2 / 2 <= s_speed   ("clf" only)
+ * with the data of sigmaenv_cbf_rewards.  The reference hands the problem to cvxpy / OSQP (eps 1e-5, polished); here every slack
+ * and lambda is eliminated in closed form (each appears in one constraint) and the remaining strictly convex, piecewise quadratic
+ * problem in the 2N controls is solved to machine precision by a projected Newton method -- the same minimiser, not the same
+ * iterates.  actions: DEVICE f32 [B,N,2] policy actions.  actions_safe: DEVICE f32 [B,N,2] = u_to_rl_action(u*, v, steering)
+ * (:499-525): what the reference writes into the action tensor when is_apply_cbf_action, and into
+ * world_state.nominal_action_{vel,steer} otherwise.  u_opt (optional): DEVICE f64 [B,N,2] the minimiser (acceleration, steering
+ * rate).  info (optional): DEVICE i32 [B,2] = Newton iterations, converged flag. */
+int sigmaenv_cbf_qp(sigmaenv_t* h, const float* actions, float* actions_safe, double* u_opt, int32_t* info);
 
 #ifdef __cplusplus
 }

@@ -68,6 +68,8 @@ class CbfConfig(C.Structure):
         ("safety_buffer", C.c_double), ("circle_radius", C.c_double), ("circle_x", C.c_double * CBF_MAX_CIRCLES),
         ("l_r", C.c_double), ("l_wb", C.c_double), ("min_speed", C.c_float), ("min_steering", C.c_float),
         ("reserved2", C.c_float * 2), ("k_clf_speed", C.c_double), ("k_clf_heading", C.c_double), ("ref_speed", C.c_double),
+        ("qp_w_acc", C.c_double), ("qp_w_steer", C.c_double), ("qp_w_lane", C.c_double), ("qp_w_pair", C.c_double), ("qp_w_clf", C.c_double),
+        ("qp_w_lambda", C.c_double), ("lam_clf", C.c_double),
     ]
 
 
@@ -120,6 +122,7 @@ _SIGS = {
     "sync": (C.c_int, [C.c_void_p]),
     "cbf_attach": (C.c_int, [C.c_void_p, C.POINTER(CbfConfig), C.c_void_p, C.c_void_p, C.c_int32]),
     "cbf_rewards": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cbf_qp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 _PRODUCT_ONLY = {
     "step_time_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),

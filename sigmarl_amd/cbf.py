@@ -105,6 +105,12 @@ def make_cbf_config(p, n_circles: int | None = None):
     c.k_clf_speed = float(getattr(p, "k_clf_speed", 1.0))  # cbf_qp.py:408-417 (read with getattr there as well)
     c.k_clf_heading = float(getattr(p, "k_clf_heading", 1.0))
     c.ref_speed = float(getattr(p, "ref_speed", 1.0))
+    # centralized QP weights, cbf_qp.py:409-433 (nom_weight = diag(10, 1); the lambda penalty only with Parameters.adaptive_lambda, :924-927)
+    c.qp_w_acc, c.qp_w_steer = 10.0, 1.0
+    c.qp_w_lane = c.qp_w_pair = 1e9
+    c.qp_w_clf = float(getattr(p, "w_clf_relax", 1.0))
+    c.qp_w_lambda = 1e3 if bool(getattr(p, "adaptive_lambda", False)) else 0.0
+    c.lam_clf = float(getattr(p, "lam_clf", 2.0))
     return c
 
 

@@ -222,6 +222,24 @@ class SigmaEnv:
             mp = C.c_void_p(margins.data_ptr())
         self._chk(self.lib.cbf_rewards(self.h, C.c_void_p(actions.data_ptr()), mp), "cbf_rewards")
 
+    def cbf_qp(self, actions: torch.Tensor, actions_safe: torch.Tensor | None = None, u_opt: torch.Tensor | None = None, info: torch.Tensor | None = None):
+        """The centralized CBF-QP safety filter of every env (``CBFQP.update_centralized_cbf_qp``, ``sigmarl/cbf_qp.py:1019-1400``):
+        returns ``actions_safe`` float32 [B, N, 2] = ``u_to_rl_action`` of the minimiser; ``u_opt`` (float64 [B, N, 2]) and ``info``
+        (int32 [B, 2]: Newton iterations, converged) are filled when given."""
+        if not (isinstance(actions, torch.Tensor) and actions.is_cuda and actions.dtype == torch.float32 and actions.is_contiguous()):
+            raise TypeError("actions must be a contiguous float32 CUDA tensor")
+        if tuple(actions.shape) != (self.B, self.N, 2):
+            raise ValueError(f"actions must have shape {(self.B, self.N, 2)}, got {tuple(actions.shape)}")
+        if actions_safe is None:
+            actions_safe = torch.empty_like(actions)
+        for t, dt in ((actions_safe, torch.float32), (u_opt, torch.float64), (info, torch.int32)):
+            if t is not None and not (t.is_cuda and t.dtype == dt and t.is_contiguous()):
+                raise TypeError("cbf_qp outputs must be contiguous CUDA tensors (float32 / float64 / int32)")
+        self._chk(self.lib.cbf_qp(self.h, C.c_void_p(actions.data_ptr()), C.c_void_p(actions_safe.data_ptr()),
+                                  C.c_void_p(u_opt.data_ptr()) if u_opt is not None else None,
+                                  C.c_void_p(info.data_ptr()) if info is not None else None), "cbf_qp")
+        return actions_safe
+
     def step_autoreset(self, actions: torch.Tensor, seed: int = 0, counter: int | None = None, path_first: int | None = None,
                        path_count: int | None = None):
         """``step`` + ``auto_reset`` in one launch (same end state); the terminal observation goes to the slab only."""
@@ -323,6 +341,14 @@ class NumpyAdapter:
         self.env.cbf_rewards(a, m)
         self.env.sync()
         return None if m is None else split_cbf_margins(m.cpu().numpy(), self.B, self.N, int(self.env.cbf_cfg.n_circles))
+
+    def cbf_qp(self, actions):
+        a = torch.as_tensor(np.ascontiguousarray(actions, np.float32).reshape(self.B, self.N, 2)).to(self.env.device)
+        u = torch.zeros((self.B, self.N, 2), dtype=torch.float64, device=self.env.device)
+        info = torch.zeros((self.B, 2), dtype=torch.int32, device=self.env.device)
+        safe = self.env.cbf_qp(a, None, u, info)
+        self.env.sync()
+        return safe.cpu().numpy(), u.cpu().numpy(), info.cpu().numpy()
 
     def auto_reset(self, seed, counter, path_first, path_count):
         self.env.auto_reset(seed, counter, path_first, path_count)

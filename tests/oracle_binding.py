@@ -44,6 +44,7 @@ def load_oracle() -> capi.Library:
             "fn_ego": (None, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
             "fn_wrap": (None, [C.c_int, C.c_void_p, C.c_void_p]),
             "fn_pseudo_distance": (None, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+            "cbf_qp_ex": (C.c_int, [C.c_void_p] * 7),
             "path_table": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(_f32p), C.POINTER(_f32p), C.POINTER(_f32p)]),
         }
         _lib = capi.Library(ORACLE_SO, "sigmaenv_oracle_", extra)
@@ -148,6 +149,21 @@ class OracleEnv:
         if rc != 0:
             raise RuntimeError(f"oracle cbf_rewards failed: {rc}")
         return None if m is None else split_cbf_margins(m, self.B, self.N, Cc)
+
+    def cbf_qp(self, actions, with_data=False):
+        """(actions_safe f32 [B,N,2], u_opt f64 [B,N,2], info i32 [B,2]) and, with_data, the constraint rows [B,n_con,8] and u_nom."""
+        a = np.ascontiguousarray(actions, np.float32).reshape(self.B, self.N, 2)
+        Cc = int(self.cbf_cfg.n_circles)
+        ncon = self.N * Cc * 2 + self.N * (self.N - 1) // 2 * Cc * Cc
+        safe = np.zeros((self.B, self.N, 2), np.float32)
+        u = np.zeros((self.B, self.N, 2), np.float64)
+        info = np.zeros((self.B, 2), np.int32)
+        con = np.zeros((self.B, ncon, 8), np.float64) if with_data else None
+        unom = np.zeros((self.B, self.N, 2), np.float64) if with_data else None
+        rc = self.lib.cbf_qp_ex(self.h, ptr(a), ptr(safe), ptr(u), ptr(info), ptr(con) if with_data else None, ptr(unom) if with_data else None)
+        if rc != 0:
+            raise RuntimeError(f"oracle cbf_qp failed: {rc}")
+        return (safe, u, info, con, unom) if with_data else (safe, u, info)
 
     def auto_reset(self, seed, counter, path_first, path_count):
         rc = self.lib.auto_reset(self.h, int(seed), int(counter), int(path_first), int(path_count))

@@ -204,3 +204,39 @@ def test_cbf_requires_attach_and_rejects_qp():
     with pytest.raises(RuntimeError, match="cbf_attach"):
         dev.cbf_rewards(np.zeros((2, 4, 2), np.float32))
     dev.close()
+
+
+@pytest.mark.parametrize("nominal,adaptive,N", [("rl", False, 16), ("rl", True, 16), ("clf", False, 16), ("clf", True, 8), ("rl", False, 32), ("rl", False, 3)])
+def test_cbf_qp_vs_oracle_and_kkt(nominal, adaptive, N):
+    """The centralized CBF-QP (sigmarl/cbf_qp.py:733-1400): HIP minimiser == the oracle's, and it satisfies the KKT conditions of the
+    original problem (checked in numpy on the constraint data; cvxpy / OSQP are absent, see tests/test_cbf_qp.py)."""
+    from test_cbf_qp import check_kkt, qp_case
+
+    B = 48 if N <= 16 else 12
+    dev, act = qp_case(_hip_env, N=N if N <= 16 else 16, B=B, nominal=nominal, adaptive_lambda=adaptive) if N <= 16 else (None, None)
+    if N > 16:  # 32 agents: sampled starts (the set-state fixture has 16 agents per env)
+        mp = load_map("cpm_entire")
+        p = Parameters(n_agents=N, scenario_type="cpm_entire", dt=0.05, rew_method="cbf", is_solve_qp=False, is_using_cbf_training=True,
+                       is_obs_noise=False, is_apply_mask=False, nom_controller_type=nominal, adaptive_lambda=adaptive)
+        cfg = make_config(p, mp, B)
+        dev, ora = _hip_env(cfg, mp), ob.OracleEnv(cfg, mp)
+        seg_l, seg_r = cbf.load_segment_tables(mp)
+        for e in (dev, ora):
+            e.cbf_attach(cbf.make_cbf_config(p), seg_l, seg_r)
+        dev.env.buffer(capi.BUF_DONE).fill_(1)
+        ora.get(capi.BUF_DONE, copy=False)[:] = 1
+        dev.auto_reset(4, 0, mp.list_first[0], mp.list_count[0])
+        ora.auto_reset(4, 0, mp.list_first[0], mp.list_count[0])
+        act = np.random.default_rng(8).uniform(-0.6, 1.2, (B, N, 2)).astype(np.float32)
+    else:
+        ora, _ = qp_case(ob.OracleEnv, N=N, B=B, nominal=nominal, adaptive_lambda=adaptive)
+    safe_d, u_d, info_d = dev.cbf_qp(act)
+    safe_o, u_o, info_o, con, unom = ora.cbf_qp(act, with_data=True)
+    assert info_d[:, 1].all() and info_o[:, 1].all(), (info_d[:, 1].sum(), info_o[:, 1].sum())
+    assert info_d[:, 0].max() <= 60
+    assert np.abs(u_d - u_o).max() <= 1e-7, np.abs(u_d - u_o).max()
+    assert np.abs(safe_d - safe_o).max() <= 1e-6
+    check_kkt(ora, u_d, con, unom, nominal, tol=1e-8)  # the HIP minimiser against the (oracle-computed) problem data
+    assert (np.abs(u_d - unom).max(axis=(1, 2)) > 1e-6).sum() >= 3
+    dev.close()
+    ora.close()
