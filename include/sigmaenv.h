@@ -60,6 +60,8 @@ extern "C" {
 #define SIGMAENV_REW_TTC 2          /* "ttc" in rew_method */
 #define SIGMAENV_REW_EXACT_SPARSE 4 /* rew_method == "sparse" */
 #define SIGMAENV_REW_HAS_SPARSE 8   /* "sparse" in rew_method */
+#define SIGMAENV_REW_CBF_QP 32      /* "cbf" in rew_method with Parameters.is_solve_qp == True: the step penalises the deviation of the applied
+                                     * action from SIGMAENV_BUF_CBF_NOMINAL, written by sigmaenv_cbf_qp (road_traffic.py:1112-1135) */
 #define SIGMAENV_REW_CBF 16         /* "cbf" in rew_method with Parameters.is_solve_qp == False: the step adds the three margin
                                      * channels written by sigmaenv_cbf_rewards (road_traffic.py:1112-1151) */
 
@@ -94,6 +96,7 @@ typedef struct sigmaenv_config {
   float threshold_near_boundary_low, threshold_near_boundary_high;
   float threshold_near_other_agents_low, threshold_near_other_agents_high;
   float ttc_low, ttc_high;
+  float penalty_deviate_from_cbf_vel, penalty_deviate_from_cbf_steer; /* road_traffic.py:238-243 (-5/100 each); SIGMAENV_REW_CBF_QP */
 } sigmaenv_config_t;
 
 /* Unpadded reference-path table (output of the map parser, sigmarl/map_manager.py:13-40).  The library builds the padded
@@ -134,7 +137,8 @@ typedef enum sigmaenv_buf {
   SIGMAENV_BUF_DONE = 17,        /* u8  [B]                                                                 */
   SIGMAENV_BUF_TIMER = 18,       /* i32 [B,4]    timer.step, num_task_tries, task_success_times, episodes_reset */
   SIGMAENV_BUF_ACTION = 19,      /* f32 [B,N,2]  clamped action (agent.action.u after WorldCustom.step)     */
-  SIGMAENV_BUF_COUNT = 20
+  SIGMAENV_BUF_CBF_NOMINAL = 20, /* f32 [B,N,2] world_state.nominal_action_{vel,steer} as the CBF-QP leaves them (cbf_qp.py:1315-1379) */
+  SIGMAENV_BUF_COUNT = 21
 } sigmaenv_buf_t;
 
 typedef struct sigmaenv sigmaenv_t;
@@ -253,6 +257,8 @@ typedef struct sigmaenv_cbf_config {
   double qp_w_clf;               /* w_clf_relax (1) */
   double qp_w_lambda;            /* lambda_weight (1e3) when Parameters.adaptive_lambda, else 0 (:924-927) */
   double lam_clf;                /* lam_clf (2) */
+  int32_t is_apply_cbf_action;   /* Parameters.is_apply_cbf_action: which action SIGMAENV_BUF_CBF_NOMINAL receives (below) */
+  int32_t reserved3;
 } sigmaenv_cbf_config_t;
 
 /* seg_left / seg_right: HOST pointers f32 [n_paths, seg_stride, 5] = per boundary segment (cos, sin, m_b, m_t, length): the
@@ -279,7 +285,10 @@ int sigmaenv_cbf_rewards(sigmaenv_t* h, const float* actions, double* margins);
  * iterates.  actions: DEVICE f32 [B,N,2] policy actions.  actions_safe: DEVICE f32 [B,N,2] = u_to_rl_action(u*, v, steering)
  * (:499-525): what the reference writes into the action tensor when is_apply_cbf_action, and into
  * world_state.nominal_action_{vel,steer} otherwise.  u_opt (optional): DEVICE f64 [B,N,2] the minimiser (acceleration, steering
- * rate).  info (optional): DEVICE i32 [B,2] = Newton iterations, converged flag. */
+ * rate).  info (optional): DEVICE i32 [B,2] = Newton iterations, converged flag.  SIGMAENV_BUF_CBF_NOMINAL receives what the reference
+ * leaves in world_state.nominal_action_*: the safe action when is_apply_cbf_action == 0 (the caller then steps with the policy's action,
+ * :1343-1379), the clamped policy action when it is 1 (the caller steps with actions_safe, :1262-1283, 1315-1325); with
+ * SIGMAENV_REW_CBF_QP the next step penalises the distance between the two (road_traffic.py:1117-1135). */
 int sigmaenv_cbf_qp(sigmaenv_t* h, const float* actions, float* actions_safe, double* u_opt, int32_t* info);
 
 #ifdef __cplusplus

@@ -43,7 +43,7 @@ typedef struct sigmaenv_oracle {
   int32_t *n_center, *n_left, *n_right;
   uint8_t* is_loop;
   float *state, *prev_pos, *vertices, *short_term, *dist_ref, *dist_left, *dist_right, *dist_bound, *dist_agents;
-  float *reward, *reward_info, *obs, *action;
+  float *reward, *reward_info, *obs, *action, *cbf_nominal;
   int32_t *path, *closest, *nearing, *timer;
   uint8_t *col_agents, *col_flags, *done;
   sigmaenv_cbf_config_t cbf;    /* sigmaenv_oracle_cbf_attach */
@@ -405,6 +405,14 @@ static float agent_reward(oracle_t* o, int b, int i, float* near_other_out, int*
       rew += p; rew += pen_lane;
       if (c->rew_flags & SIGMAENV_REW_HAS_SPARSE) { rew += pca; rew += pcl; }
     }
+    if (c->rew_flags & SIGMAENV_REW_CBF_QP) {                                        /* :1112-1139, is_solve_qp == True */
+      const float* nomv = o->cbf_nominal + bi * 2;                   /* world_state.nominal_action_{vel,steer}, left by the CBF-QP */
+      const float* cur = o->action + bi * 2;                         /* agent.action.u after WorldCustom.step's clamp */
+      float pv = c->penalty_deviate_from_cbf_vel * (fabsf(cur[0] - nomv[0]) / c->max_speed);        /* :1127-1129 */
+      float ps = c->penalty_deviate_from_cbf_steer * (fabsf(cur[1] - nomv[1]) / c->max_steering);   /* :1130-1133 */
+      rew += pv + ps;
+      if (c->rew_flags & SIGMAENV_REW_HAS_SPARSE) { rew += pca; rew += pcl; }
+    }
     if (c->rew_flags & SIGMAENV_REW_CBF) {                                           /* :1112-1151, is_solve_qp == False */
       size_t BNn = (size_t)o->B * N;
       const float* RI = o->reward_info;                              /* written by CBFQP.update_qp before the step */
@@ -706,7 +714,7 @@ int sigmaenv_oracle_create(const sigmaenv_config_t* cfg, const sigmaenv_map_t* m
   o->short_term = xcalloc(BN * NS * 2, 4); o->dist_ref = xcalloc(BN, 4); o->dist_left = xcalloc(BN * 5, 4);
   o->dist_right = xcalloc(BN * 5, 4); o->dist_bound = xcalloc(BN, 4); o->dist_agents = xcalloc(BN * N, 4);
   o->reward = xcalloc(BN, 4); o->reward_info = xcalloc(BN * SIGMAENV_N_REWARD_INFO, 4); o->obs = xcalloc(BN * o->D, 4);
-  o->action = xcalloc(BN * 2, 4); o->path = xcalloc(BN * 4, 4); o->closest = xcalloc(BN * 3, 4);
+  o->action = xcalloc(BN * 2, 4); o->cbf_nominal = xcalloc(BN * 2, 4); o->path = xcalloc(BN * 4, 4); o->closest = xcalloc(BN * 3, 4);
   o->nearing = xcalloc(BN * (K ? K : 1), 4); o->timer = xcalloc((size_t)B * 4, 4);
   o->col_agents = xcalloc(BN * N, 1); o->col_flags = xcalloc(BN * 4, 1); o->done = xcalloc(B, 1);
   *out = o;
@@ -718,7 +726,7 @@ void sigmaenv_oracle_destroy(oracle_t* o) {
   void* ptrs[] = {o->center, o->left, o->right, o->yaw, o->n_center, o->n_left, o->n_right, o->is_loop, o->state, o->prev_pos,
                   o->vertices, o->short_term, o->dist_ref, o->dist_left, o->dist_right, o->dist_bound, o->dist_agents, o->reward,
                   o->reward_info, o->obs, o->action, o->path, o->closest, o->nearing, o->timer, o->col_agents, o->col_flags, o->done,
-                  o->seg_left, o->seg_right};
+                  o->seg_left, o->seg_right, o->cbf_nominal};
   for (size_t k = 0; k < sizeof(ptrs) / sizeof(ptrs[0]); ++k) free(ptrs[k]);
   free(o);
 }
@@ -848,6 +856,7 @@ int sigmaenv_oracle_get(oracle_t* o, sigmaenv_buf_t which, void** ptr, size_t* b
     case SIGMAENV_BUF_DONE: *ptr = o->done; *bytes = (size_t)o->B; break;
     case SIGMAENV_BUF_TIMER: *ptr = o->timer; *bytes = (size_t)o->B * 16; break;
     case SIGMAENV_BUF_ACTION: *ptr = o->action; *bytes = BN * 8; break;
+    case SIGMAENV_BUF_CBF_NOMINAL: *ptr = o->cbf_nominal; *bytes = BN * 8; break;
     default: return SIGMAENV_EINVAL;
   }
   return SIGMAENV_OK;

@@ -16,7 +16,7 @@ import os
 
 ABI_VERSION = 1
 DIST_C2C, DIST_MTV = 0, 1
-REW_DISTANCE, REW_TTC, REW_EXACT_SPARSE, REW_HAS_SPARSE, REW_CBF = 1, 2, 4, 8, 16
+REW_DISTANCE, REW_TTC, REW_EXACT_SPARSE, REW_HAS_SPARSE, REW_CBF, REW_CBF_QP = 1, 2, 4, 8, 16, 32
 CBF_MAX_CIRCLES = 4
 N_SHORT_TERM = 3
 MAX_NEARING = 4
@@ -24,7 +24,7 @@ N_REWARD_INFO = 12
 
 (BUF_STATE, BUF_PREV_POS, BUF_VERTICES, BUF_PATH, BUF_SHORT_TERM, BUF_DIST_REF, BUF_DIST_LEFT, BUF_DIST_RIGHT,
  BUF_DIST_BOUND, BUF_CLOSEST, BUF_DIST_AGENTS, BUF_COL_AGENTS, BUF_COL_FLAGS, BUF_REWARD, BUF_REWARD_INFO, BUF_OBS,
- BUF_NEARING, BUF_DONE, BUF_TIMER, BUF_ACTION) = range(20)
+ BUF_NEARING, BUF_DONE, BUF_TIMER, BUF_ACTION, BUF_CBF_NOMINAL) = range(21)
 
 REWARD_INFO_FIELDS = (
     "rew_progress", "rew_reach_goal", "rew_speed", "rew_centerline", "rew_near_other_agents", "rew_near_left_lane",
@@ -48,6 +48,7 @@ class Config(C.Structure):
         ("threshold_near_boundary_low", C.c_float), ("threshold_near_boundary_high", C.c_float),
         ("threshold_near_other_agents_low", C.c_float), ("threshold_near_other_agents_high", C.c_float),
         ("ttc_low", C.c_float), ("ttc_high", C.c_float),
+        ("penalty_deviate_from_cbf_vel", C.c_float), ("penalty_deviate_from_cbf_steer", C.c_float),
     ]
 
 
@@ -69,7 +70,7 @@ class CbfConfig(C.Structure):
         ("l_r", C.c_double), ("l_wb", C.c_double), ("min_speed", C.c_float), ("min_steering", C.c_float),
         ("reserved2", C.c_float * 2), ("k_clf_speed", C.c_double), ("k_clf_heading", C.c_double), ("ref_speed", C.c_double),
         ("qp_w_acc", C.c_double), ("qp_w_steer", C.c_double), ("qp_w_lane", C.c_double), ("qp_w_pair", C.c_double), ("qp_w_clf", C.c_double),
-        ("qp_w_lambda", C.c_double), ("lam_clf", C.c_double),
+        ("qp_w_lambda", C.c_double), ("lam_clf", C.c_double), ("is_apply_cbf_action", C.c_int32), ("reserved3", C.c_int32),
     ]
 
 
@@ -87,10 +88,7 @@ def rew_flags_from_method(rew_method: str, is_solve_qp: bool = True) -> int:
     """Decode ``Parameters.rew_method`` the way sigmarl/scenarios/road_traffic.py:1056-1151 tests the string."""
     f = 0
     if "cbf" in rew_method:
-        if is_solve_qp:
-            raise ValueError("rew_method containing 'cbf' with is_solve_qp=True needs the CBF-QP solver (SURVEY.md section 8 config 5): "
-                             "not built; the QP-free margin reward (is_solve_qp=False) is")
-        f |= REW_CBF
+        f |= REW_CBF_QP if is_solve_qp else REW_CBF
     if "distance" in rew_method:
         f |= REW_DISTANCE
     if "ttc" in rew_method:

@@ -111,6 +111,7 @@ def make_cbf_config(p, n_circles: int | None = None):
     c.qp_w_clf = float(getattr(p, "w_clf_relax", 1.0))
     c.qp_w_lambda = 1e3 if bool(getattr(p, "adaptive_lambda", False)) else 0.0
     c.lam_clf = float(getattr(p, "lam_clf", 2.0))
+    c.is_apply_cbf_action = int(bool(getattr(p, "is_apply_cbf_action", False)))
     return c
 
 
@@ -139,8 +140,8 @@ class CBFQP:
         self.env_idx = env_idx
         self.agent_idx = agent_idx
         self.parameters = sc.parameters
-        if self.parameters.is_solve_qp or self.parameters.is_grouping_agents:
-            raise NotImplementedError("sigmarl_amd.cbf.CBFQP: only the QP-free margin reward (is_solve_qp=False, no grouping) is built")
+        if self.parameters.is_grouping_agents:
+            raise NotImplementedError("sigmarl_amd.cbf.CBFQP: the grouped QPs are not built (centralized QP and QP-free margin reward are)")
         self.time_pseudo_dis = 0
         self.cbf_solving_t = []
         if getattr(sc.env, "cbf_cfg", None) is None:
@@ -152,7 +153,15 @@ class CBFQP:
         if self.env_idx not in (None, 0):
             return
         act = tensordict[("agents", "action")] if not hasattr(tensordict, "is_cuda") else tensordict
-        self.scenario.env.cbf_rewards(act.contiguous())
+        env = self.scenario.env
+        if not self.parameters.is_solve_qp:
+            env.cbf_rewards(act.contiguous())
+            return
+        # update_centralized_cbf_qp (cbf_qp.py:1019-1400): solve, leave world_state.nominal_action_* (BUF_CBF_NOMINAL) behind, and replace the
+        # action in place when is_apply_cbf_action (:1262-1283)
+        safe = env.cbf_qp(act.contiguous())
+        if self.parameters.is_apply_cbf_action:
+            act.copy_(safe)
 
 
 def cbf_constrained_centralized_policy(tensordict, policy, cbf_controllers):

@@ -1009,6 +1009,16 @@ __global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigm
           rew += p; rew += pen_lane;
           if (c.rew_flags & SIGMAENV_REW_HAS_SPARSE) { rew += pca; rew += pcl; }
         }
+        if (c.rew_flags & SIGMAENV_REW_CBF_QP) {                     // :1112-1139 with is_solve_qp == True
+          // deviation of the applied (clamped) action from world_state.nominal_action_*, which sigmaenv_cbf_qp left behind
+          const float2 nomv = reinterpret_cast<const float2*>(g.cbf_nominal)[gi];
+          const float2 ua = reinterpret_cast<const float2*>(actions)[gi];
+          const float cur0 = clampf(ua.x, -c.max_speed, c.max_speed), cur1 = clampf(ua.y, -c.max_steering, c.max_steering);
+          const float pv = c.penalty_deviate_from_cbf_vel * (fabsf(cur0 - nomv.x) / c.max_speed);
+          const float ps = c.penalty_deviate_from_cbf_steer * (fabsf(cur1 - nomv.y) / c.max_steering);
+          rew += pv + ps;
+          if (c.rew_flags & SIGMAENV_REW_HAS_SPARSE) { rew += pca; rew += pcl; }
+        }
         if (c.rew_flags & SIGMAENV_REW_CBF) {                        // :1112-1151 with is_solve_qp == False
           // the three margin channels CBFQP.update_qp wrote before this step (sigmaenv_cbf_rewards)
           const float cbf_rew = ((g.reward_info[5 * BN + gi] + g.reward_info[6 * BN + gi]) + g.reward_info[4 * BN + gi]) / 3.0f;
@@ -1869,6 +1879,7 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
       {SIGMAENV_BUF_REWARD_INFO, (void**)&g.reward_info, BN * SIGMAENV_N_REWARD_INFO * 4}, {SIGMAENV_BUF_OBS, (void**)&g.obs, BN * h->D * 4},
       {SIGMAENV_BUF_NEARING, (void**)&g.nearing, BN * K * 4}, {SIGMAENV_BUF_DONE, (void**)&g.done, (size_t)B},
       {SIGMAENV_BUF_TIMER, (void**)&g.timer, (size_t)B * 16}, {SIGMAENV_BUF_ACTION, (void**)&g.action, BN * 8},
+      {SIGMAENV_BUF_CBF_NOMINAL, (void**)&g.cbf_nominal, BN * 8},
   };
   for (auto& sp : specs) {
     ALLOC(*sp.p, sp.bytes);

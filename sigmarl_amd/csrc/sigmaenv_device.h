@@ -59,7 +59,7 @@ struct DevMap {
 
 struct DevBufs {
   float *state, *prev_pos, *vertices, *short_term, *dist_ref, *dist_left, *dist_right, *dist_bound, *dist_agents;
-  float *reward, *reward_info, *obs, *action;
+  float *reward, *reward_info, *obs, *action, *cbf_nominal;
   int32_t *path, *closest, *nearing, *timer;
   uint8_t *col_agents, *col_flags, *done;
   unsigned long long* reset_mask;  // [B] bit i: agent i needs its derived state rebuilt

@@ -27,6 +27,7 @@ def _buf_layout(B, N, K, D):
         capi.BUF_COL_FLAGS: ("u8", (B, N, 4)), capi.BUF_REWARD: ("f32", (B, N)), capi.BUF_REWARD_INFO: ("f32", (12, B, N)),
         capi.BUF_OBS: ("f32", (B, N, D)), capi.BUF_NEARING: ("i32", (B, N, K)), capi.BUF_DONE: ("u8", (B,)),
         capi.BUF_TIMER: ("i32", (B, 4)), capi.BUF_ACTION: ("f32", (B, N, 2)),
+        capi.BUF_CBF_NOMINAL: ("f32", (B, N, 2)),
     }
 
 

@@ -110,9 +110,7 @@ def check_supported(p: Parameters) -> None:
     if p.is_using_cbf_testing:
         bad.append("CBF-QP safety filter at test time (BASELINE config 5)")
     if p.is_using_cbf_training or "cbf" in p.rew_method:
-        # only the QP-free margin reward of CBFQP.update_qp is built (sigmarl/cbf_qp.py:2534-2560)
-        if p.is_solve_qp:
-            bad.append("CBF-QP solver (is_solve_qp=True); the QP-free margin reward needs is_solve_qp=False")
+        # built: the centralized QP (is_solve_qp=True) and the QP-free margin reward (sigmarl/cbf_qp.py:2534-2560); not the grouped QPs
         if p.is_grouping_agents:
             bad.append("is_grouping_agents=True")
         if p.nom_controller_type not in ("rl", "clf"):
@@ -174,6 +172,7 @@ def make_config(p: Parameters, map_table, n_envs: int, make_world_scenario_type:
     else:
         c.threshold_near_other_agents_low = p.threshold_near_other_agents_c2c_low if p.threshold_near_other_agents_c2c_low is not None else 0
         c.threshold_near_other_agents_high = p.threshold_near_other_agents_c2c_high if p.threshold_near_other_agents_c2c_high is not None else 0.3
+    c.penalty_deviate_from_cbf_vel = c.penalty_deviate_from_cbf_steer = -5 / r_p_normalizer  # road_traffic.py:238-243
     c.ttc_low = p.ttc_low if p.ttc_low is not None else 0
     c.ttc_high = p.ttc_high if p.ttc_high is not None else 3.75
     return c

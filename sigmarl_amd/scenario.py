@@ -280,9 +280,12 @@ class ScenarioRoadTraffic(BaseScenario):
             with_agents=e.buffer(capi.BUF_COL_AGENTS), with_lanelets=cf[..., 0], with_entry_segments=cf[..., 1], with_exit_segments=cf[..., 2])
         ref_paths = SimpleNamespace(short_term=e.buffer(capi.BUF_SHORT_TERM), scenario_id=pth[..., 1], path_id=pth[..., 2], point_id=pth[..., 3])
         act = e.buffer(capi.BUF_ACTION)
+        nom = e.buffer(capi.BUF_CBF_NOMINAL)
+        qp = bool(self.env.cfg.rew_flags & capi.REW_CBF_QP)  # the CBF-QP leaves its result in world_state.nominal_action_* (cbf_qp.py:1315-1379)
         self.world_state = SimpleNamespace(
             distances=distances, collisions=collisions, ref_paths_agent_related=ref_paths, vertices=e.buffer(capi.BUF_VERTICES), world=self._world,
-            nominal_action_vel=act[..., 0], nominal_action_steer=act[..., 1], applied_action_vel=act[..., 0], applied_action_steer=act[..., 1])
+            nominal_action_vel=(nom if qp else act)[..., 0], nominal_action_steer=(nom if qp else act)[..., 1],
+            applied_action_vel=act[..., 0], applied_action_steer=act[..., 1])
         self.observation_provider = SimpleNamespace(observations=SimpleNamespace(nearing_agents_indices=e.buffer(capi.BUF_NEARING)))
         ri = e.buffer(capi.BUF_REWARD_INFO)
         self.reward_info = SimpleNamespace(**{name: ri[k] for k, name in enumerate(capi.REWARD_INFO_FIELDS)})

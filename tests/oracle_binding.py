@@ -77,6 +77,7 @@ _BUF_SPEC = {
     capi.BUF_DONE: (np.uint8, lambda B, N, K, D: (B,)),
     capi.BUF_TIMER: (np.int32, lambda B, N, K, D: (B, 4)),
     capi.BUF_ACTION: (np.float32, lambda B, N, K, D: (B, N, 2)),
+    capi.BUF_CBF_NOMINAL: (np.float32, lambda B, N, K, D: (B, N, 2)),
 }
 
 

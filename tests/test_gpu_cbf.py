@@ -195,10 +195,11 @@ def test_cbf_full_scan_fallback_matches(monkeypatch):
     ora.close()
 
 
-def test_cbf_requires_attach_and_rejects_qp():
+def test_cbf_requires_attach_and_rejects_grouping():
     mp = load_map("cpm_entire")
     with pytest.raises(NotImplementedError):
-        make_config(Parameters(n_agents=4, rew_method="cbf", is_solve_qp=True, is_using_cbf_training=True, is_apply_mask=False, is_obs_noise=False), mp, 2)
+        make_config(Parameters(n_agents=4, rew_method="cbf", is_solve_qp=True, is_using_cbf_training=True, is_grouping_agents=True, is_apply_mask=False,
+                               is_obs_noise=False), mp, 2)
     p = Parameters(n_agents=4, rew_method="cbf", is_solve_qp=False, is_using_cbf_training=True, is_apply_mask=False, is_obs_noise=False)
     dev = _hip_env(make_config(p, mp, 2), mp)
     with pytest.raises(RuntimeError, match="cbf_attach"):
@@ -238,5 +239,52 @@ def test_cbf_qp_vs_oracle_and_kkt(nominal, adaptive, N):
     assert np.abs(safe_d - safe_o).max() <= 1e-6
     check_kkt(ora, u_d, con, unom, nominal, tol=1e-8)  # the HIP minimiser against the (oracle-computed) problem data
     assert (np.abs(u_d - unom).max(axis=(1, 2)) > 1e-6).sum() >= 3
+    dev.close()
+    ora.close()
+
+
+@pytest.mark.parametrize("apply,nominal", [(False, "rl"), (True, "rl"), (True, "clf")])
+def test_cbf_qp_rollout_reward_vs_oracle(apply, nominal):
+    """rew_method "cbf_sparse" with is_solve_qp=True: the QP before every step, the step penalises |applied - nominal| action
+    (road_traffic.py:1112-1139); with is_apply_cbf_action the safe action is what the env steps with."""
+    import torch
+    from test_gpu_parity import _compare_all
+
+    N, B = 8, 20
+    p = Parameters(n_agents=N, scenario_type="cpm_entire", rew_method="cbf_sparse", dt=0.05, is_solve_qp=True, is_using_cbf_training=True,
+                   is_apply_cbf_action=apply, nom_controller_type=nominal, is_apply_mask=False, is_obs_noise=False, max_steps=6, is_use_mtv_distance=False)
+    mp = load_map("cpm_entire")
+    cfg = make_config(p, mp, B)
+    assert cfg.rew_flags & capi.REW_CBF_QP and not cfg.rew_flags & capi.REW_CBF
+    dev, ora = _hip_env(cfg, mp), ob.OracleEnv(cfg, mp)
+    seg_l, seg_r = cbf.load_segment_tables(mp)
+    cc = cbf.make_cbf_config(p)
+    assert cc.is_apply_cbf_action == int(apply)
+    for e in (dev, ora):
+        e.cbf_attach(cc, seg_l, seg_r)
+    dev.env.buffer(capi.BUF_DONE).fill_(1)
+    ora.get(capi.BUF_DONE, copy=False)[:] = 1
+    pf, pc = mp.list_first[0], mp.list_count[0]
+    dev.auto_reset(6, 0, pf, pc)
+    ora.auto_reset(6, 0, pf, pc)
+    rng = np.random.default_rng(21)
+    changed = 0
+    for t in range(6):
+        act = np.stack([rng.uniform(-0.7, 1.3, (B, N)), rng.uniform(-0.7, 0.7, (B, N))], axis=-1).astype(np.float32)
+        safe_d, u_d, info_d = dev.cbf_qp(act)
+        safe_o, u_o, info_o = ora.cbf_qp(act)
+        assert info_d[:, 1].all() and info_o[:, 1].all()
+        assert np.abs(u_d - u_o).max() <= 1e-7 and np.abs(safe_d - safe_o).max() <= 1e-6
+        assert np.abs(dev.get(capi.BUF_CBF_NOMINAL) - ora.get(capi.BUF_CBF_NOMINAL)).max() <= 1e-6
+        changed += int((np.abs(safe_o - np.clip(act, [-0.5, -0.5411], [1.0, 0.5411])).max(axis=(1, 2)) > 1e-5).sum())
+        # continue both sides from the ORACLE's QP result so that a last-bit difference cannot leak into the state comparison
+        dev.env.buffer(capi.BUF_CBF_NOMINAL).copy_(torch.from_numpy(ora.get(capi.BUF_CBF_NOMINAL)))
+        step_act = safe_o if apply else act
+        dev.step(step_act)
+        ora.step(step_act)
+        _compare_all(dev, ora, f"step {t}")
+        dev.auto_reset(6, t + 1, pf, pc)
+        ora.auto_reset(6, t + 1, pf, pc)
+    assert changed > 0
     dev.close()
     ora.close()

@@ -35,17 +35,20 @@ def test_rew_flags_follow_the_reference_string_tests():
     assert f("sparse") == capi.REW_EXACT_SPARSE | capi.REW_HAS_SPARSE
     assert f("ttc_sparse") == capi.REW_TTC | capi.REW_HAS_SPARSE
     assert f("distance_sparse") == capi.REW_DISTANCE | capi.REW_HAS_SPARSE
-    with pytest.raises(ValueError):
-        f("cbf")
+    assert f("cbf") == capi.REW_CBF_QP and f("cbf", False) == capi.REW_CBF  # is_solve_qp (default True) selects the QP penalty
+    assert f("cbf_sparse", False) == capi.REW_CBF | capi.REW_HAS_SPARSE
 
 
 def test_unsupported_configurations_fail_loudly():
     ok = Parameters(is_apply_mask=False)
     check_supported(ok)
-    for kw in (dict(is_apply_mask=True), dict(is_apply_mask=False, is_ego_view=False), dict(is_apply_mask=False, is_using_cbf_training=True),
+    for kw in (dict(is_apply_mask=True), dict(is_apply_mask=False, is_ego_view=False), dict(is_apply_mask=False, is_using_cbf_training=True, is_grouping_agents=True),
+               dict(is_apply_mask=False, is_using_cbf_testing=True),
                dict(is_apply_mask=False, n_points_short_term=5)):
         with pytest.raises(NotImplementedError):
             check_supported(Parameters(**kw))
+    check_supported(Parameters(is_apply_mask=False, is_using_cbf_training=True))  # centralized CBF-QP (is_solve_qp defaults to True)
+    check_supported(Parameters(is_apply_mask=False, is_using_cbf_training=True, is_solve_qp=False, rew_method="cbf"))  # QP-free margin reward
 
 
 def test_config_mirrors_init_params():

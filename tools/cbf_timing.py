@@ -56,3 +56,17 @@ if os.environ.get("CPU", "1") != "0":
     env.cbf_rewards(act); env.sync()
     d = np.abs(env.buffer(capi.BUF_REWARD_INFO)[4:7, :Bs].cpu().numpy() - ora.get(capi.BUF_REWARD_INFO)[4:7])
     print("HIP vs oracle reward channels on the sample: max |diff| %.3g" % d.max())
+if os.environ.get("QP", "1") != "0":
+    u = torch.zeros((B, N, 2), dtype=torch.float64, device="cuda")
+    info = torch.zeros((B, 2), dtype=torch.int32, device="cuda")
+    safe = torch.zeros((B, N, 2), device="cuda")
+    env.cbf_qp(act, safe, u, info); env.sync()
+    torch.cuda.synchronize(); s.record()
+    for _ in range(10):
+        env.cbf_qp(act, safe, u, info)
+    e.record(); torch.cuda.synchronize()
+    msq = s.elapsed_time(e) / 10
+    it = info[:, 0].float()
+    print("cbf_qp: %.3f ms per launch (%d envs x %d agents): %.4g env QPs/s; Newton iterations mean %.1f max %d; converged %d of %d; actions changed in %d envs"
+          % (msq, B, N, B / msq * 1e3, it.mean().item(), int(it.max().item()), int(info[:, 1].sum().item()), B,
+             int(((safe - act.clamp(min=torch.tensor([-0.5, -0.5411], device="cuda"), max=torch.tensor([1.0, 0.5411], device="cuda"))).abs().amax(dim=(1, 2)) > 1e-5).sum().item())))
