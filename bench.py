@@ -93,6 +93,8 @@ def main():
                     "(sigmaenv_actor_forward, MFMA bf16) instead of replaying precomputed actions; reported in config.policy")
     ap.add_argument("--cbf", action="store_true", help="widening (SURVEY 8f-4): rew_method='cbf' with the QP-free CBF margin reward "
                     "(sigmaenv_cbf_rewards before every step); reported in config.cbf")
+    ap.add_argument("--cbf-qp", action="store_true", help="widening (BASELINE config 5): rew_method='cbf' with the centralized CBF-QP safety "
+                    "filter solved for every env before every step (sigmaenv_cbf_qp); reported in config.cbf")
     ap.add_argument("--exchange", choices=["alltoall", "gather"], default="alltoall",
                     help="N > 1: how the rollout buffer is concatenated.  alltoall: distributed over the ranks by time slices (every rank "
                          "receives 1/N of the steps of ALL envs -- a data-parallel learner; the record crosses xGMI once, over all links); "
@@ -136,6 +138,9 @@ def main():
                      is_apply_mask=False, is_obs_noise=False, max_steps=128, num_vmas_envs=B)
     if args.cbf:
         params_kw.update(rew_method="cbf", is_solve_qp=False, is_using_cbf_training=True)
+    if args.cbf_qp:
+        params_kw.update(rew_method="cbf", is_solve_qp=True, is_using_cbf_training=True)
+        args.cbf = True  # same call sites below; the QP launch replaces the margin launch
     # env shards of this GPU: S handles of B / S envs, each on its own HIP stream (no cross-env dependency anywhere in the path)
     # (only when every shard still fills the GPU's CUs with whole tiles; small batches are launch-bound and stay in one piece)
     S = args.streams if (args.streams >= 1 and B % max(1, args.streams) == 0 and (B // max(1, args.streams)) * N >= 64 * int(os.environ.get("BENCH_MIN_TILES", "512"))) else 1
@@ -201,6 +206,7 @@ def main():
             with torch.cuda.stream(streams[k]):
                 actors.append(Actor(mlp, low=[-1.0, -0.6109], high=[1.0, 0.6109]))  # -/+ (max_speed, max_steering)
                 act_bufs.append(torch.zeros((Bs, N, 2), dtype=torch.float32, device=device))
+    safe_bufs = [torch.zeros((Bs, N, 2), dtype=torch.float32, device=device) for _ in range(S)] if args.cbf_qp else []
     W = N * (env.D + 1) + 1
     act_ptrs = [[acts[q].data_ptr() + k * Bs * N * 2 * 4 for k in range(S)] for q in range(n_act)]
     shard_seeds = [seed * 64 + k for k in range(S)]
@@ -233,13 +239,18 @@ def main():
         if fused and args.policy:  # policy on device, then the fused step on the actions it wrote
             for k, e in enumerate(envs):
                 actors[k].forward(e, act_bufs[k], seed=shard_seeds[k], counter=cnt)
-                if args.cbf:
+                if args.cbf_qp:
+                    e.cbf_qp(act_bufs[k], safe_bufs[k])
+                elif args.cbf:
                     e.cbf_rewards(act_bufs[k])
                 e.step_autoreset_ptr(act_bufs[k].data_ptr(), shard_seeds[k], cnt, pf, pc)
         elif fused and args.cbf:  # margin rewards of the action about to be applied, then the fused step that consumes them
             a = acts[t % n_act]
             for k, e in enumerate(envs):
-                e.cbf_rewards(a[k * Bs:(k + 1) * Bs])
+                if args.cbf_qp:
+                    e.cbf_qp(a[k * Bs:(k + 1) * Bs], safe_bufs[k])
+                else:
+                    e.cbf_rewards(a[k * Bs:(k + 1) * Bs])
                 e.step_autoreset_ptr(ap[k], shard_seeds[k], cnt, pf, pc)
         elif fused:
             pass  # done above
@@ -333,8 +344,10 @@ def main():
             "n_agents": N, "envs_per_gpu": B, "envs_total": B * world, "distance": args.distance, "env_shards_per_gpu": S,
             "policy": ("actor MLP 32-256-256-256-4 (bf16 MFMA, TanhNormal sample) on device before every step" if args.policy
                        else "none in the timed region (precomputed actions resident in HBM)"),
-            **({"cbf": "QP-free CBF margin reward (sigmaenv_cbf_rewards: 3 circles per vehicle, 9-point fp16 pseudo-distance stencils to both "
-                       "boundaries, float64 margins) launched before every step"} if args.cbf else {}),
+            **({"cbf": ("centralized CBF-QP safety filter of every env (sigmaenv_cbf_qp: 32 controls, 96 lane + 1080 pair constraints, projected "
+                        "Newton in float64) solved before every step; the step penalises the deviation from the safe action" if args.cbf_qp else
+                        "QP-free CBF margin reward (sigmaenv_cbf_rewards: 3 circles per vehicle, 9-point fp16 pseudo-distance stencils to both "
+                        "boundaries, float64 margins) launched before every step")} if args.cbf else {}),
             "resets_per_step_per_gpu": dones / max(1, args.steps), "rollout_gather": gather_state["note"] or gather_note,
         },
         "roofline": {
