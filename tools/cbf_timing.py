@@ -56,6 +56,12 @@ if os.environ.get("CPU", "1") != "0":
     env.cbf_rewards(act); env.sync()
     d = np.abs(env.buffer(capi.BUF_REWARD_INFO)[4:7, :Bs].cpu().numpy() - ora.get(capi.BUF_REWARD_INFO)[4:7])
     print("HIP vs oracle reward channels on the sample: max |diff| %.3g" % d.max())
+    if os.environ.get("QP", "1") != "0":
+        t0 = time.perf_counter(); reps = 0
+        while time.perf_counter() - t0 < 5.0:
+            ora.cbf_qp(a); reps += 1
+        el = (time.perf_counter() - t0) / reps
+        print("CPU oracle QP (OpenMP, %d threads): %.2f ms per %d envs: %.4g env QPs/s" % (os.cpu_count(), el * 1e3, Bs, Bs / el))
 if os.environ.get("QP", "1") != "0":
     u = torch.zeros((B, N, 2), dtype=torch.float64, device="cuda")
     info = torch.zeros((B, 2), dtype=torch.int32, device="cuda")
