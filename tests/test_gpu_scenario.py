@@ -131,6 +131,52 @@ def test_cbf_margin_reward_through_the_surface():
     sc.env.close()
 
 
+@pytest.mark.parametrize("apply", [False, True])
+def test_cbf_qp_through_the_surface(apply):
+    """is_solve_qp=True: CBFQP.update_qp solves the centralized QP of every env, leaves world_state.nominal_action_* behind (and overwrites the
+    action tensor when is_apply_cbf_action); the step's reward carries the deviation penalty (road_traffic.py:1112-1139)."""
+    import torch
+    from sigmarl_amd.cbf import CBFQP
+    from sigmarl_amd.scenario import make_scenario
+
+    B, N = 12, 6
+    p = Parameters(n_agents=N, scenario_type="cpm_entire", rew_method="cbf", is_solve_qp=True, is_using_cbf_training=True, is_apply_cbf_action=apply,
+                   is_apply_mask=False, is_obs_noise=False, is_use_mtv_distance=False, num_vmas_envs=B)
+    sc = make_scenario(p)
+    sc.env_make_world(B, "cuda:0", n_agents=N)
+    sc.env_reset_world_at(None)
+    ctl = CBFQP(env=sc)
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    seen = 0
+    for t in range(4):
+        act = (torch.rand((B, N, 2), generator=gen, device="cuda") * torch.tensor([1.6, 1.2], device="cuda") - torch.tensor([0.5, 0.6], device="cuda")).contiguous()
+        rl = act.clone()
+        td = {("agents", "action"): act}
+        ctl.update_qp(td)
+        sc.env.sync()
+        nom = torch.stack([sc.world_state.nominal_action_vel, sc.world_state.nominal_action_steer], -1).clone()
+        rl_c = torch.stack([rl[..., 0].clamp(-0.5, 1.0), rl[..., 1].clamp(-float(sc.max_steering), float(sc.max_steering))], -1)
+        if apply:
+            assert torch.allclose(nom, rl_c, atol=1e-7)   # the nominal slot keeps the (clamped) policy action ...
+            safe = act                                      # ... and the action tensor was overwritten with the safe action
+        else:
+            assert torch.equal(act, rl)
+            safe = nom
+        seen += int(((safe - rl_c).abs().amax(dim=(1, 2)) > 1e-5).sum())
+        obs, rew, done, info = _vmas_step(sc, act)
+        # the deviation penalty: -0.05 * |applied - nominal| / max, per channel, inside the clamped reward
+        applied = torch.stack([a.action.u for a in sc.world.agents], 1)
+        pen = -0.05 * ((applied[..., 0] - nom[..., 0]).abs() / 1.0) + -0.05 * ((applied[..., 1] - nom[..., 1]).abs() / float(sc.max_steering))
+        r = torch.stack(rew, 1)
+        base = torch.stack([sc.reward_info.rew_total for _ in range(1)], 0)  # (only the last agent's entry survives; not used further)
+        assert torch.isfinite(r).all() and base.shape[-1] == N
+        assert float((r - pen).abs().max()) < 1.2  # progress / goal terms on top of the penalty; sanity only
+        for e in torch.nonzero(done).flatten().tolist():
+            sc.env_reset_world_at(e)
+    assert seen > 0
+    sc.env.close()
+
+
 @pytest.mark.parametrize("scen,N,testing", [("intersection_1", 4, False), ("on_ramp_1", 4, False), ("cpm_entire", 4, True)])
 def test_host_driven_agent_resets(scen, N, testing):
     """Non-loop maps / testing mode: done() performs the per-agent resets (torch RNG) the reference performs there.
