@@ -224,8 +224,9 @@ int sigmaenv_actor_forward(sigmaenv_t* h, sigmaenv_actor_t* a, const float* obs,
  * sigmarl/helper_training.py:687-788, without its per-step Python): actions_buf device f32 [B,N,2] scratch; optional records:
  * slab_base device f32 [n_steps, B, N*(D+1)+1], logp_base device f32 [n_steps, B, N], actions_rec device f32 [n_steps, B, N, 2].
  * Step t uses the random-stream counter counter0 + t for both the policy sample and the resets.  When the handle has SIGMAENV_REW_CBF
- * set and sigmaenv_cbf_attach has been called, sigmaenv_cbf_rewards runs on the sampled actions between the two (the order of
- * cbf_constrained_centralized_policy, sigmarl/helper_training.py:1604-1635). */
+ * (or SIGMAENV_REW_CBF_QP) set and sigmaenv_cbf_attach has been called, sigmaenv_cbf_rewards (sigmaenv_cbf_qp) runs on the sampled actions
+ * between the two (the order of cbf_constrained_centralized_policy, sigmarl/helper_training.py:1604-1635); with is_apply_cbf_action the
+ * env steps with the QP's safe actions. */
 int sigmaenv_rollout(sigmaenv_t* h, sigmaenv_actor_t* a, int32_t n_steps, float* actions_buf, float* slab_base, float* logp_base, float* actions_rec,
                      uint64_t seed, uint64_t counter0, int32_t path_first, int32_t path_count, int32_t deterministic);
 

@@ -1647,7 +1647,7 @@ struct sigmaenv {
   unsigned long long launch_count = 0;
   // QP-free CBF margin reward (sigmaenv_cbf.inc)
   sigmaenv_cbf_config_t cbf_cfg{};
-  void *cbf_seg4 = nullptr, *cbf_segl = nullptr, *cbf_cxy = nullptr, *cbf_u = nullptr, *cbf_kin = nullptr, *cbf_clf = nullptr;
+  void *cbf_seg4 = nullptr, *cbf_segl = nullptr, *cbf_cxy = nullptr, *cbf_u = nullptr, *cbf_kin = nullptr, *cbf_clf = nullptr, *cbf_safe = nullptr;
   int cbf_seg_stride = 0;
   std::string err;
 };

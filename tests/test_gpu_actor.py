@@ -160,3 +160,34 @@ def test_rollout_with_cbf_margin_reward_equals_stepwise_calls():
         e.close()
     actor.close()
     actor2.close()
+
+
+def test_rollout_with_cbf_qp_equals_stepwise_calls():
+    """is_solve_qp=True with is_apply_cbf_action: sigmaenv_rollout runs policy -> centralized QP -> fused step on the SAFE action."""
+    from sigmarl_amd import capi
+    from sigmarl_amd.shard import slab_width
+    kw = dict(rew_method="cbf", is_solve_qp=True, is_using_cbf_training=True, is_apply_cbf_action=True)
+    torch, env, mlp, actor = _setup(B=24, N=8, seed=5, **kw)
+    _, env2, _, _ = _setup(B=24, N=8, seed=5, **kw)
+    actor2 = __import__("sigmarl_amd.actor", fromlist=["Actor"]).Actor(mlp, low=[-1.0, -0.6], high=[1.0, 0.6])
+    for e in (env, env2):
+        e.cbf_attach()
+    T, W = 4, slab_width(env.N, env.D)
+    slab, slab2 = torch.zeros((T, env.B, W), device="cuda"), torch.zeros((T, env.B, W), device="cuda")
+    actor.rollout(env, T, slab=slab, seed=4, counter0=70)
+    env.sync()
+    a = torch.zeros((env2.B, env2.N, 2), device="cuda")
+    for t in range(T):
+        actor2.forward(env2, a, seed=4, counter=70 + t)
+        safe = env2.cbf_qp(a)
+        env2.set_slab(slab2[t])
+        env2.step_autoreset(safe, seed=4, counter=70 + t)
+        env2.sync()
+    # the QP's float64 atomics are not summation-order deterministic: states agree to rounding, not bitwise
+    assert float((env.state - env2.state).abs().max()) <= 1e-5
+    assert float((slab - slab2).abs().max()) <= 1e-4
+    assert torch.equal(env.buffer(capi.BUF_TIMER), env2.buffer(capi.BUF_TIMER))
+    for e in (env, env2):
+        e.close()
+    actor.close()
+    actor2.close()
