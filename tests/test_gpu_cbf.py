@@ -155,6 +155,44 @@ def test_cbf_full_size_sample_vs_oracle():
     env.close()
 
 
+def test_cbf_degenerate_states_vs_oracle():
+    """Vehicles metres off their lane and outside the map (large pseudo distances, bounds that prune nothing), coincident vehicles, zero
+    speed, reversed heading: margins, channels and the QP agree with the oracle."""
+    z, meta = _cbf_fixture()
+    N, B = 16, 12
+    mp = load_map("cpm_entire")
+    p = Parameters(n_agents=N, scenario_type="cpm_entire", dt=0.05, rew_method="cbf", is_solve_qp=False, is_using_cbf_training=True,
+                   is_obs_noise=False, is_apply_mask=False)
+    cfg = make_config(p, mp, B)
+    dev, ora = _hip_env(cfg, mp), ob.OracleEnv(cfg, mp)
+    seg_l, seg_r = cbf.load_segment_tables(mp)
+    st8 = np.zeros((B, N, 8), np.float32)
+    st8[..., :5] = z["p2_state"][:B]
+    rng = np.random.default_rng(4)
+    st8[:, 2, 0:2] += rng.uniform(-3.0, 3.0, (B, 2)).astype(np.float32)      # metres away from the own lane
+    st8[:, 3, 0:2] = np.float32([40.0, -25.0])                                # outside the map altogether
+    st8[:, 5, 0:3] = st8[:, 4, 0:3]                                           # coincident with vehicle 4
+    st8[:, 6, 3] = 0.0                                                        # standing still
+    st8[:, 7, 2] += np.float32(np.pi)                                         # facing backwards
+    ids = np.zeros((B, N, 4), np.int32)
+    ids[..., 0] = z["p2_path"][:B]
+    ids[..., 2] = ids[..., 0]
+    for e in (dev, ora):
+        e.cbf_attach(cbf.make_cbf_config(p), seg_l, seg_r)
+        e.reset(np.repeat(np.arange(B), N), np.tile(np.arange(N), B), ids.reshape(-1, 4), st8.reshape(-1, 8), 1)
+    act = z["p2_act"][:B]
+    md, mo = dev.cbf_rewards(act), ora.cbf_rewards(act)
+    _cmp_margins(md, mo, "degenerate")
+    _cmp_rewards(dev, ora, "degenerate")
+    assert np.isfinite(mo[0]).all() and np.abs(mo[0]).max() > 10  # far-away vehicles: margins of tens of metres
+    safe_d, u_d, info_d = dev.cbf_qp(act)
+    safe_o, u_o, info_o = ora.cbf_qp(act)
+    assert info_d[:, 1].all() and info_o[:, 1].all()
+    assert np.abs(u_d - u_o).max() <= 1e-6 and np.abs(safe_d - safe_o).max() <= 1e-6
+    dev.close()
+    ora.close()
+
+
 def test_cbf_own_segment_tables_on_compiled_map():
     """A map without a shipped table asset (compiled by sigmarl_amd.mapc): the tables come from sigmarl_amd.cbf.segment_tables."""
     from sigmarl_amd import mapc
