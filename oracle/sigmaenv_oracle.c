@@ -494,6 +494,11 @@ static void agent_observation(oracle_t* o, int b, int i) {
     ob[p++] = (va * cr_cos(rr)) / n_v;
     ob[p++] = (va * cr_sin(rr)) / n_v;
     ob[p++] = Drow[j] / n_dl;                                    /* :373-375 */
+    if (c->is_apply_mask && Drow[j] >= c->distance_mask_agents) {  /* masked by distance, :638-665: vertices / distance := 1, velocity := 0 */
+      for (int q = 0; q < 8; ++q) ob[p - 11 + q] = 1.0f;         /* :734-737 */
+      ob[p - 3] = 0.0f; ob[p - 2] = 0.0f;                        /* :717-719 */
+      ob[p - 1] = 1.0f;                                          /* :747-749 */
+    }
   }
 }
 

@@ -49,6 +49,7 @@ class Config(C.Structure):
         ("threshold_near_other_agents_low", C.c_float), ("threshold_near_other_agents_high", C.c_float),
         ("ttc_low", C.c_float), ("ttc_high", C.c_float),
         ("penalty_deviate_from_cbf_vel", C.c_float), ("penalty_deviate_from_cbf_steer", C.c_float),
+        ("is_apply_mask", C.c_int32), ("distance_mask_agents", C.c_float),
     ]
 
 

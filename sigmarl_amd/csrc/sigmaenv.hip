@@ -606,6 +606,7 @@ __device__ inline void observe_tile(const sigmaenv_config_t& c, const Smem& s, c
     const float* si = s.st + sl * 8;
     float tx, ty;
     int pos;
+    bool masked = false;
     if (q < NS) {  // [own] short-term reference path (:451-460, :893-897)
       tx = s.shrt[sl * NS * 2 + 2 * q]; ty = s.shrt[sl * NS * 2 + 2 * q + 1];
       pos = 1 + 2 * q;
@@ -614,11 +615,13 @@ __device__ inline void observe_tile(const sigmaenv_config_t& c, const Smem& s, c
       int sj = ebase + s.near[sl * K + k];
       tx = s.vnew[sj * 10 + 2 * v]; ty = s.vnew[sj * 10 + 2 * v + 1];
       pos = 4 + 2 * NS + 11 * k + 2 * v;
+      // masked by distance (observation_provider_rt.py:638-665, 734-737): the vertices read 1
+      masked = c.is_apply_mask && s.dist[sl * DIST_STRIDE(N) + s.near[sl * K + k]] >= c.distance_mask_agents;
     }
     float dx = tx - si[0], dy = ty - si[1];
     float ci = s.cs[sl * 2], sn = s.cs[sl * 2 + 1];
-    s.obs[sl * D + pos] = (dx * ci + dy * sn) / n_pos;
-    s.obs[sl * D + pos + 1] = (dy * ci - dx * sn) / n_pos;
+    s.obs[sl * D + pos] = masked ? 1.0f : (dx * ci + dy * sn) / n_pos;
+    s.obs[sl * D + pos + 1] = masked ? 1.0f : (dy * ci - dx * sn) / n_pos;
   }
   TSO(2);
   // relative velocities (one lane per (agent, self or observed neighbour)) from the front of the block, the per-agent distances
@@ -642,8 +645,9 @@ __device__ inline void observe_tile(const sigmaenv_config_t& c, const Smem& s, c
         s.obs[sl * D] = va / n_v;  // [own] only the longitudinal component is observed; cos(0) = 1 (:864-868, :885-887)
       } else {
         int base = 4 + 2 * NS + 11 * (q - 1);
-        s.obs[sl * D + base + 8] = (va * cr) / n_v;
-        s.obs[sl * D + base + 9] = (va * sr) / n_v;
+        const bool masked = c.is_apply_mask && s.dist[sl * DIST_STRIDE(N) + s.near[sl * K + (q - 1)]] >= c.distance_mask_agents;  // :717-719
+        s.obs[sl * D + base + 8] = masked ? 0.0f : (va * cr) / n_v;
+        s.obs[sl * D + base + 9] = masked ? 0.0f : (va * sr) / n_v;
       }
     } else if (w3 < n3) {
       const int sl = real_slot(w3);
@@ -653,7 +657,10 @@ __device__ inline void observe_tile(const sigmaenv_config_t& c, const Smem& s, c
       s.obs[sl * D + 1 + 2 * NS] = s.dref[sl] / n_dl;        // :376-378, :898-904
       s.obs[sl * D + 2 + 2 * NS] = ml / n_dl;                // :379-382
       s.obs[sl * D + 3 + 2 * NS] = mr / n_dl;                // :383-386
-      for (int k = 0; k < K; ++k) s.obs[sl * D + 4 + 2 * NS + 11 * k + 10] = s.dist[sl * DIST_STRIDE(N) + s.near[sl * K + k]] / n_dl;  // :373-375
+      for (int k = 0; k < K; ++k) {
+        const float dk = s.dist[sl * DIST_STRIDE(N) + s.near[sl * K + k]];
+        s.obs[sl * D + 4 + 2 * NS + 11 * k + 10] = (c.is_apply_mask && dk >= c.distance_mask_agents) ? 1.0f : dk / n_dl;  // :373-375, :747-749
+      }
     }
   }
   TSO(3);

@@ -95,8 +95,10 @@ def check_supported(p: Parameters) -> None:
         bad.append("is_observe_distance_to_boundaries=False")
     if not p.is_observe_distance_to_center_line:
         bad.append("is_observe_distance_to_center_line=False")
-    if p.is_apply_mask:
-        bad.append("is_apply_mask=True")
+    if p.is_apply_mask and p.scenario_type not in ("cpm_entire", "cpm_mixed"):
+        # the CPM parser provides no neighbouring-lanelet table, so only the distance criterion applies there
+        # (observation_provider_rt.py:646-662); the OSM maps additionally mask by lanelet relation, which is not built
+        bad.append(f"is_apply_mask=True on {p.scenario_type!r} (mask by neighbouring lanelets)")
     if p.is_obs_steering:
         bad.append("is_obs_steering=True")
     if p.is_observe_ref_path_other_agents:
@@ -172,6 +174,8 @@ def make_config(p: Parameters, map_table, n_envs: int, make_world_scenario_type:
     else:
         c.threshold_near_other_agents_low = p.threshold_near_other_agents_c2c_low if p.threshold_near_other_agents_c2c_low is not None else 0
         c.threshold_near_other_agents_high = p.threshold_near_other_agents_c2c_high if p.threshold_near_other_agents_c2c_high is not None else 0.3
+    c.is_apply_mask = int(bool(p.is_apply_mask))
+    c.distance_mask_agents = A["length"] * 5  # road_traffic.py:663
     c.penalty_deviate_from_cbf_vel = c.penalty_deviate_from_cbf_steer = -5 / r_p_normalizer  # road_traffic.py:238-243
     c.ttc_low = p.ttc_low if p.ttc_low is not None else 0
     c.ttc_high = p.ttc_high if p.ttc_high is not None else 3.75

@@ -496,6 +496,9 @@ TRAJS = {
                       is_use_mtv_distance=False, rew_method="cbf", is_using_cbf_training=True, is_solve_qp=False),
     "intersection4_cbf": dict(T=48, B=3, seed=22, mode_pattern=[1, 1, 0], hook="cbf", n_agents=4, scenario_type="intersection_1", dt=0.1,
                               is_use_mtv_distance=True, rew_method="cbf_sparse", is_using_cbf_training=True, is_solve_qp=False),
+    # Parameters' default is_apply_mask=True on the CPM map (no neighbouring-lanelet table there: the distance mask only)
+    "cpm16_mask": dict(T=24, B=3, seed=24, mode_pattern=[1, 0, 1], n_agents=16, scenario_type="cpm_entire", dt=0.05,
+                       is_use_mtv_distance=False, rew_method="distance", is_apply_mask=True),
     # "clf" nominal controller (cbf_qp.py:2616-2628): the margins are evaluated at a P controller's action instead of the policy's
     "onramp4_cbf_clf": dict(T=24, B=3, seed=23, mode_pattern=[1, 0, 1], hook="cbf", n_agents=4, scenario_type="on_ramp_1", dt=0.05,
                             is_use_mtv_distance=False, rew_method="cbf", is_using_cbf_training=True, is_solve_qp=False, nom_controller_type="clf"),

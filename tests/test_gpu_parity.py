@@ -117,6 +117,37 @@ def test_hip_vs_oracle_seeded(scen, N, B, mtv, rew, dt, testing, steps):
     ora.close()
 
 
+def test_distance_mask_hip_vs_oracle():
+    """Parameters' default is_apply_mask=True on the CPM map: neighbours at or beyond 5 vehicle lengths are masked in the observation."""
+    N, B = 16, 48
+    p = Parameters(n_agents=N, scenario_type="cpm_entire", is_use_mtv_distance=True, rew_method="ttc", dt=0.05, is_apply_mask=True, is_obs_noise=False,
+                   max_steps=9)
+    mp = load_map("cpm_entire")
+    cfg = make_config(p, mp, B)
+    assert cfg.is_apply_mask == 1 and abs(cfg.distance_mask_agents - 1.1) < 1e-6
+    dev, ora = _hip_env(cfg, mp), ob.OracleEnv(cfg, mp)
+    dev.env.buffer(capi.BUF_DONE).fill_(1)
+    ora.get(capi.BUF_DONE, copy=False)[:] = 1
+    pf, pc = mp.list_first[0], mp.list_count[0]
+    dev.auto_reset(2, 0, pf, pc)
+    ora.auto_reset(2, 0, pf, pc)
+    _compare_all(dev, ora, "after reset")
+    rng = np.random.default_rng(5)
+    masked = 0
+    for t in range(8):
+        act = np.stack([rng.uniform(-0.2, 1.3, (B, N)), rng.uniform(-0.7, 0.7, (B, N))], axis=-1).astype(np.float32)
+        dev.step(act)
+        ora.step(act)
+        _compare_all(dev, ora, f"step {t}")
+        blk = ora.get(capi.BUF_OBS)[..., 10:].reshape(B, N, 2, 11)
+        masked += int(((blk[..., 10] == 1.0) & (blk[..., 0] == 1.0) & (blk[..., 8] == 0.0)).sum())
+        dev.auto_reset(2, t + 1, pf, pc)
+        ora.auto_reset(2, t + 1, pf, pc)
+    assert masked > 100
+    dev.close()
+    ora.close()
+
+
 def test_forced_overlaps_and_edge_cases():
     """Injected states: overlapping rectangles (collision masks, negative mtv), coincident agents (atan2(0,0), zero distance),
     an agent far outside the map, zero speed, steering beyond the clamp."""
