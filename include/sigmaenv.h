@@ -98,8 +98,9 @@ typedef struct sigmaenv_config {
   float ttc_low, ttc_high;
   float penalty_deviate_from_cbf_vel, penalty_deviate_from_cbf_steer; /* road_traffic.py:238-243 (-5/100 each); SIGMAENV_REW_CBF_QP */
   int32_t is_apply_mask;        /* Parameters.is_apply_mask: observed neighbours at or beyond distance_mask_agents are masked (vertices and
-                                 * distance := 1, velocity := 0; observation_provider_rt.py:638-749).  Only the distance criterion: maps whose
-                                 * parser provides neighbouring lanelets (the OSM ones) additionally mask by lanelet, which is not built. */
+                                 * distance := 1, velocity := 0; observation_provider_rt.py:638-749).  The distance criterion is the only live
+                                 * one in ego view: the reference computes the agents' lanelets (for the mask by lanelet relation) in its
+                                 * bird-view branch only (:537-588), so that mask stays empty (map_manager.py:21,102-118). */
   float distance_mask_agents;   /* thresholds.distance_mask_agents = 5 * length (road_traffic.py:663) */
 } sigmaenv_config_t;
 

@@ -95,10 +95,9 @@ def check_supported(p: Parameters) -> None:
         bad.append("is_observe_distance_to_boundaries=False")
     if not p.is_observe_distance_to_center_line:
         bad.append("is_observe_distance_to_center_line=False")
-    if p.is_apply_mask and p.scenario_type not in ("cpm_entire", "cpm_mixed"):
-        # the CPM parser provides no neighbouring-lanelet table, so only the distance criterion applies there
-        # (observation_provider_rt.py:646-662); the OSM maps additionally mask by lanelet relation, which is not built
-        bad.append(f"is_apply_mask=True on {p.scenario_type!r} (mask by neighbouring lanelets)")
+    # is_apply_mask: in ego view (the only view built) only the DISTANCE criterion is live in the reference -- the lanelet of every agent
+    # (MapManager.determine_current_lanelet) is only computed in the bird-view branch of update_state (observation_provider_rt.py:537-588),
+    # so current_lanelet_idx stays empty and determine_masked_agents_by_lanelets masks nobody (map_manager.py:21,102-118) on every map
     if p.is_obs_steering:
         bad.append("is_obs_steering=True")
     if p.is_observe_ref_path_other_agents:

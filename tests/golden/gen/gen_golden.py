@@ -499,6 +499,12 @@ TRAJS = {
     # Parameters' default is_apply_mask=True on the CPM map (no neighbouring-lanelet table there: the distance mask only)
     "cpm16_mask": dict(T=24, B=3, seed=24, mode_pattern=[1, 0, 1], n_agents=16, scenario_type="cpm_entire", dt=0.05,
                        is_use_mtv_distance=False, rew_method="distance", is_apply_mask=True),
+    # is_apply_mask on OSM maps (whose parser lists neighbouring lanelets): in ego view the lanelet mask stays empty -- the agents' lanelets
+    # are only computed in the bird-view branch (observation_provider_rt.py:537-588) -- so these pin the distance mask there as well
+    "intersection4_mask": dict(T=40, B=3, seed=25, mode_pattern=[1, 1, 0], n_agents=4, scenario_type="intersection_1", dt=0.1,
+                               is_use_mtv_distance=False, rew_method="distance", is_apply_mask=True),
+    "roundabout6_mask": dict(T=40, B=2, seed=26, mode_pattern=[1, 0], n_agents=6, scenario_type="roundabout_2", dt=0.1,
+                             is_use_mtv_distance=True, rew_method="ttc", is_apply_mask=True),
     # "clf" nominal controller (cbf_qp.py:2616-2628): the margins are evaluated at a P controller's action instead of the policy's
     "onramp4_cbf_clf": dict(T=24, B=3, seed=23, mode_pattern=[1, 0, 1], hook="cbf", n_agents=4, scenario_type="on_ramp_1", dt=0.05,
                             is_use_mtv_distance=False, rew_method="cbf", is_using_cbf_training=True, is_solve_qp=False, nom_controller_type="clf"),

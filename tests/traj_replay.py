@@ -17,7 +17,7 @@ from sigmarl_amd.params import Parameters, make_config
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 TRAJ_NAMES = ["cpm16_c2c", "cpm16_mtv", "intersection4_c2c", "onramp6_mtv", "cpm16_c2c_noreset", "cpm8_mtv_noreset", "cpmmixed4_c2c",
-              "cpm16_cbf", "intersection4_cbf", "onramp4_cbf_clf", "cpm16_mask"]
+              "cpm16_cbf", "intersection4_cbf", "onramp4_cbf_clf", "cpm16_mask", "intersection4_mask", "roundabout6_mask"]
 # The reference rounds the pseudo distance to fp16 and differentiates it numerically (pseudo_distance.py:118, cbf_qp.py:624-644): a
 # one-ulp difference in a float32 circle centre (torch's SLEEF cos/sin vs the correctly rounded ones of oracle and HIP path) can flip
 # an fp16 rounding and move a margin by up to ~5e-3.  Against the reference goldens the CBF quantities are therefore checked as:
