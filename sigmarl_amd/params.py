@@ -108,9 +108,7 @@ def check_supported(p: Parameters) -> None:
         bad.append("reset_agent_fixed_duration>0")
     if p.is_challenging_initial_state_buffer:
         bad.append("is_challenging_initial_state_buffer=True")
-    if p.is_using_cbf_testing:
-        bad.append("CBF-QP safety filter at test time (BASELINE config 5)")
-    if p.is_using_cbf_training or "cbf" in p.rew_method:
+    if p.is_using_cbf_training or p.is_using_cbf_testing or "cbf" in p.rew_method:
         # built: the centralized QP (is_solve_qp=True) and the QP-free margin reward (sigmarl/cbf_qp.py:2534-2560); not the grouped QPs
         if p.is_grouping_agents:
             bad.append("is_grouping_agents=True")

@@ -281,7 +281,10 @@ class ScenarioRoadTraffic(BaseScenario):
         ref_paths = SimpleNamespace(short_term=e.buffer(capi.BUF_SHORT_TERM), scenario_id=pth[..., 1], path_id=pth[..., 2], point_id=pth[..., 3])
         act = e.buffer(capi.BUF_ACTION)
         nom = e.buffer(capi.BUF_CBF_NOMINAL)
-        qp = bool(self.env.cfg.rew_flags & capi.REW_CBF_QP)  # the CBF-QP leaves its result in world_state.nominal_action_* (cbf_qp.py:1315-1379)
+        # with a CBF controller in the loop (training or testing) world_state.nominal_action_* is what CBFQP left behind
+        # (cbf_qp.py:1315-1379); without one info() mirrors the applied action (road_traffic.py:1522-1540)
+        pp = self.parameters
+        qp = bool((pp.is_using_cbf_training or pp.is_using_cbf_testing) and pp.is_solve_qp)
         self.world_state = SimpleNamespace(
             distances=distances, collisions=collisions, ref_paths_agent_related=ref_paths, vertices=e.buffer(capi.BUF_VERTICES), world=self._world,
             nominal_action_vel=(nom if qp else act)[..., 0], nominal_action_steer=(nom if qp else act)[..., 1],
