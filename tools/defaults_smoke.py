@@ -1,5 +1,8 @@
 """The reference's DEFAULT Parameters() through the VMAS surface (is_apply_mask, observation noise, mtv distances): a six-step smoke."""
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from sigmarl_amd.params import Parameters
 from sigmarl_amd.scenario import make_scenario
