@@ -326,3 +326,51 @@ def test_cbf_qp_rollout_reward_vs_oracle(apply, nominal):
     assert changed > 0
     dev.close()
     ora.close()
+
+
+def test_cbf_qp_dense_cluster_uses_the_full_system():
+    """24 vehicles piled within half a metre: (almost) every vehicle is coupled to others through active pair rows, more than the 16 the
+    compacted register factorisation takes -- the full-system LDS path; same minimiser as the oracle, KKT conditions hold."""
+    from test_cbf_qp import check_kkt
+
+    z, meta = _cbf_fixture()
+    N, B = 24, 6
+    mp = load_map("cpm_entire")
+    p = Parameters(n_agents=N, scenario_type="cpm_entire", dt=0.05, rew_method="cbf", is_solve_qp=True, is_using_cbf_training=True,
+                   is_obs_noise=False, is_apply_mask=False)
+    cfg = make_config(p, mp, B)
+    dev, ora = _hip_env(cfg, mp), ob.OracleEnv(cfg, mp)
+    seg_l, seg_r = cbf.load_segment_tables(mp)
+    rng = np.random.default_rng(9)
+    st8 = np.zeros((B, N, 8), np.float32)
+    ids = np.zeros((B, N, 4), np.int32)
+    for b in range(B):
+        st8[b, :, :5] = z["p2_state"][b, 0]                                   # everybody starts from vehicle 0's pose ...
+        st8[b, :, 0:2] += rng.uniform(-0.25, 0.25, (N, 2)).astype(np.float32)  # ... scattered within half a metre
+        st8[b, :, 2] += rng.uniform(-0.5, 0.5, N).astype(np.float32)
+        st8[b, :, 3] = rng.uniform(0.0, 1.0, N).astype(np.float32)
+        ids[b, :, 0] = z["p2_path"][b, 0]
+    ids[..., 2] = ids[..., 0]
+    for e in (dev, ora):
+        e.cbf_attach(cbf.make_cbf_config(p), seg_l, seg_r)
+        e.reset(np.repeat(np.arange(B), N), np.tile(np.arange(N), B), ids.reshape(-1, 4), st8.reshape(-1, 8), 1)
+    act = rng.uniform(-0.3, 1.0, (B, N, 2)).astype(np.float32)
+    safe_d, u_d, info_d = dev.cbf_qp(act)
+    safe_o, u_o, info_o, con, unom = ora.cbf_qp(act, with_data=True)
+    assert info_d[:, 1].all() and info_o[:, 1].all(), (info_d, info_o)
+    # coupled vehicles per env (from the oracle's active pair rows at its solution): the case must exceed the compact limit somewhere
+    n_lane = N * 3 * 2
+    worst_coupled = 0
+    for b in range(B):
+        cpl = set()
+        for row in con[b][n_lane:]:
+            i, j = int(row[0]), int(row[1])
+            g = row[2:6] @ u_o[b].reshape(-1)[[2 * i, 2 * i + 1, 2 * j, 2 * j + 1]] + row[6] + max(row[7], 0.0)
+            if g < 0:
+                cpl.update((i, j))
+        worst_coupled = max(worst_coupled, len(cpl))
+    assert worst_coupled > 16, worst_coupled
+    assert np.abs(u_d - u_o).max() <= 1e-6, np.abs(u_d - u_o).max()
+    check_kkt(ora, u_d, con, unom, "rl", tol=1e-7)
+    dev.close()
+    ora.close()
