@@ -333,7 +333,7 @@ def main():
     except Exception:  # noqa: BLE001
         pass
     out = {
-        "metric": "env-steps/sec (agents x envs x steps), CPM scenario, 16 agents",
+        "metric": f"env-steps/sec (agents x envs x steps), CPM scenario, {N} agents",
         "value": value, "unit": "agent-env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
