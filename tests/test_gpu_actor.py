@@ -183,9 +183,7 @@ def test_rollout_with_cbf_qp_equals_stepwise_calls():
         env2.set_slab(slab2[t])
         env2.step_autoreset(safe, seed=4, counter=70 + t)
         env2.sync()
-    # the QP's float64 atomics are not summation-order deterministic: states agree to rounding, not bitwise
-    assert float((env.state - env2.state).abs().max()) <= 1e-5
-    assert float((slab - slab2).abs().max()) <= 1e-4
+    assert torch.equal(env.state, env2.state) and torch.equal(slab, slab2)  # the QP launch is bitwise repeatable
     assert torch.equal(env.buffer(capi.BUF_TIMER), env2.buffer(capi.BUF_TIMER))
     for e in (env, env2):
         e.close()

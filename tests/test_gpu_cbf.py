@@ -374,3 +374,21 @@ def test_cbf_qp_dense_cluster_uses_the_full_system():
     check_kkt(ora, u_d, con, unom, "rl", tol=1e-7)
     dev.close()
     ora.close()
+
+
+def test_cbf_qp_is_bitwise_repeatable():
+    """The candidate list is compacted in row order and the Newton phase runs on one wavefront (its LDS atomics execute in program / lane
+    order): repeated launches on the same state return the same bits."""
+    import torch
+    from test_cbf_qp import qp_case
+
+    dev, act = qp_case(_hip_env, N=16, B=48)
+    a = torch.as_tensor(act).cuda()
+    outs = []
+    for _ in range(4):
+        u = torch.zeros((48, 16, 2), dtype=torch.float64, device="cuda")
+        safe = dev.env.cbf_qp(a, None, u, None)
+        dev.env.sync()
+        outs.append((u.clone(), safe.clone()))
+    assert all(torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]) for o in outs[1:])
+    dev.close()
