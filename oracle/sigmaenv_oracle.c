@@ -17,14 +17,16 @@
  *   - fp32 everywhere, one IEEE operation per reference torch op, no FMA contraction
  *     (-ffp-contract=off) EXCEPT torch.norm over a length-2 dim, which PyTorch-CPU
  *     evaluates as sqrt(fma(y, y, x*x)) [measured in the build container];
- *   - sin/cos/tan/atan/atan2 are the correctly rounded fp32 value, obtained as
- *     (float)f((double)x) (the reference uses SLEEF, within 1 ulp of this);
+ *   - sin/cos/tan/atan are the correctly rounded fp32 value, (float) of a shared fp64 evaluation
+ *     (include/sigma_trig_f32.h; the reference's MKL vector math is within 1 ulp of it); atan2 is
+ *     SLEEF's 1.0-ULP algorithm restated there, bit-identical to torch.atan2;
  *   - argmin/top-k ties resolve to the lowest index (torch.min semantics).
  *
  * Every function cites the reference lines it follows (paths relative to
  * /root/reference/sigmarl).
  */
 #include "../include/sigmaenv.h"
+#include "../include/sigma_trig_f32.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -53,11 +55,13 @@ typedef struct sigmaenv_oracle {
 } oracle_t;
 
 /* ---- scalar helpers ------------------------------------------------------------------------------------------- */
-static inline float cr_sin(float x) { return (float)sin((double)x); }
-static inline float cr_cos(float x) { return (float)cos((double)x); }
-static inline float cr_tan(float x) { return (float)tan((double)x); }
-static inline float cr_atan(float x) { return (float)atan((double)x); }
-static inline float cr_atan2(float y, float x) { return (float)atan2((double)y, (double)x); }
+/* sin / cos / tan / atan: correctly rounded fp32 through the shared fp64 algorithm; atan2: SLEEF's algorithm == torch.atan2 bit for bit
+ * (include/sigma_trig_f32.h states what was measured about the reference's own trig) */
+static inline float cr_sin(float x) { return sigma_sinf(x); }
+static inline float cr_cos(float x) { return sigma_cosf(x); }
+static inline float cr_tan(float x) { return sigma_tanf(x); }
+static inline float cr_atan(float x) { return sigma_atanf(x); }
+static inline float cr_atan2(float y, float x) { return sigma_atan2f(y, x); }
 /* torch.norm(..., dim=<len-2 dim>) on PyTorch-CPU == sqrt(fma(y,y,x*x)) */
 static inline float norm2(float x, float y) { return sqrtf(fmaf(y, y, x * x)); }
 static inline float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
@@ -912,3 +916,16 @@ void sigmaenv_oracle_fn_wrap(int n, const float* a, float* out) {
 }
 
 #include "sigmaenv_cbf_oracle.inc"
+
+/* the contract's trig on arrays (tests/test_trig.py): kind 0 sin, 1 cos, 2 tan, 3 atan (b unused), 4 atan2(a, b) */
+void sigmaenv_oracle_fn_trig(int kind, int n, const float* a, const float* b, float* out) {
+  for (int k = 0; k < n; ++k) {
+    switch (kind) {
+      case 0: out[k] = cr_sin(a[k]); break;
+      case 1: out[k] = cr_cos(a[k]); break;
+      case 2: out[k] = cr_tan(a[k]); break;
+      case 3: out[k] = cr_atan(a[k]); break;
+      default: out[k] = cr_atan2(a[k], b[k]); break;
+    }
+  }
+}

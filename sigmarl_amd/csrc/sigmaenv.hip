@@ -39,17 +39,21 @@ __device__ __constant__ uint32_t W_REF_BITS[3] = {0x3F0E38E3u, 0x3EAAAAABu, 0x3D
 #define COL_STRIDE(N) ((N) + 4)    /* byte stride whose word stride ((N+4)/4) is odd for N = 16 */
 #define ESCR_BYTES (8 * 4 * 4 * 16) /* up to 8 wavefronts x 4 lane groups x 4 segments x float4 */
 #define CAND_LIST 16               /* candidate chunks listed per (agent, polyline); longer masks fall back to bit counting */
+#define NEAR_CAP 8                 /* boundary segments within the circumradius listed per (agent, side); more are tested in place */
 struct Smem {
   float *st, *vold, *vnew, *shrt, *dref, *dleft, *dright, *dbound, *dist, *obs, *thr, *cs, *rew;
   int *path, *cp, *near, *flags, *npts;
-  unsigned long long* cmask;  // candidate-chunk masks of the centre / left / right scan, [S][3]
-  uint8_t* cand;              // the first CAND_LIST set bits of every mask as a list of chunk indices, [S][3][CAND_LIST]
+  unsigned long long* cmask;  // candidate-chunk masks of the centre / left / right scan, [S][3]            (block layout only)
+  uint8_t* cand;              // the first CAND_LIST set bits of every mask as a list of chunk indices, [S][3][CAND_LIST]   (block layout only)
   uint16_t* pidx;             // (i, j), i < j, of the u-th unordered agent pair of an env: i | j << 8, [N (N - 1) / 2]
-  float4* escr;               // B2 staging of the segments close enough to hit the rectangle, [MAX_WAVES][4 lane groups][4]
+  float4* escr;               // B2 staging of the segments close enough to hit the rectangle, [MAX_WAVES][4 lane groups][4]  (block layout only)
   uint8_t* col;
-  __device__ Smem(char* base, int S, int N, int K, int D) {
+  uint8_t* nearl;             // wave layout: indices of the boundary segments within the circumradius, [S][2][NEAR_CAP]
+  uint8_t* nearc;             // wave layout: their count (bit 7: a hit was already found in place), [S][2]
+  // LEAN = the wave-per-tile layout of the step kernel: no escr / cmask / cand (its scan keeps them in registers), near-segment lists instead
+  __device__ Smem(char* base, int S, int N, int K, int D, bool lean = false) {
     escr = reinterpret_cast<float4*>(base);  // first: the dynamic LDS base is 16-byte aligned
-    float* f = reinterpret_cast<float*>(base + ESCR_BYTES);
+    float* f = reinterpret_cast<float*>(base + (lean ? 0 : ESCR_BYTES));
     obs = f; f += (S * D + 3) & ~3;  // 16-byte aligned (vector copy to HBM), and so is everything up to vold
     st = f; f += S * 8;
     vold = f; f += S * 10;
@@ -70,25 +74,47 @@ struct Smem {
     flags = i; i += S * 4;
     npts = i; i += S * 3;  // point counts of the agent's centre line / left / right boundary
     i += (S * 3) & 1;      // keep the 64-bit masks 8-byte aligned
-    cmask = reinterpret_cast<unsigned long long*>(i); i += S * 3 * 2;
-    cand = reinterpret_cast<uint8_t*>(i); i += S * 3 * (CAND_LIST / 4);
+    cmask = reinterpret_cast<unsigned long long*>(i);
+    if (!lean) i += S * 3 * 2;
+    cand = reinterpret_cast<uint8_t*>(i);
+    if (!lean) i += S * 3 * (CAND_LIST / 4);
     pidx = reinterpret_cast<uint16_t*>(i); i += (N * (N - 1) / 2 + 1) / 2;
+    nearl = reinterpret_cast<uint8_t*>(i);
+    if (lean) i += (S * 2 * NEAR_CAP + 3) / 4;
+    nearc = reinterpret_cast<uint8_t*>(i);
+    if (lean) i += (S * 2 + 3) / 4;
     col = reinterpret_cast<uint8_t*>(i);
   }
-  __host__ __device__ static size_t bytes(int S, int N, int K, int D) {
+  __host__ __device__ static size_t bytes(int S, int N, int K, int D, bool lean = false) {
     size_t f = (size_t)S * 8 + S * 10 * 2 + S * NS * 2 + S + S * 5 * 2 + S + (size_t)S * DIST_STRIDE(N) + (size_t)S * D + S * 3 + S * 2 + S * 2;
-    size_t i = (size_t)S + S * 3 + S * (K > 0 ? K : 1) + S * 4 + S * 3 + 1 + (size_t)S * 3 * 2 + (size_t)S * 3 * (CAND_LIST / 4);
-    return ESCR_BYTES + (f + i + 3 + (size_t)(N * (N - 1) / 2 + 1) / 2) * 4 + (size_t)S * COL_STRIDE(N) + 16;
+    size_t i = (size_t)S + S * 3 + S * (K > 0 ? K : 1) + S * 4 + S * 3 + 1;
+    i += lean ? ((size_t)(S * 2 * NEAR_CAP + 3) / 4 + (size_t)(S * 2 + 3) / 4) : ((size_t)S * 3 * 2 + (size_t)S * 3 * (CAND_LIST / 4));
+    return (lean ? 0 : ESCR_BYTES) + (f + i + 3 + (size_t)(N * (N - 1) / 2 + 1) / 2) * 4 + (size_t)S * COL_STRIDE(N) + 16;
   }
 };
 
-// what a workgroup covers
+// The thread group that owns a tile: a whole workgroup (reset / observe / start-table kernels) or ONE wavefront (the step kernel, whose
+// wavefronts never synchronise with each other).  Within a wavefront LDS operations execute in program order; wave_sync only stops the
+// compiler from moving LDS accesses across the point where other lanes' data is consumed.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <bool WAVE>
+struct Grp {
+  __device__ static __forceinline__ int tid() { return WAVE ? (int)(threadIdx.x & 63) : (int)threadIdx.x; }
+  __device__ static __forceinline__ int size() { return WAVE ? 64 : (int)blockDim.x; }
+  __device__ static __forceinline__ void sync() { if (WAVE) wave_sync(); else __syncthreads(); }
+};
+
+// what a workgroup (or, in the step kernel, a wavefront) covers
 struct Tile {
   int env0, nenv, slots, N, K, D;
   size_t a0;  // global agent index of slot 0 (= env0 * N)
-  __device__ Tile(const sigmaenv_config_t& c, int G) {
+  __device__ Tile(const sigmaenv_config_t& c, int G, int tile_index = -1) {
     N = c.n_agents; K = c.n_nearing; D = 4 + 2 * NS + 11 * K;
-    env0 = blockIdx.x * G;
+    env0 = (tile_index < 0 ? (int)blockIdx.x : tile_index) * G;
     nenv = min(G, c.n_envs - env0);
     slots = nenv * N;
     a0 = (size_t)env0 * N;
@@ -537,9 +563,11 @@ __device__ inline void topk_nearest(const float* Drow, int N, int K, int* out) {
 // Rows are assembled in LDS and written out coalesced.  All threads of the block participate.
 // env_sel / n_sel: restrict the work to these envs of the tile (the reset tail only refreshes the envs it touched); the loops then run
 // over "virtual" slots v = (position in env_sel) * N + agent, so that the lanes stay densely used.
+template <bool WAVE = false>
 __device__ inline void observe_tile(const sigmaenv_config_t& c, const Smem& s, const DevBufs& g, const Tile& t, int ts_base = -1,
                                     const int* env_sel = nullptr, int n_sel = 0) {
   const int N = t.N, K = t.K, D = t.D;
+  const int TID = Grp<WAVE>::tid(), NTHR = Grp<WAVE>::size();
   const int n_slots = env_sel ? n_sel * N : t.slots;
   auto real_slot = [&](int v) {
     if (!env_sel) return v;
@@ -550,11 +578,11 @@ __device__ inline void observe_tile(const sigmaenv_config_t& c, const Smem& s, c
   const float n_pos = (float)((double)c.length * 10.0);   // normalizers.pos, road_traffic.py:588-592
   const float n_v = c.max_speed;                            // :596
   const float n_dl = (float)((double)c.lane_width * 3.0);   // :599-601 (distance_lanelet also normalises the agent distances)
-  if (K == 2 && n_slots * 4 <= (int)blockDim.x) {
+  if (K == 2 && n_slots * 4 <= NTHR) {
     // Two nearest of every agent with FOUR lanes per agent (a quad): lane q scans the candidates q, q + 4, q + 8, ... in increasing
     // order, then the quads merge their (distance, index)-sorted pairs through DPP quad permutations.  Same result as the selection
     // loop (ascending distance, lowest index on ties, unconditional first entries), a quarter of its dependent chain.
-    const int tid = threadIdx.x, qd = tid & 3, v = tid >> 2;
+    const int tid = TID, qd = tid & 3, v = tid >> 2;
     const bool act = v < n_slots;
     const int sl = act ? real_slot(v) : 0;
     const float* row = s.dist + sl * DIST_STRIDE(N);
@@ -587,19 +615,19 @@ __device__ inline void observe_tile(const sigmaenv_config_t& c, const Smem& s, c
 #undef SIGMA_QUAD
     if (act && qd == 0) { s.near[sl * K] = i0; s.near[sl * K + 1] = i1; }
   } else {
-    for (int v = threadIdx.x; v < n_slots; v += blockDim.x) {
+    for (int v = TID; v < n_slots; v += NTHR) {
       const int sl = real_slot(v);
       topk_nearest(s.dist + sl * DIST_STRIDE(N), N, K, s.near + sl * K);
     }
   }
   TSO(0);
-  __syncthreads();
+  Grp<WAVE>::sync();
   TSO(1);
   // The reference goes through atan2 / cos / sin (helper_scenario.py:1261-1271); the same rotation is applied here with the
   // agent's cos(psi), sin(psi) (already needed for the vertices): rel = R(-psi_i) (p_j - p_i).  Identical up to ~1e-7, well inside
   // the 1e-5 bar; no mask or index depends on it.  The oracle keeps the reference's formulation.
   const int T1 = NS + 4 * K;
-  for (int w = threadIdx.x; w < n_slots * T1; w += blockDim.x) {
+  for (int w = TID; w < n_slots * T1; w += NTHR) {
     const int v = fdiv(w, g.mT1), q = w - v * T1;
     const int sl = real_slot(v);
     int ebase = fdiv(sl, g.mN) * N;
@@ -628,8 +656,8 @@ __device__ inline void observe_tile(const sigmaenv_config_t& c, const Smem& s, c
   // from its back, so that both run at the same time when the block is wide enough
   const int T2 = K + 1;
   const int n2 = n_slots * T2, n3 = n_slots;
-  const int span = max(n2 + n3, (int)blockDim.x);
-  for (int w0 = threadIdx.x; w0 < span; w0 += blockDim.x) {
+  const int span = max(n2 + n3, NTHR);
+  for (int w0 = TID; w0 < span; w0 += NTHR) {
     const int w3 = (span - 1) - w0;  // the back of the span carries the third pass
     if (w0 < n2) {
       const int w = w0;
@@ -664,24 +692,24 @@ __device__ inline void observe_tile(const sigmaenv_config_t& c, const Smem& s, c
     }
   }
   TSO(3);
-  __syncthreads();
+  Grp<WAVE>::sync();
   TSO(4);
   if (env_sel) {  // only the rows of the selected envs (they are contiguous per env)
     const int ND = N * D, NK = N * K;
     for (int q = 0; q < n_sel; ++q) {
       const int e = env_sel[q];
-      for (int k = threadIdx.x; k < ND; k += blockDim.x) g.obs[(t.a0 + e * N) * D + k] = s.obs[e * ND + k];
-      for (int k = threadIdx.x; k < NK; k += blockDim.x) g.nearing[(t.a0 + e * N) * K + k] = s.near[e * NK + k];
+      for (int k = TID; k < ND; k += NTHR) g.obs[(t.a0 + e * N) * D + k] = s.obs[e * ND + k];
+      for (int k = TID; k < NK; k += NTHR) g.nearing[(t.a0 + e * N) * K + k] = s.near[e * NK + k];
     }
   } else {
     if ((D & 3) == 0) {  // rows are whole float4s: both the LDS staging area and the tile's slice of g.obs are 16-byte aligned
       const float4* so4 = reinterpret_cast<const float4*>(s.obs);
       float4* go4 = reinterpret_cast<float4*>(g.obs + t.a0 * D);
-      for (int k = threadIdx.x; k < t.slots * D / 4; k += blockDim.x) go4[k] = so4[k];
+      for (int k = TID; k < t.slots * D / 4; k += NTHR) go4[k] = so4[k];
     } else {
-      for (int k = threadIdx.x; k < t.slots * D; k += blockDim.x) g.obs[t.a0 * D + k] = s.obs[k];
+      for (int k = TID; k < t.slots * D; k += NTHR) g.obs[t.a0 * D + k] = s.obs[k];
     }
-    for (int k = threadIdx.x; k < t.slots * K; k += blockDim.x) g.nearing[t.a0 * K + k] = s.near[k];
+    for (int k = TID; k < t.slots * K; k += NTHR) g.nearing[t.a0 * K + k] = s.near[k];
   }
   TSO(5);
 #undef TSO
@@ -714,9 +742,10 @@ struct ResetPrefetch {
   bool have;  // the first env of this wavefront (e == wave) has its candidates here already
 };
 
+template <bool WAVE = false>
 __device__ inline void auto_reset_tile(const sigmaenv_config_t& c, const DevMap& m, const DevBufs& g, const Smem& s, const Tile& t,
                                        const unsigned long long* s_mask, const int* s_full, uint64_t seed, uint64_t counter, int path_first,
-                                       int path_count, int obs_mode, const ResetPrefetch& pre);
+                                       int path_count, int obs_mode, const ResetPrefetch& pre, int g_cap = 64);
 #define MAX_G 64
 #ifndef STEP_MIN_WAVES
 #define STEP_MIN_WAVES 4  // <= 128 VGPRs: 4 workgroups per CU resident, 16 workgroups per CU at 16x4096 = 4 full rounds
@@ -1194,8 +1223,9 @@ __global__ void sigmaenv_reset_scatter_kernel(DevBufs g, int N, int n, const int
 // per-env tail (road_traffic.py:902-923) for the envs of the tile whose bit is set in env_bits; with_obs: also a fresh
 // observation of the whole tile.  Expects s.st / s.path / s.vnew / s.cp (scan guesses) of the tile in LDS; agent_mask[e] is the
 // per-env agent bit mask, full[e] the full-env flag.  All threads of the block participate.
+template <bool WAVE = false>
 __device__ inline void reset_finish_body(const sigmaenv_config_t& c, const DevBufs& g, const Smem& s, const Tile& t,
-                                         const unsigned long long* agent_mask, const int* full, int with_obs);
+                                         const unsigned long long* agent_mask, const int* full, int with_obs, int g_cap = 64);
 __device__ inline void reset_derive_body(const sigmaenv_config_t& c, const DevMap& m, const DevBufs& g, const Smem& s, const Tile& t,
                                          const unsigned long long* agent_mask, const int* full, int with_obs) {
   const int N = t.N;
@@ -1263,19 +1293,20 @@ __device__ inline void reset_derive_body(const sigmaenv_config_t& c, const DevMa
     for (int k = 0; k < NS * 2; ++k) { g.short_term[gi * NS * 2 + k] = sp[k]; s.shrt[sl * NS * 2 + k] = sp[k]; }
   }
 #undef TS2
-  reset_finish_body(c, g, s, t, agent_mask, full, with_obs);
+  reset_finish_body<false>(c, g, s, t, agent_mask, full, with_obs);
 }
 
 // tail of every touched env: mutual distances, collisions cleared, prev_pos := pos, timer (road_traffic.py:902-923); with_obs:
 // also a fresh observation of the whole tile (2: every input of it is already in LDS).  Expects the derived state of the marked
 // agents in LDS and HBM.
+template <bool WAVE>
 __device__ inline void reset_finish_body(const sigmaenv_config_t& c, const DevBufs& g, const Smem& s, const Tile& t,
-                                         const unsigned long long* agent_mask, const int* full, int with_obs) {
+                                         const unsigned long long* agent_mask, const int* full, int with_obs, int g_cap) {
   const int N = t.N;
-  const int tid = threadIdx.x;
+  const int tid = Grp<WAVE>::tid();
 #define TS2(k) do { if (g.dbg_ts2 && tid == 0) g.dbg_ts2[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
   const float diag = sqrtf(c.world_x_dim * c.world_x_dim + c.world_y_dim * c.world_y_dim);
-  for (int p = tid; p < t.slots * N; p += blockDim.x) {
+  for (int p = tid; p < t.slots * N; p += Grp<WAVE>::size()) {
     int si = fdiv(p, g.mN), j = p - si * N;
     int e = fdiv(si, g.mN);
     if (agent_mask[e] == 0ull) continue;
@@ -1285,7 +1316,7 @@ __device__ inline void reset_finish_body(const sigmaenv_config_t& c, const DevBu
     g.dist_agents[t.a0 * N + p] = d;
     g.col_agents[t.a0 * N + p] = 0;
   }
-  for (int sl = tid; sl < t.slots; sl += blockDim.x) {
+  for (int sl = tid; sl < t.slots; sl += Grp<WAVE>::size()) {
     int e = sl / N, i = sl - e * N;
     if (agent_mask[e] == 0ull) continue;
     const size_t gi = t.a0 + sl;
@@ -1301,21 +1332,21 @@ __device__ inline void reset_finish_body(const sigmaenv_config_t& c, const DevBu
   }
   if (with_obs) {
     __threadfence_block();
-    __syncthreads();
+    Grp<WAVE>::sync();
     TS2(5);
     if (with_obs == 2) {
       // every input of the observation is in LDS (fused tail / a tile whose envs were all reset): only the touched envs' rows change
-      int* env_sel = const_cast<int*>(full) + MAX_G + 2;  // after s_full, s_any and the step kernel's pair counter
+      int* env_sel = const_cast<int*>(full) + g_cap + 2;  // after s_full, s_any and the step kernel's pair counter
       if (tid == 0) {
         int cnt = 0;
         for (int e = 0; e < t.nenv; ++e) if (agent_mask[e]) env_sel[1 + cnt++] = e;
         env_sel[0] = cnt;
       }
-      __syncthreads();
-      observe_tile(c, s, g, t, -1, env_sel + 1, env_sel[0]);
+      Grp<WAVE>::sync();
+      observe_tile<WAVE>(c, s, g, t, -1, env_sel + 1, env_sel[0]);
     } else {
       load_tile_for_observation(s, g, t);
-      observe_tile(c, s, g, t);
+      observe_tile<WAVE>(c, s, g, t);
     }
     TS2(6);
   }
@@ -1489,11 +1520,12 @@ __device__ __forceinline__ void place_from_start_table(const DevMap& m, const De
 // agent up front and the FIRST feasible try wins, which is exactly the sequential loop's result for the same draws (bounded to
 // 64 tries; the reference loops without bound).  Then the deterministic reset as in sigmaenv_reset and a fresh observation.
 // All threads of the block participate.
+template <bool WAVE>
 __device__ inline void auto_reset_tile(const sigmaenv_config_t& c, const DevMap& m, const DevBufs& g, const Smem& s, const Tile& t,
                                        const unsigned long long* s_mask, const int* s_full, uint64_t seed, uint64_t counter, int path_first,
-                                       int path_count, int obs_mode, const ResetPrefetch& pre) {
+                                       int path_count, int obs_mode, const ResetPrefetch& pre, int g_cap) {
   const int N = t.N;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
+  const int tid = Grp<WAVE>::tid(), lane = tid & 63, wave = tid >> 6, n_waves = Grp<WAVE>::size() >> 6;
   const ResetDraw rd{seed, counter, path_first, path_count};
 #define TS2(k) do { if (g.dbg_ts2 && tid == 0) g.dbg_ts2[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
   TS2(1);
@@ -1578,11 +1610,13 @@ __device__ inline void auto_reset_tile(const sigmaenv_config_t& c, const DevMap&
     }
   }
   __threadfence_block();
-  __syncthreads();
+  Grp<WAVE>::sync();
   TS2(2);
-  reset_finish_body(c, g, s, t, s_mask, s_full, obs_mode);
+  reset_finish_body<WAVE>(c, g, s, t, s_mask, s_full, obs_mode, g_cap);
 #undef TS2
 }
+
+#include "sigmaenv_step_wave.inc"
 
 // stand-alone launch: one workgroup per tile; tiles without a finished env / a reset request exit at once
 __global__ void __launch_bounds__(512) sigmaenv_auto_reset_kernel(sigmaenv_config_t c, DevMap m, DevBufs g, uint64_t seed, uint64_t counter,
@@ -1637,7 +1671,10 @@ struct sigmaenv {
   size_t smem_bytes = 0;
   int block = 256;
   int reset_block = 256;
-  int G = 1;      // environments per workgroup (G * N <= 64 agent slots)
+  int G = 1;      // environments per workgroup (G * N <= 64 agent slots) of the block kernels (reset / observe)
+  int wave_G = 1, wave_wpb = 1, wave_grid = 1;  // step kernel: environments per wavefront tile, wavefronts per workgroup, workgroups
+  size_t wave_tile_lds = 0;
+  bool use_block_step = false;  // SIGMAENV_STEP_KERNEL=block: the workgroup-per-tile step kernel (A/B baseline)
   int dbg_skip = 0;  // SIGMAENV_DEBUG_SKIP: phase-ablation bit mask for profiling experiments (results invalid when non-zero)
   int grid = 1;
   void* bufs[SIGMAENV_BUF_COUNT] = {nullptr};
@@ -1907,7 +1944,7 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
   g.dbg_ts = nullptr;
   g.dbg_ts2 = nullptr;
   if (const char* e = getenv("SIGMAENV_TIMESTAMPS")) {
-    if (atoi(e) == 1) { ALLOC(g.dbg_ts, (size_t)B * 16 * sizeof(unsigned long long)); }
+    if (atoi(e) == 1) { ALLOC(g.dbg_ts, (size_t)B * 16 * sizeof(unsigned long long)); (void)hipMemsetAsync(g.dbg_ts, 0, (size_t)B * 128, h->stream); }
     if (atoi(e) == 2) { ALLOC(g.dbg_ts2, (size_t)B * 16 * sizeof(unsigned long long)); hipMemsetAsync(g.dbg_ts2, 0, (size_t)B * 128, h->stream); }
   }
 #undef ALLOC
@@ -1940,6 +1977,22 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_observe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem_bytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_reset_derive_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem_bytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_auto_reset_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem_bytes);
+  }
+  {  // the step kernel's tiling: one wavefront per tile of wave_G environments; as many tiles as give every SIMD four wavefronts
+    int wg = 64 / N;
+    if (wg < 1) wg = 1;
+    while (wg > 1 && (B + wg - 1) / wg < 16 * n_cu) wg >>= 1;
+    if (cfg->envs_per_group >= 1 && cfg->envs_per_group * N <= 64) wg = cfg->envs_per_group;
+    if (const char* e = getenv("SIGMAENV_WAVE_G")) { int v = atoi(e); if (v >= 1 && v * N <= 64) wg = v; }
+    h->wave_G = wg;
+    h->wave_wpb = 1;
+    if (const char* e = getenv("SIGMAENV_WPB")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) h->wave_wpb = v; }
+    h->wave_tile_lds = (((Smem::bytes(wg * N, N, K, h->D, true) + 15) & ~(size_t)15) + 16 * (size_t)wg + 16 + 15) & ~(size_t)15;
+    const int tiles = (B + wg - 1) / wg;
+    h->wave_grid = (tiles + h->wave_wpb - 1) / h->wave_wpb;
+    if (h->wave_tile_lds * h->wave_wpb > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(h->wave_tile_lds * h->wave_wpb));
+    if (const char* e = getenv("SIGMAENV_STEP_KERNEL")) h->use_block_step = (strcmp(e, "block") == 0);
   }
   if (hipStreamSynchronize(h->stream) != hipSuccess) { sigmaenv_destroy(h); return SIGMAENV_EHIP; }
   *out = h;
@@ -2010,8 +2063,12 @@ static int launch_step(sigmaenv* h, const float* actions, uint64_t seed, uint64_
     h->ev_used.push_back(slot);
     HIPCHK(h, hipEventRecord(h->ev_pool[slot].first, h->stream));
   }
-  hipLaunchKernelGGL(sigmaenv_step_kernel, dim3(h->grid), dim3(h->block), h->smem_bytes, h->stream, h->cfg, h->map, h->buf, actions, h->G,
-                     h->dbg_skip, seed, counter, path_first, path_count, h->buf.slab);
+  if (h->use_block_step)
+    hipLaunchKernelGGL(sigmaenv_step_kernel, dim3(h->grid), dim3(h->block), h->smem_bytes, h->stream, h->cfg, h->map, h->buf, actions, h->G,
+                       h->dbg_skip, seed, counter, path_first, path_count, h->buf.slab);
+  else
+    hipLaunchKernelGGL(sigmaenv_step_wave_kernel, dim3(h->wave_grid), dim3(64 * h->wave_wpb), h->wave_tile_lds * h->wave_wpb, h->stream, h->cfg, h->map,
+                       h->buf, actions, h->wave_G, (int)h->wave_tile_lds, seed, counter, path_first, path_count, h->buf.slab);
   HIPCHK(h, hipGetLastError());
   if (slot >= 0) HIPCHK(h, hipEventRecord(h->ev_pool[slot].second, h->stream));
   return SIGMAENV_OK;
@@ -2086,7 +2143,7 @@ extern "C" int sigmaenv_debug_timestamps(sigmaenv_t* h, unsigned long long* out,
     return n2;
   }
   if (!h->buf.dbg_ts) return 0;
-  int n = h->grid < max_groups ? h->grid : max_groups;
+  int n = h->B < max_groups ? h->B : max_groups;  // one row per tile; unused rows stay zero
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipMemcpy(out, h->buf.dbg_ts, (size_t)n * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return n;

@@ -3,8 +3,8 @@
 // Arithmetic contract (DESIGN.md "Arithmetic contract"): fp32, one IEEE operation per torch op of the reference,
 // compiled with -ffp-contract=off so nothing is fused implicitly; the only fused operation is the explicit fmaf in
 // norm2 (PyTorch-CPU evaluates torch.norm over a length-2 dim as sqrt(fma(y,y,x*x))).  Division and sqrt are the
-// correctly rounded forms (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).  sin/cos/tan/atan/atan2 are the
-// correctly rounded fp32 value obtained through the fp64 OCML routine: (float)f((double)x).
+// correctly rounded forms (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).  sin/cos/tan/atan are the correctly
+// rounded fp32 value through the fp64 algorithm the oracle shares (include/sigma_trig_f32.h): identical bits on both sides.
 //
 // Reference citations are relative to /root/reference/sigmarl.
 #pragma once
@@ -13,6 +13,7 @@
 #include <stdint.h>
 
 #include "../../include/sigmaenv.h"
+#include "../../include/sigma_trig_f32.h"
 
 #define NS SIGMAENV_N_SHORT_TERM
 #define PI32 3.14159274101257324f
@@ -85,16 +86,11 @@ __device__ __forceinline__ int fdiv(int x, uint32_t m) { return m ? (int)__umulh
 struct __attribute__((packed, aligned(4))) F4u { float x, y, z, w; };
 
 // ---- scalar helpers ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float cr_sin(float x) { return (float)sin((double)x); }
-__device__ __forceinline__ float cr_cos(float x) { return (float)cos((double)x); }
-__device__ __forceinline__ float cr_tan(float x) { return (float)tan((double)x); }
-__device__ __forceinline__ float cr_atan(float x) { return (float)atan((double)x); }
-__device__ __forceinline__ void cr_sincos(float x, float& s, float& c) {
-  double ds, dc;
-  sincos((double)x, &ds, &dc);
-  s = (float)ds;
-  c = (float)dc;
-}
+__device__ __forceinline__ float cr_sin(float x) { return sigma_sinf(x); }
+__device__ __forceinline__ float cr_cos(float x) { return sigma_cosf(x); }
+__device__ __forceinline__ float cr_tan(float x) { return sigma_tanf(x); }
+__device__ __forceinline__ float cr_atan(float x) { return sigma_atanf(x); }
+__device__ __forceinline__ void cr_sincos(float x, float& s, float& c) { sigma_sincosf(x, &s, &c); }
 __device__ __forceinline__ float norm2(float x, float y) { return sqrtf(fmaf(y, y, x * x)); }
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 __device__ __forceinline__ float remainder_pos(float a, float b) {  // torch.remainder, b > 0

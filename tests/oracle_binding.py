@@ -21,7 +21,7 @@ _f32p = C.POINTER(C.c_float)
 
 
 def build_oracle(force: bool = False) -> str:
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("sigmaenv_oracle.c", "sigmaenv_cbf_oracle.inc")] + [os.path.join(ROOT, "include", "sigmaenv.h")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("sigmaenv_oracle.c", "sigmaenv_cbf_oracle.inc")] + [os.path.join(ROOT, "include", f) for f in ("sigmaenv.h", "sigma_trig_f32.h")]
     if force or not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-B", "libsigmaenv_oracle.so"], stdout=subprocess.DEVNULL)
     return ORACLE_SO
@@ -43,6 +43,7 @@ def load_oracle() -> capi.Library:
             "fn_mtv": (None, [C.c_int, C.c_void_p, C.c_void_p]),
             "fn_ego": (None, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
             "fn_wrap": (None, [C.c_int, C.c_void_p, C.c_void_p]),
+            "fn_trig": (None, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
             "fn_pseudo_distance": (None, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
             "cbf_qp_ex": (C.c_int, [C.c_void_p] * 7),
             "path_table": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(_f32p), C.POINTER(_f32p), C.POINTER(_f32p)]),
