@@ -154,7 +154,7 @@ def main():
     for k in range(S):
         with torch.cuda.stream(streams[k]):
             kw = dict(params_kw, num_vmas_envs=Bs)
-            e = SigmaEnv(Parameters(**kw), n_envs=Bs, device=device, envs_per_group=(max(1, 64 // N) if S > 1 else 0))
+            e = SigmaEnv(Parameters(**kw), n_envs=Bs, device=device)
             e.reset_random(seed=seed * 64 + k)
             if args.cbf:
                 e.cbf_attach()

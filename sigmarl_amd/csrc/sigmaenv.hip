@@ -39,6 +39,7 @@ __device__ __constant__ uint32_t W_REF_BITS[3] = {0x3F0E38E3u, 0x3EAAAAABu, 0x3D
 #define COL_STRIDE(N) ((N) + 4)    /* byte stride whose word stride ((N+4)/4) is odd for N = 16 */
 #define ESCR_BYTES (8 * 4 * 4 * 16) /* up to 8 wavefronts x 4 lane groups x 4 segments x float4 */
 #define CAND_LIST 16               /* candidate chunks listed per (agent, polyline); longer masks fall back to bit counting */
+#define ITEM_CAP(S) ((S) * 24)       /* candidate chunks of a tile listed for the balanced scan; tasks beyond it walk their chunks themselves */
 #define NEAR_CAP 8                 /* boundary segments within the circumradius listed per (agent, side); more are tested in place */
 struct Smem {
   float *st, *vold, *vnew, *shrt, *dref, *dleft, *dright, *dbound, *dist, *obs, *thr, *cs, *rew;
@@ -48,8 +49,12 @@ struct Smem {
   uint16_t* pidx;             // (i, j), i < j, of the u-th unordered agent pair of an env: i | j << 8, [N (N - 1) / 2]
   float4* escr;               // B2 staging of the segments close enough to hit the rectangle, [MAX_WAVES][4 lane groups][4]  (block layout only)
   uint8_t* col;
-  uint8_t* nearl;             // wave layout: indices of the boundary segments within the circumradius, [S][2][NEAR_CAP]
-  uint8_t* nearc;             // wave layout: their count (bit 7: a hit was already found in place), [S][2]
+  // wave layout (step kernel): the balanced scan's work list and per-task accumulators
+  uint16_t* items;            // (task (pl-major) << 6 | chunk) of every candidate chunk of the tile, [ITEM_CAP(S)]
+  unsigned long long* acc64;  // per task: (bits of the minimal centre-point distance) << 32 | its lowest segment index, [S * 3]
+  uint32_t* acc32;            // per boundary task: bits of the four minimal SQUARED corner distances, [S * 2][4]
+  int* nearn;                 // per boundary task: number of segments within the circumradius, [S * 2]
+  uint8_t* nearl;             // indices of the boundary segments within the circumradius, [S * 2][NEAR_CAP]
   // LEAN = the wave-per-tile layout of the step kernel: no escr / cmask / cand (its scan keeps them in registers), near-segment lists instead
   __device__ Smem(char* base, int S, int N, int K, int D, bool lean = false) {
     escr = reinterpret_cast<float4*>(base);  // first: the dynamic LDS base is 16-byte aligned
@@ -79,16 +84,24 @@ struct Smem {
     cand = reinterpret_cast<uint8_t*>(i);
     if (!lean) i += S * 3 * (CAND_LIST / 4);
     pidx = reinterpret_cast<uint16_t*>(i); i += (N * (N - 1) / 2 + 1) / 2;
+    if (lean) i += ((reinterpret_cast<uintptr_t>(i) >> 2) & 1);  // 8-byte alignment of acc64 (the base is 16-byte aligned)
+    acc64 = reinterpret_cast<unsigned long long*>(i);
+    if (lean) i += S * 3 * 2;
+    acc32 = reinterpret_cast<uint32_t*>(i);
+    if (lean) i += S * 2 * 4;
+    nearn = i;
+    if (lean) i += S * 2;
+    items = reinterpret_cast<uint16_t*>(i);
+    if (lean) i += (ITEM_CAP(S) + 1) / 2;
     nearl = reinterpret_cast<uint8_t*>(i);
     if (lean) i += (S * 2 * NEAR_CAP + 3) / 4;
-    nearc = reinterpret_cast<uint8_t*>(i);
-    if (lean) i += (S * 2 + 3) / 4;
     col = reinterpret_cast<uint8_t*>(i);
   }
   __host__ __device__ static size_t bytes(int S, int N, int K, int D, bool lean = false) {
     size_t f = (size_t)S * 8 + S * 10 * 2 + S * NS * 2 + S + S * 5 * 2 + S + (size_t)S * DIST_STRIDE(N) + (size_t)S * D + S * 3 + S * 2 + S * 2;
     size_t i = (size_t)S + S * 3 + S * (K > 0 ? K : 1) + S * 4 + S * 3 + 1;
-    i += lean ? ((size_t)(S * 2 * NEAR_CAP + 3) / 4 + (size_t)(S * 2 + 3) / 4) : ((size_t)S * 3 * 2 + (size_t)S * 3 * (CAND_LIST / 4));
+    i += lean ? (1 + (size_t)S * 3 * 2 + (size_t)S * 2 * 4 + (size_t)S * 2 + (size_t)(ITEM_CAP(S) + 1) / 2 + (size_t)(S * 2 * NEAR_CAP + 3) / 4)
+              : ((size_t)S * 3 * 2 + (size_t)S * 3 * (CAND_LIST / 4));
     return (lean ? 0 : ESCR_BYTES) + (f + i + 3 + (size_t)(N * (N - 1) / 2 + 1) / 2) * 4 + (size_t)S * COL_STRIDE(N) + 16;
   }
 };
@@ -1943,6 +1956,10 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
   }
   g.dbg_ts = nullptr;
   g.dbg_ts2 = nullptr;
+  g.dbg_skip = 0;
+#ifdef SIGMAENV_PROFILE
+  if (const char* e = getenv("SIGMAENV_DEBUG_SKIP")) g.dbg_skip = atoi(e);
+#endif
   if (const char* e = getenv("SIGMAENV_TIMESTAMPS")) {
     if (atoi(e) == 1) { ALLOC(g.dbg_ts, (size_t)B * 16 * sizeof(unsigned long long)); (void)hipMemsetAsync(g.dbg_ts, 0, (size_t)B * 128, h->stream); }
     if (atoi(e) == 2) { ALLOC(g.dbg_ts2, (size_t)B * 16 * sizeof(unsigned long long)); hipMemsetAsync(g.dbg_ts2, 0, (size_t)B * 128, h->stream); }
@@ -1985,13 +2002,19 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
     if (cfg->envs_per_group >= 1 && cfg->envs_per_group * N <= 64) wg = cfg->envs_per_group;
     if (const char* e = getenv("SIGMAENV_WAVE_G")) { int v = atoi(e); if (v >= 1 && v * N <= 64) wg = v; }
     h->wave_G = wg;
+    { const unsigned d = (unsigned)(wg * N); h->buf.mSG = d <= 1u ? 0u : (uint32_t)(((1ull << 32) + d - 1ull) / d); }
     h->wave_wpb = 1;
     if (const char* e = getenv("SIGMAENV_WPB")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) h->wave_wpb = v; }
     h->wave_tile_lds = (((Smem::bytes(wg * N, N, K, h->D, true) + 15) & ~(size_t)15) + 16 * (size_t)wg + 16 + 15) & ~(size_t)15;
     const int tiles = (B + wg - 1) / wg;
     h->wave_grid = (tiles + h->wave_wpb - 1) / h->wave_wpb;
-    if (h->wave_tile_lds * h->wave_wpb > 64 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(h->wave_tile_lds * h->wave_wpb));
+    if (h->wave_tile_lds * h->wave_wpb > 64 * 1024) {
+      const int lds = (int)(h->wave_tile_lds * h->wave_wpb);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_wave_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_wave_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_wave_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_wave_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    }
     if (const char* e = getenv("SIGMAENV_STEP_KERNEL")) h->use_block_step = (strcmp(e, "block") == 0);
   }
   if (hipStreamSynchronize(h->stream) != hipSuccess) { sigmaenv_destroy(h); return SIGMAENV_EHIP; }
@@ -2066,9 +2089,14 @@ static int launch_step(sigmaenv* h, const float* actions, uint64_t seed, uint64_
   if (h->use_block_step)
     hipLaunchKernelGGL(sigmaenv_step_kernel, dim3(h->grid), dim3(h->block), h->smem_bytes, h->stream, h->cfg, h->map, h->buf, actions, h->G,
                        h->dbg_skip, seed, counter, path_first, path_count, h->buf.slab);
-  else
-    hipLaunchKernelGGL(sigmaenv_step_wave_kernel, dim3(h->wave_grid), dim3(64 * h->wave_wpb), h->wave_tile_lds * h->wave_wpb, h->stream, h->cfg, h->map,
-                       h->buf, actions, h->wave_G, (int)h->wave_tile_lds, seed, counter, path_first, path_count, h->buf.slab);
+  else {
+    // instantiations: exact shared-reciprocal division or plain `/` in the scan (DevMap::fast_div), lane pair per agent in the dynamics or not
+    const bool par = 2 * h->wave_G * h->N <= 64;
+    auto kern = h->map.fast_div ? (par ? sigmaenv_step_wave_kernel<true, true> : sigmaenv_step_wave_kernel<true, false>)
+                                : (par ? sigmaenv_step_wave_kernel<false, true> : sigmaenv_step_wave_kernel<false, false>);
+    hipLaunchKernelGGL(kern, dim3(h->wave_grid), dim3(64 * h->wave_wpb), h->wave_tile_lds * h->wave_wpb, h->stream, h->cfg, h->map, h->buf, actions,
+                       h->wave_G, (int)h->wave_tile_lds, seed, counter, path_first, path_count, h->buf.slab);
+  }
   HIPCHK(h, hipGetLastError());
   if (slot >= 0) HIPCHK(h, hipEventRecord(h->ev_pool[slot].second, h->stream));
   return SIGMAENV_OK;

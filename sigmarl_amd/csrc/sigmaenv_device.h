@@ -68,7 +68,8 @@ struct DevBufs {
   float* slab;                     // optional rollout record of this step: [B][N*D obs | N reward | 1 done] fp32 (sigmaenv_set_slab)
   // magic multipliers ceil(2^32 / d) for the divisors the kernels' index arithmetic divides by (fdiv below): agents per env, items per
   // agent of the two observation passes, unordered pairs per env, floats per rollout record row
-  uint32_t mN, mT1, mT2, mTP, mW;
+  uint32_t mN, mT1, mT2, mTP, mW, mSG;  // mSG: slots of a full tile of the step kernel (G * N)
+  int dbg_skip;                    // profile build only: phase-ablation mask of the step kernel (SIGMAENV_DEBUG_SKIP; results invalid when non-zero)
   unsigned long long* dbg_ts2;     // same for the auto-reset kernel (SIGMAENV_TIMESTAMPS=2)
   unsigned long long* dbg_ts;      // optional [grid][8] shader-clock timestamps at the phase boundaries (SIGMAENV_TIMESTAMPS=1)
 };
