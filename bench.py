@@ -1,20 +1,30 @@
 #!/usr/bin/env python
-"""bench.py -- env-steps/sec (agents x envs x steps) of the fused CAV environment step, CPM scenario, 16 agents.
+"""bench.py -- env-steps/sec (agents x envs x steps) of the fused CAV environment step.
 
 Contract (see the round prompt): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 the driver launches it through
 ``python -m torch.distributed.run`` with one rank per GPU.  W untimed warm-up steps, then exactly K timed steps bracketed by a
 barrier + torch.cuda.synchronize() on both sides, MAX over ranks, rank 0 prints ONE JSON line.
 
-A "step" is one pass of the hot path over one batch of synthetic input: ONE launch (sigmaenv_step_autoreset) that steps agents x envs,
-writes the rollout record of the step (observation incl. the terminal one, reward, done -- the reference's step_and_maybe_reset
-keeps both the terminal and the post-reset observation) into the rollout chunk buffer and re-places the envs that finished; for
-N > 1 additionally one asynchronous RCCL gather per chunk of steps to the learner rank.  Inputs (actions) are resident in HBM
-before the timed region starts.
-Weak scaling: every GPU steps BASELINE config 2 (16 agents x 4096 envs); N = 8 is config 3 (32768 envs).
+A "step" is one pass of the hot path over one batch of synthetic input: ONE launch per env shard (sigmaenv_step_autoreset) that steps
+agents x envs, writes the rollout record of the step (observation incl. the terminal one, reward, done -- the reference's
+step_and_maybe_reset keeps both the terminal and the post-reset observation) into the rollout chunk buffer and re-places the envs that
+finished; for N > 1 additionally one asynchronous RCCL exchange of the rollout chunk per --chunk-steps steps (--exchange alltoall: by
+time slices to every rank, the default; --exchange gather: everything to rank 0).  Inputs (actions) are resident in HBM before the timed
+region starts.  Weak scaling: every GPU steps BASELINE config 2 (CPM map, 16 agents x 4096 envs); N = 8 is config 3 (32768 envs).
+
+Other workloads of BASELINE.json through the same code path:
+  --scenario on_ramp_1 --agents 32 --envs-per-gpu 8192      config 4 (injected start, see sigmarl_amd.maps.injected_start)
+  --cbf-qp                                                  config 5 (centralized CBF-QP before every step)
+  --sweep                                                   the metric's batch sweep 16 agents x {256 .. 32768} envs in `sweep`
+
+roofline (SURVEY.md section 8d / BASELINE.md section 3): `achieved` = algorithmic bytes per agent-env-step (44 + 251 + 5 N) x agent-env-steps
+per second of ONE GPU; `frac` = achieved / 8 TB/s.  The record and reset rewrites are real extra stores and are reported separately
+(`achieved_incl_record`).  The step is VALU-bound, not HBM-bound: `valu_*` carry the issue-side picture from the committed PMC passes.
 """
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -24,6 +34,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ALGO_BYTES_READ = 44  # state 32 + action 8 + path id 4           
+HBM_PEAK_GBPS = 8000.0
+FP32_PEAK_TFLOPS = 157.3
 
 
 def algorithmic_bytes_per_agent_step(n_agents: int) -> int:
@@ -31,25 +43,49 @@ def algorithmic_bytes_per_agent_step(n_agents: int) -> int:
     return ALGO_BYTES_READ + 251 + 5 * n_agents
 
 
-def cpu_baseline(params_kw, n_envs, target_seconds):
+def make_params_kw(args, n_envs):
+    kw = dict(n_agents=args.agents, scenario_type=args.scenario, dt=0.05, is_use_mtv_distance=(args.distance == "mtv"), rew_method="distance",
+              is_apply_mask=False, is_obs_noise=False, max_steps=128, num_vmas_envs=n_envs)
+    if args.cbf_qp:
+        kw.update(rew_method="cbf", is_solve_qp=True, is_using_cbf_training=True)
+    elif args.cbf:
+        kw.update(rew_method="cbf", is_solve_qp=False, is_using_cbf_training=True)
+    return kw
+
+
+def needs_injected_start(mp, n_agents):
+    """More agents than the reference's own reset can place on this map: start from the injected state."""
+    return n_agents > 2 * mp.default_n_agents and mp.scenario_type != "cpm_entire"
+
+
+def cpu_baseline(args, n_envs, target_seconds):
     """The CPU oracle (bit-checked C restatement of the reference path, OpenMP over envs) timed on this box's host cores on a
     bounded sample of the same workload.  Checker code used as the measured baseline leg only."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_binding as ob
     from sigmarl_amd import capi
-    from sigmarl_amd.maps import load_map
+    from sigmarl_amd.maps import injected_start, load_map
     from sigmarl_amd.params import Parameters, make_config
 
-    p = Parameters(**params_kw)
+    p = Parameters(**make_params_kw(args, n_envs))
     mp = load_map(p.scenario_type)
     cfg = make_config(p, mp, n_envs)
     env = ob.OracleEnv(cfg, mp)
-    env.get(capi.BUF_DONE, copy=False)[:] = 1
     pf, pc = mp.list_first[0], mp.list_count[0]
-    env.auto_reset(0, 0, pf, pc)
-    rng = np.random.default_rng(0)
     N = cfg.n_agents
+    if needs_injected_start(mp, N):
+        idx, st = injected_start(mp, N)
+        ids = np.zeros((n_envs, N, 4), np.int32)
+        ids[..., 0] = np.asarray([mp.global_path(0, q) for q in idx], np.int32)[None, :]
+        ids[..., 2] = np.asarray(idx, np.int32)[None, :]
+        st8 = np.zeros((n_envs, N, 8), np.float32)
+        st8[..., 0:3] = np.asarray(st, np.float32)[None, :, :]
+        env.reset(np.repeat(np.arange(n_envs, dtype=np.int32), N), np.tile(np.arange(N, dtype=np.int32), n_envs), ids.reshape(-1, 4), st8.reshape(-1, 8), 1)
+    else:
+        env.get(capi.BUF_DONE, copy=False)[:] = 1
+        env.auto_reset(0, 0, pf, pc)
+    rng = np.random.default_rng(0)
     acts = [np.stack([rng.uniform(0, 1, (n_envs, N)), rng.uniform(-0.25, 0.25, (n_envs, N))], axis=-1).astype(np.float32) for _ in range(8)]
     env.step(acts[0])  # warm-up (also spins the OpenMP team up)
     env.auto_reset(0, 1, pf, pc)
@@ -71,8 +107,216 @@ def cpu_baseline(params_kw, n_envs, target_seconds):
     threads = int(os.environ.get("OMP_NUM_THREADS", cores))
     return {
         "value": N * n_envs * k / el, "unit": "agent-env-steps/s", "cores": threads, "kind": "port",
-        "sample": f"C oracle (oracle/sigmaenv_oracle.c, OpenMP over envs), {N} agents x {n_envs} envs x {k} steps incl. resets, {el:.1f} s",
+        "sample": f"C oracle (oracle/sigmaenv_oracle.c, OpenMP over envs), {p.scenario_type}, {N} agents x {n_envs} envs x {k} steps incl. resets, {el:.1f} s",
     }
+
+
+_SHARD_STREAMS = {}
+
+
+def shard_streams(torch, device, S):
+    """The S shard streams of this process, created once.  The runtime maps streams to a few hardware queues as they are created; two shard
+    streams that land on the same queue run their kernels back to back instead of side by side (observed with streams created later in
+    the process, and once RCCL has created its own) -- alternate priorities keep the pair apart."""
+    key = (str(device), S)
+    if key not in _SHARD_STREAMS:
+        _SHARD_STREAMS[key] = [torch.cuda.Stream(device, priority=-(k % 2)) for k in range(S)]
+    return _SHARD_STREAMS[key]
+
+
+class GpuRun:
+    """The envs of ONE GPU: S shards (handles) of B / S envs on S HIP streams, precomputed actions, the rollout record + exchange."""
+
+    def __init__(self, args, device, B, world, rank, with_exchange=True):
+        import torch
+        from sigmarl_amd.env import SigmaEnv
+        from sigmarl_amd.maps import injected_start
+        from sigmarl_amd.params import Parameters
+        from sigmarl_amd.shard import RolloutExchange
+
+        self.torch, self.args, self.device, self.B, self.N = torch, args, device, B, args.agents
+        N = self.N
+        # env shards of this GPU (no cross-env dependency anywhere in the path); small batches stay in one piece
+        # Shards pay while the whole batch is about one resident round of wavefronts (one env per wavefront, 16 per CU): the tail of one
+        # shard's launch -- its reset-heavy wavefronts -- then overlaps the other shard's start.  Larger batches run several rounds per launch
+        # and fill the tail by themselves (measured: 2 shards 13 % faster at 4096 envs, 20 % at 8192, slower from 16384 on).
+        min_tiles, max_envs = int(os.environ.get("BENCH_MIN_TILES", "1024")), int(os.environ.get("BENCH_SHARD_MAX_ENVS", "8192"))
+        S = args.streams if (args.streams >= 1 and B % max(1, args.streams) == 0 and (B // max(1, args.streams)) >= min_tiles and B <= max_envs) else 1
+        self.S, self.Bs = S, B // S
+        Bs = self.Bs
+        self.main_stream = torch.cuda.current_stream(device)
+        self.streams = [self.main_stream] if S == 1 else shard_streams(torch, device, S)
+        self.seed = 1000 + rank
+        self.envs = []
+        kw = make_params_kw(args, Bs)
+        for k in range(S):
+            with torch.cuda.stream(self.streams[k]):
+                e = SigmaEnv(Parameters(**kw), n_envs=Bs, device=device)
+                if needs_injected_start(e.map, N):
+                    e.reset_injected(*injected_start(e.map, N))
+                    self.start = "injected (sigmarl_amd.maps.injected_start: the same state in every env, zero speed)"
+                else:
+                    e.reset_random(seed=self.seed * 64 + k)
+                    self.start = "device-side sampler"
+                if args.cbf or args.cbf_qp:
+                    e.cbf_attach()
+                self.envs.append(e)
+        self.env = self.envs[0]
+        self.D = self.env.D
+        gen = torch.Generator(device=device).manual_seed(self.seed)
+        self.n_act = 16
+        self.acts = torch.empty((self.n_act, B, N, 2), dtype=torch.float32, device=device)
+        self.acts[..., 0] = torch.rand((self.n_act, B, N), generator=gen, device=device)                 # v_cmd ~ U[0, 1]
+        self.acts[..., 1] = torch.rand((self.n_act, B, N), generator=gen, device=device) * 0.5 - 0.25    # delta_cmd ~ U[-0.25, 0.25] rad
+        torch.cuda.synchronize()
+        self.pf, self.pc = self.env.map.list_first[0], self.env.map.list_count[0]
+        self.counter = 1
+        self.gather = None
+        self.gather_note = "disabled by --no-gather"
+        self.gather_fail = None
+        if with_exchange and not args.no_gather:
+            try:  # the rollout exchange must never take the benchmark down: fall back to "no gather" and say so in the JSON line
+                ex_mode = args.exchange if args.chunk_steps % max(1, world) == 0 else "gather"
+                self.gather = RolloutExchange(B, N, self.D, args.chunk_steps, device, force_collective=args.force_dist, mode=ex_mode)
+                slot0 = self.gather.slot()
+                for k, e in enumerate(self.envs):
+                    e.set_slab(slot0[k * Bs:(k + 1) * Bs])
+                    e.step(self.acts[0][k * Bs:(k + 1) * Bs])
+                torch.cuda.synchronize()
+                self.gather.advance()
+                self.gather.flush(self.streams if S > 1 else None)
+                self.gather.wait_all()
+                torch.cuda.synchronize()
+                for k, e in enumerate(self.envs):
+                    e.auto_reset(seed=self.seed * 64 + k, counter=0, path_first=self.pf, path_count=self.pc)
+                self.gather_note = (f"step kernel records (obs, reward, done) into a [{args.chunk_steps}, B, {N * (self.D + 1) + 1}] chunk buffer"
+                                    + (("; one async all-to-all per chunk (rank r receives steps [r T/N, (r+1) T/N) of every rank's chunk), double buffered"
+                                        if self.gather.mode == "alltoall" else "; one async gather per chunk to rank 0, double buffered")
+                                       if self.gather.collective else " (single GPU: no exchange)"))
+            except Exception as exc:  # noqa: BLE001
+                self.gather = None
+                for e in self.envs:
+                    e.set_slab(None)
+                self.gather_note = f"disabled: {type(exc).__name__}: {exc}"
+                print(f"[bench] rollout exchange disabled: {exc}", file=sys.stderr)
+        self.actors, self.act_bufs = [], []
+        if args.policy:
+            from sigmarl_amd.actor import Actor, make_mlp
+            torch.manual_seed(0)
+            mlp = make_mlp(self.D)
+            for k, e in enumerate(self.envs):
+                with torch.cuda.stream(self.streams[k]):
+                    self.actors.append(Actor(mlp, low=[-1.0, -0.6109], high=[1.0, 0.6109]))  # -/+ (max_speed, max_steering)
+                    self.act_bufs.append(torch.zeros((Bs, N, 2), dtype=torch.float32, device=device))
+        self.safe_bufs = [torch.zeros((Bs, N, 2), dtype=torch.float32, device=device) for _ in range(S)] if args.cbf_qp else []
+        self.W = N * (self.D + 1) + 1
+        self.act_ptrs = [[self.acts[q].data_ptr() + k * Bs * N * 2 * 4 for k in range(S)] for q in range(self.n_act)]
+        self.shard_seeds = [self.seed * 64 + k for k in range(S)]
+        self.fused = not (args.no_reset or args.separate_reset)
+        HArr, PArr, SArr = C.c_void_p * S, C.c_void_p * S, C.c_uint64 * S
+        self.h_arr = HArr(*[e.h for e in self.envs])
+        self.seed_arr = SArr(*self.shard_seeds)
+        self.act_arrs = [PArr(*ap_) for ap_ in self.act_ptrs]
+        self.slab_arr = PArr()
+        self.many = self.envs[0].lib.step_autoreset_many
+
+    def one_step(self, t):
+        args, S, Bs, W = self.args, self.S, self.Bs, self.W
+        base = 0
+        gather = self.gather
+        if gather is not None:
+            slot = gather.slot(self.streams if S > 1 else None)  # orders the shard streams behind the exchange that still reads this buffer
+            base = slot.data_ptr()
+        ap = self.act_ptrs[t % self.n_act]
+        cnt = self.counter
+        plain = self.fused and not args.policy and not (args.cbf or args.cbf_qp)
+        if plain:  # ONE binding call: every shard's record target + fused step / record / reset launch
+            for k in range(S):
+                self.slab_arr[k] = (base + k * Bs * W * 4) if base else None
+            rc = self.many(self.h_arr, S, self.act_arrs[t % self.n_act], self.slab_arr if base else None, self.seed_arr, cnt, self.pf, self.pc)
+            if rc != 0:
+                raise RuntimeError(f"sigmaenv_step_autoreset_many failed with code {rc}")
+        elif base:
+            for k, e in enumerate(self.envs):
+                e.set_slab_ptr(base + k * Bs * W * 4)
+        if self.fused and args.policy:  # policy on device, then the fused step on the actions it wrote
+            for k, e in enumerate(self.envs):
+                self.actors[k].forward(e, self.act_bufs[k], seed=self.shard_seeds[k], counter=cnt)
+                if args.cbf_qp:
+                    e.cbf_qp(self.act_bufs[k], self.safe_bufs[k])
+                elif args.cbf:
+                    e.cbf_rewards(self.act_bufs[k])
+                e.step_autoreset_ptr(self.act_bufs[k].data_ptr(), self.shard_seeds[k], cnt, self.pf, self.pc)
+        elif self.fused and (args.cbf or args.cbf_qp):  # margin rewards / QP of the action about to be applied, then the fused step
+            a = self.acts[t % self.n_act]
+            for k, e in enumerate(self.envs):
+                if args.cbf_qp:
+                    e.cbf_qp(a[k * Bs:(k + 1) * Bs], self.safe_bufs[k])
+                else:
+                    e.cbf_rewards(a[k * Bs:(k + 1) * Bs])
+                e.step_autoreset_ptr(ap[k], self.shard_seeds[k], cnt, self.pf, self.pc)
+        elif not self.fused:
+            a = self.acts[t % self.n_act]
+            for k, e in enumerate(self.envs):
+                e.step(a[k * Bs:(k + 1) * Bs])
+                if not args.no_reset:
+                    e.auto_reset(seed=self.shard_seeds[k], counter=cnt, path_first=self.pf, path_count=self.pc)
+        self.counter += 1
+        if gather is not None:
+            try:
+                gather.advance(self.streams if S > 1 else None)
+            except Exception as exc:  # noqa: BLE001 -- a failing exchange must not take the benchmark down: keep recording, stop exchanging
+                print(f"[bench] rollout exchange failed, continuing without it: {exc}", file=sys.stderr)
+                gather.collective = False
+                gather.pending = [None, None]
+                self.gather_fail = f"exchange failed at run time ({type(exc).__name__}); record kept, exchange disabled"
+                gather.t = 0
+
+    def finish_chunk(self):
+        if self.gather is not None:
+            self.gather.flush(self.streams if self.S > 1 else None)
+            self.gather.wait_all()
+
+    def arm_timing(self):
+        for e in self.envs:
+            e.step_time_ms()
+
+    def kernel_timing(self):
+        timings = [e.step_time_ms() for e in self.envs]
+        n_launch = sum(n for _, n in timings)
+        return sum(ms * n for ms, n in timings) / max(1, n_launch), n_launch
+
+    def episodes_reset(self):
+        from sigmarl_amd import capi
+        return sum(int(e.buffer(capi.BUF_TIMER)[:, 3].sum().item()) for e in self.envs)
+
+    def agent_requests(self):
+        """per-agent reset requests raised by the last step, and its entry / exit crossings"""
+        from sigmarl_amd import capi
+        return (sum(int(e.buffer(capi.BUF_COL_FLAGS)[..., 3].sum().item()) for e in self.envs),
+                sum(int(e.buffer(capi.BUF_COL_FLAGS)[..., 1:3].sum().item()) for e in self.envs))
+
+    def close(self):
+        for e in self.envs:
+            e.close()
+
+
+def timed(run, steps, start_t, use_dist, dist, torch, device):
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(steps):
+        run.one_step(start_t + t)
+    run.finish_chunk()
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if use_dist:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    return float(el.item())
 
 
 def main():
@@ -82,32 +326,39 @@ def main():
     ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--agents", type=int, default=16)
+    ap.add_argument("--scenario", default="cpm_entire", help="map (sigmarl_amd/assets/maps); maps that cannot hold --agents through the "
+                    "reference's own reset start from the injected state (BASELINE config 4: --scenario on_ramp_1 --agents 32 --envs-per-gpu 8192)")
     ap.add_argument("--distance", choices=["c2c", "mtv"], default="c2c")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 disables it)")
+    ap.add_argument("--sweep", action="store_true", help="also time the metric's batch sweep (envs per GPU in --sweep-envs, same agents / map) and "
+                    "report it in `sweep`; the headline stays --envs-per-gpu")
+    ap.add_argument("--sweep-envs", default="256,512,1024,2048,4096,8192,16384,32768")
+    ap.add_argument("--sweep-steps", type=int, default=64)
     ap.add_argument("--no-reset", action="store_true", help="diagnostic: leave finished envs un-reset")
     ap.add_argument("--separate-reset", action="store_true", help="two launches per step (sigmaenv_step; sigmaenv_auto_reset) instead of the fused one")
-    ap.add_argument("--no-gather", action="store_true", help="diagnostic: no rollout record (and no gather to the learner rank for N > 1)")
+    ap.add_argument("--no-gather", action="store_true", help="diagnostic: no rollout record (and no exchange for N > 1)")
     ap.add_argument("--streams", type=int, default=2, help="env shards per GPU, each stepped by its own handle on its own HIP stream "
-                    "(envs are independent: same total work per step, the shards' latency-bound phases overlap the others' scan)")
+                    "(envs are independent: same total work per step; the tail of one shard's launch -- its reset-heavy wavefronts -- overlaps the other's)")
     ap.add_argument("--policy", action="store_true", help="widening (SURVEY 8f-3): the actor MLP runs on the device before every step "
-                    "(sigmaenv_actor_forward, MFMA bf16) instead of replaying precomputed actions; reported in config.policy")
+                    "(sigmaenv_actor_forward) instead of replaying precomputed actions; reported in config.policy")
     ap.add_argument("--cbf", action="store_true", help="widening (SURVEY 8f-4): rew_method='cbf' with the QP-free CBF margin reward "
                     "(sigmaenv_cbf_rewards before every step); reported in config.cbf")
-    ap.add_argument("--cbf-qp", action="store_true", help="widening (BASELINE config 5): rew_method='cbf' with the centralized CBF-QP safety "
-                    "filter solved for every env before every step (sigmaenv_cbf_qp); reported in config.cbf")
+    ap.add_argument("--cbf-qp", action="store_true", help="BASELINE config 5: rew_method='cbf' with the centralized CBF-QP safety filter solved for "
+                    "every env before every step (sigmaenv_cbf_qp); reported in config.cbf")
     ap.add_argument("--exchange", choices=["alltoall", "gather"], default="alltoall",
                     help="N > 1: how the rollout buffer is concatenated.  alltoall: distributed over the ranks by time slices (every rank "
                          "receives 1/N of the steps of ALL envs -- a data-parallel learner; the record crosses xGMI once, over all links); "
                          "gather: everything to rank 0 (the 7 links into one GPU bound the rate)")
-    ap.add_argument("--chunk-steps", type=int, default=32, help="steps per rollout chunk gathered to the learner rank (N > 1)")
-    ap.add_argument("--force-dist", action="store_true", help="diagnostic: init RCCL and run the gather even with one rank")
+    ap.add_argument("--chunk-steps", type=int, default=32, help="steps per rollout chunk exchanged (N > 1)")
+    ap.add_argument("--force-dist", action="store_true", help="diagnostic: init RCCL and run the exchange even with one rank")
     args = ap.parse_args()
 
     # the contract is ONE JSON line on stdout: libraries (RCCL prints a version banner) get stderr instead
     real_stdout = os.dup(1)
     os.dup2(2, 1)
 
-    os.environ.setdefault("SIGMAENV_TIMING_STRIDE", "32")  # HIP-event bracket around every 32nd step launch (each bracket costs a few microseconds)
+    # HIP-event bracket around a sample of the step launches (each bracket costs a few microseconds): at least 8 samples per shard
+    os.environ.setdefault("SIGMAENV_TIMING_STRIDE", str(max(1, min(32, args.steps // 8))))
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the HIP runtime starts: enough hardware queues for the shard + RCCL streams
     import torch
     import torch.distributed as dist
@@ -128,238 +379,102 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
-    from sigmarl_amd import capi
-    from sigmarl_amd.env import SigmaEnv
-    from sigmarl_amd.params import Parameters
-    from sigmarl_amd.shard import RolloutExchange
-
     B, N = args.envs_per_gpu, args.agents
-    params_kw = dict(n_agents=N, scenario_type="cpm_entire", dt=0.05, is_use_mtv_distance=(args.distance == "mtv"), rew_method="distance",
-                     is_apply_mask=False, is_obs_noise=False, max_steps=128, num_vmas_envs=B)
-    if args.cbf:
-        params_kw.update(rew_method="cbf", is_solve_qp=False, is_using_cbf_training=True)
-    if args.cbf_qp:
-        params_kw.update(rew_method="cbf", is_solve_qp=True, is_using_cbf_training=True)
-        args.cbf = True  # same call sites below; the QP launch replaces the margin launch
-    # env shards of this GPU: S handles of B / S envs, each on its own HIP stream (no cross-env dependency anywhere in the path)
-    # (only when every shard still fills the GPU's CUs with whole tiles; small batches are launch-bound and stay in one piece)
-    S = args.streams if (args.streams >= 1 and B % max(1, args.streams) == 0 and (B // max(1, args.streams)) * N >= 64 * int(os.environ.get("BENCH_MIN_TILES", "512"))) else 1
-    Bs = B // S
-    main_stream = torch.cuda.current_stream(device)
-    # alternate priorities: the runtime maps streams to a few hardware queues, and two shard streams that land on the same queue
-    # (observed once RCCL has created its own streams) would run their kernels back to back instead of side by side
-    streams = [main_stream] if S == 1 else [torch.cuda.Stream(device, priority=(0 if os.environ.get("BENCH_PRIO") == "none" else -(k % 2))) for k in range(S)]
-    seed = 1000 + rank
-    envs = []
-    for k in range(S):
-        with torch.cuda.stream(streams[k]):
-            kw = dict(params_kw, num_vmas_envs=Bs)
-            e = SigmaEnv(Parameters(**kw), n_envs=Bs, device=device)
-            e.reset_random(seed=seed * 64 + k)
-            if args.cbf:
-                e.cbf_attach()
-            envs.append(e)
-    env = envs[0]
-    gen = torch.Generator(device=device).manual_seed(seed)
-    n_act = 16
-    acts = torch.empty((n_act, B, N, 2), dtype=torch.float32, device=device)
-    acts[..., 0] = torch.rand((n_act, B, N), generator=gen, device=device)                 # v_cmd ~ U[0, 1]
-    acts[..., 1] = torch.rand((n_act, B, N), generator=gen, device=device) * 0.5 - 0.25    # delta_cmd ~ U[-0.25, 0.25] rad
-    torch.cuda.synchronize()
-    gather = None
-    gather_note = "disabled by --no-gather"
-    if not args.no_gather:
-        try:  # the rollout exchange must never take the benchmark down: fall back to "no gather" and say so in the JSON line
-            ex_mode = args.exchange if args.chunk_steps % max(1, world) == 0 else "gather"
-            gather = RolloutExchange(B, N, env.D, args.chunk_steps, device, force_collective=args.force_dist, mode=ex_mode)
-            slot0 = gather.slot()
-            for k, e in enumerate(envs):
-                e.set_slab(slot0[k * Bs:(k + 1) * Bs])
-                e.step(acts[0][k * Bs:(k + 1) * Bs])
-            torch.cuda.synchronize()
-            gather.advance()
-            gather.flush()
-            gather.wait_all()
-            torch.cuda.synchronize()
-            for k, e in enumerate(envs):
-                e.auto_reset(seed=seed * 64 + k, counter=0, path_first=env.map.list_first[0], path_count=env.map.list_count[0])
-            gather_note = (f"step kernel records (obs, reward, done) into a [{args.chunk_steps}, B, {N * (env.D + 1) + 1}] chunk buffer"
-                           + ((f"; one async all-to-all per chunk (rank r receives steps [r T/N, (r+1) T/N) of every rank's chunk), double buffered"
-                               if gather.mode == "alltoall" else "; one async gather per chunk to rank 0, double buffered")
-                              if gather.collective else " (single GPU: no exchange)"))
-        except Exception as exc:  # noqa: BLE001
-            gather = None
-            for e in envs:
-                e.set_slab(None)
-            gather_note = f"disabled: {type(exc).__name__}: {exc}"
-            print(f"[bench] rollout exchange disabled: {exc}", file=sys.stderr)
-    pf, pc = env.map.list_first[0], env.map.list_count[0]
-    counter = [1]
-    gather_state = {"note": None}
-
-    actors, act_bufs = [], []
-    if args.policy:
-        from sigmarl_amd.actor import Actor, make_mlp
-        torch.manual_seed(0)
-        mlp = make_mlp(env.D)
-        for k, e in enumerate(envs):
-            with torch.cuda.stream(streams[k]):
-                actors.append(Actor(mlp, low=[-1.0, -0.6109], high=[1.0, 0.6109]))  # -/+ (max_speed, max_steering)
-                act_bufs.append(torch.zeros((Bs, N, 2), dtype=torch.float32, device=device))
-    safe_bufs = [torch.zeros((Bs, N, 2), dtype=torch.float32, device=device) for _ in range(S)] if args.cbf_qp else []
-    W = N * (env.D + 1) + 1
-    act_ptrs = [[acts[q].data_ptr() + k * Bs * N * 2 * 4 for k in range(S)] for q in range(n_act)]
-    shard_seeds = [seed * 64 + k for k in range(S)]
-    fused = not (args.no_reset or args.separate_reset)
-
-    import ctypes as C
-    HArr, PArr, SArr = C.c_void_p * S, C.c_void_p * S, C.c_uint64 * S
-    h_arr = HArr(*[e.h for e in envs])
-    seed_arr = SArr(*shard_seeds)
-    act_arrs = [PArr(*ap_) for ap_ in act_ptrs]
-    slab_arr = PArr()
-    many = envs[0].lib.step_autoreset_many
-
-    def one_step(t):
-        base = 0
-        if gather is not None:
-            slot = gather.slot(streams if S > 1 else None)  # orders the shard streams behind the gather that still reads this buffer
-            base = slot.data_ptr()
-        ap = act_ptrs[t % n_act]
-        cnt = counter[0]
-        if fused and not args.policy and not args.cbf:  # ONE binding call: every shard's record target + fused step / record / reset launch
-            for k in range(S):
-                slab_arr[k] = (base + k * Bs * W * 4) if base else None
-            rc = many(h_arr, S, act_arrs[t % n_act], slab_arr if base else None, seed_arr, cnt, pf, pc)
-            if rc != 0:
-                raise RuntimeError(f"sigmaenv_step_autoreset_many failed with code {rc}")
-        elif base:
-            for k, e in enumerate(envs):
-                e.set_slab_ptr(base + k * Bs * W * 4)
-        if fused and args.policy:  # policy on device, then the fused step on the actions it wrote
-            for k, e in enumerate(envs):
-                actors[k].forward(e, act_bufs[k], seed=shard_seeds[k], counter=cnt)
-                if args.cbf_qp:
-                    e.cbf_qp(act_bufs[k], safe_bufs[k])
-                elif args.cbf:
-                    e.cbf_rewards(act_bufs[k])
-                e.step_autoreset_ptr(act_bufs[k].data_ptr(), shard_seeds[k], cnt, pf, pc)
-        elif fused and args.cbf:  # margin rewards of the action about to be applied, then the fused step that consumes them
-            a = acts[t % n_act]
-            for k, e in enumerate(envs):
-                if args.cbf_qp:
-                    e.cbf_qp(a[k * Bs:(k + 1) * Bs], safe_bufs[k])
-                else:
-                    e.cbf_rewards(a[k * Bs:(k + 1) * Bs])
-                e.step_autoreset_ptr(ap[k], shard_seeds[k], cnt, pf, pc)
-        elif fused:
-            pass  # done above
-        else:
-            a = acts[t % n_act]
-            for k, e in enumerate(envs):
-                e.step(a[k * Bs:(k + 1) * Bs])
-                if not args.no_reset:
-                    e.auto_reset(seed=shard_seeds[k], counter=cnt, path_first=pf, path_count=pc)
-        counter[0] += 1
-        if gather is not None:
-            if S > 1 and gather.t == gather.T - 1:  # the chunk is complete: the gather (main stream) follows every shard's last write
-                for st in streams:
-                    main_stream.wait_stream(st)
-            try:
-                gather.advance()
-            except Exception as exc:  # noqa: BLE001 -- a failing exchange must not take the benchmark down: keep recording, stop gathering
-                print(f"[bench] rollout gather failed, continuing without the exchange: {exc}", file=sys.stderr)
-                gather.collective = False
-                gather.pending = [None, None]
-                gather_state["note"] = f"gather failed at run time ({type(exc).__name__}); record kept, exchange disabled"
-                gather.t = 0
-
-    def finish_chunk():
-        if gather is not None:
-            if S > 1:
-                for st in streams:
-                    main_stream.wait_stream(st)
-            gather.flush()
-            gather.wait_all()
-
+    run = GpuRun(args, device, B, world, rank)
     for t in range(args.warmup):
-        one_step(t)
-    finish_chunk()
+        run.one_step(t)
+    run.finish_chunk()
     torch.cuda.synchronize()
-    for e in envs:
-        e.step_time_ms()  # arms the HIP-event bracketing of the step launches (on the env's stream)
-    resets_before = sum(int(e.buffer(capi.BUF_TIMER)[:, 3].sum().item()) for e in envs)  # episodes_reset counters
-
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for t in range(args.steps):
-        one_step(args.warmup + t)
-    finish_chunk()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    el = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if use_dist:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
-
-    timings = [e.step_time_ms() for e in envs]
-    n_launch = sum(n for _, n in timings)
-    kernel_ms = sum(ms * n for ms, n in timings) / max(1, n_launch)
-    dones = sum(int(e.buffer(capi.BUF_TIMER)[:, 3].sum().item()) for e in envs) - resets_before
+    run.arm_timing()  # arms the HIP-event bracketing of the step launches (on the env's stream)
+    resets_before = run.episodes_reset()
+    elapsed = timed(run, args.steps, args.warmup, use_dist, dist, torch, device)
+    kernel_ms, n_launch = run.kernel_timing()
+    dones = run.episodes_reset() - resets_before
+    req_last, entry_exit_last = run.agent_requests()
+    S, Bs, D = run.S, run.Bs, run.D
     total_agent_steps = N * B * world * args.steps
     value = total_agent_steps / elapsed
+    value_per_gpu = value / world
     bytes_per = algorithmic_bytes_per_agent_step(N)
-    # the fused launch also rewrites the whole record of every agent of a reset env: 320 + 5 N bytes
-    reset_bytes = (320 + 5 * N) * N * (dones / max(1, args.steps)) if fused else 0.0
-    slab_bytes = 4.0 * (N * (env.D + 1) + 1) * B if gather is not None else 0.0  # the rollout record row of every env
-    step_bytes = bytes_per * N * B + reset_bytes + slab_bytes  # algorithmic bytes of one step over all shards of this GPU
-    if S == 1:
-        achieved = step_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None
-        achieved_basis = "algorithmic bytes per launch / average launch duration (HIP events)"
-    else:  # S launches per step run concurrently: the rate the GPU sustains is bytes per step over the wall time per step
-        achieved = step_bytes / (elapsed / args.steps) / 1e9
-        achieved_basis = (f"{S} concurrent launches per step (one per env shard): algorithmic bytes of all shards per step / wall time per step; "
-                          "kernel_avg_ms is the average duration of ONE shard's launch while it shares the GPU with the others")
-    traffic = None
+    achieved = bytes_per * value_per_gpu / 1e9  # GB/s of ONE GPU: SURVEY.md section 8(d)'s per-unit figure x the units it processes per second
+    # what the launch stores on top of section 8(d)'s list: the rollout record row of every env, and the whole record of every agent of a
+    # re-placed env once more (320 + 5 N bytes)
+    reset_bytes = (320 + 5 * N) * N * (dones / max(1, args.steps)) if run.fused else 0.0
+    slab_bytes = 4.0 * (N * (D + 1) + 1) * B if run.gather is not None else 0.0
+    step_s = elapsed / args.steps
+    achieved_incl = (bytes_per * N * B + reset_bytes + slab_bytes) / step_s / 1e9
+    per_launch_bytes = bytes_per * N * Bs
+    traffic, traffic_source = None, None
     try:  # HBM bytes per launch from the separate rocprofv3 --pmc passes (tools/pmc_passes.sh), corrected as the MI355X guide says
         with open(os.path.join(ROOT, "profiles", "traffic_latest.json")) as f:
             tr = json.load(f)
-        if tr.get("n_agents") == N and tr.get("envs_per_launch", tr.get("envs_per_gpu")) == Bs and tr.get("distance") == args.distance:
-            traffic = tr["hbm_bytes_per_launch"] * S  # per step, like `achieved` (S launches of B / S envs)
+        if tr.get("n_agents") == N and tr.get("envs_per_launch") == Bs and tr.get("distance") == args.distance and tr.get("scenario", "cpm_entire") == args.scenario:
+            traffic = tr["hbm_bytes_per_launch"]
+            traffic_source = "profiles/traffic_latest.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload (not this run), per launch"
+    except Exception:  # noqa: BLE001
+        pass
+    valu = {}
+    try:  # issue-side figures of the dominant kernel from the committed SQ passes (tools/make_valu_json.py)
+        with open(os.path.join(ROOT, "profiles", "valu_latest.json")) as f:
+            vj = json.load(f)
+        if vj.get("n_agents") == N and vj.get("envs_per_launch") == Bs and vj.get("scenario", "cpm_entire") == args.scenario:
+            launches_per_s = S / step_s  # the per-launch counts of the profile at this run's launch rate
+            valu = {
+                "valu_issue_frac": vj["valu_busy_cycles_per_launch"] * launches_per_s / (vj["n_simd"] * vj["clock_hz"]),
+                "fp32_flop_frac": vj["fp32_flops_per_launch"] * launches_per_s / (FP32_PEAK_TFLOPS * 1e12),
+                "valu_insts_per_launch": vj["valu_insts_per_launch"], "valu_source": vj.get("source", "profiles/valu_latest.json") + " (not this run)",
+            }
     except Exception:  # noqa: BLE001
         pass
     out = {
-        "metric": f"env-steps/sec (agents x envs x steps), CPM scenario, {N} agents",
+        "metric": f"env-steps/sec (agents x envs x steps), {'CPM' if args.scenario.startswith('cpm') else args.scenario} scenario, {N} agents",
         "value": value, "unit": "agent-env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {
-            "workload": f"cpm_entire map, {N} agents x {B} envs per GPU ({B * world} envs total), {args.distance} distance, rew_method={params_kw['rew_method']}, "
-                        f"dt=0.05, obs_dim={env.D}, fused step + device-side reset of finished envs "
-                        + ("(one launch)" if fused else "(two launches)" if not args.no_reset else "(resets disabled)") + ((" + rollout record" + ((" + " + gather.mode) if gather.collective else "")) if gather else ""),
-            "n_agents": N, "envs_per_gpu": B, "envs_total": B * world, "distance": args.distance, "env_shards_per_gpu": S,
-            "policy": ("actor MLP 32-256-256-256-4 (bf16 MFMA, TanhNormal sample) on device before every step" if args.policy
+            "workload": f"{args.scenario} map, {N} agents x {B} envs per GPU ({B * world} envs total), {args.distance} distance, "
+                        f"rew_method={make_params_kw(args, B)['rew_method']}, dt=0.05, obs_dim={D}, start: {run.start}, fused step + device-side reset of finished envs "
+                        + ("(one launch)" if run.fused else "(two launches)" if not args.no_reset else "(resets disabled)")
+                        + ((" + rollout record" + ((" + " + run.gather.mode) if run.gather.collective else "")) if run.gather else ""),
+            "n_agents": N, "envs_per_gpu": B, "envs_total": B * world, "distance": args.distance, "scenario": args.scenario, "env_shards_per_gpu": S,
+            "policy": ("actor MLP 32-256-256-256-4 on device before every step" if args.policy
                        else "none in the timed region (precomputed actions resident in HBM)"),
-            **({"cbf": ("centralized CBF-QP safety filter of every env (sigmaenv_cbf_qp: 32 controls, 96 lane + 1080 pair constraints, projected "
+            **({"cbf": ("centralized CBF-QP safety filter of every env (sigmaenv_cbf_qp: 2 N controls, lane + pair constraints, projected "
                         "Newton in float64) solved before every step; the step penalises the deviation from the safe action" if args.cbf_qp else
                         "QP-free CBF margin reward (sigmaenv_cbf_rewards: 3 circles per vehicle, 9-point fp16 pseudo-distance stencils to both "
-                        "boundaries, float64 margins) launched before every step")} if args.cbf else {}),
-            "resets_per_step_per_gpu": dones / max(1, args.steps), "rollout_gather": gather_state["note"] or gather_note,
+                        "boundaries, float64 margins) launched before every step")} if (args.cbf or args.cbf_qp) else {}),
+            "resets_per_step_per_gpu": dones / max(1, args.steps),
+            "agent_reset_requests_last_step": req_last, "entry_exit_crossings_last_step": entry_exit_last,
+            "rollout_gather": run.gather_fail or run.gather_note,
         },
         "roofline": {
-            "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": (achieved / 8000.0) if achieved else None,
-            "traffic": traffic, "kernel": "sigmaenv_step_kernel", "kernel_avg_ms": kernel_ms, "kernel_launches": n_launch,
-            "algorithmic_bytes_per_agent_env_step": bytes_per, "algorithmic_bytes_per_launch": step_bytes / S, "launches_per_step": S, "achieved_basis": achieved_basis,
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": traffic, "traffic_source": traffic_source,
+            "kernel": "sigmaenv_step_wave_kernel", "kernel_avg_ms": kernel_ms, "kernel_launches": n_launch, "launches_per_step": S,
+            "algorithmic_bytes_per_agent_env_step": bytes_per, "algorithmic_bytes_per_launch": per_launch_bytes,
+            "achieved_per_launch": (per_launch_bytes / (kernel_ms * 1e-3) / 1e9) if kernel_ms > 0 else None,
+            "achieved_incl_record": achieved_incl,
+            "achieved_basis": "algorithmic bytes per agent-env-step (SURVEY.md 8d: 44 + 251 + 5 N) x agent-env-steps/s of one GPU; achieved_per_launch = the same "
+                              "bytes of ONE launch / its average duration by HIP events (launches of different shards overlap); achieved_incl_record adds the "
+                              "rollout record rows and the rewrites of re-placed envs",
+            **valu,
         },
     }
+    run.close()
+    if args.sweep:
+        sweep = []
+        for Bx in [int(x) for x in args.sweep_envs.split(",") if x]:
+            r = GpuRun(args, device, Bx, world, rank)
+            for t in range(16):
+                r.one_step(t)
+            r.finish_chunk()
+            el = timed(r, args.sweep_steps, 16, use_dist, dist, torch, device)
+            sweep.append({"envs_per_gpu": Bx, "value": N * Bx * world * args.sweep_steps / el, "ms_per_step": el / args.sweep_steps * 1e3,
+                          "env_shards_per_gpu": r.S, "roofline_frac": bytes_per * (N * Bx * args.sweep_steps / el) / 1e9 / HBM_PEAK_GBPS})
+            r.close()
+        out["sweep"] = sweep
     if rank == 0 and args.cpu_seconds > 0 and world == 1:
-        out["cpu_baseline"] = cpu_baseline(params_kw, B, args.cpu_seconds)
-    for e in envs:
-        e.close()
+        out["cpu_baseline"] = cpu_baseline(args, B, args.cpu_seconds)
     if use_dist:
         dist.destroy_process_group()
     sys.stdout.flush()

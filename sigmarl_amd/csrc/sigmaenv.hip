@@ -1996,7 +1996,9 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_auto_reset_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem_bytes);
   }
   {  // the step kernel's tiling: one wavefront per tile of wave_G environments; as many tiles as give every SIMD four wavefronts
-    int wg = 64 / N;
+    // about 16 agent slots per wavefront (measured at 16 agents: one env per wavefront beats two and four at every batch size from 256
+    // to 32768 envs -- a bigger tile is a longer serial chain per wavefront and more LDS per wavefront, i.e. fewer of them resident)
+    int wg = 16 / N;
     if (wg < 1) wg = 1;
     while (wg > 1 && (B + wg - 1) / wg < 16 * n_cu) wg >>= 1;
     if (cfg->envs_per_group >= 1 && cfg->envs_per_group * N <= 64) wg = cfg->envs_per_group;

@@ -306,6 +306,20 @@ class SigmaEnv:
     def state(self):
         return self._views[capi.BUF_STATE]
 
+    def reset_injected(self, predefined_ref_path_idx, init_state):
+        """Initial reset of every env from ONE injected state (``Parameters.predefined_ref_path_idx`` / ``init_state``: path per agent and
+        [x, y, yaw] per agent; speed, steering, velocity and side-slip zero -- world_state_rt_sim.py:99-126), the same in every env."""
+        B, N = self.B, self.N
+        idx = np.asarray(predefined_ref_path_idx, np.int32).reshape(N)
+        st = np.asarray(init_state, np.float32).reshape(N, -1)[:, 0:3]
+        ids = np.zeros((B, N, 4), np.int32)
+        ids[..., 0] = np.asarray([self.map.global_path(0, int(p)) for p in idx], np.int32)[None, :]
+        ids[..., 2] = idx[None, :]
+        state8 = np.zeros((B, N, 8), np.float32)
+        state8[..., 0:3] = st[None, :, :]
+        self.reset(np.repeat(np.arange(B, dtype=np.int32), N), np.tile(np.arange(N, dtype=np.int32), B), ids.reshape(-1, 4), state8.reshape(-1, 8), True)
+        self.observe()
+
     def reset_random(self, seed: int = 0):
         """Initial reset of every env through the device-side sampler (marks all envs done first)."""
         self._views[capi.BUF_DONE].fill_(1)

@@ -92,6 +92,26 @@ class MapTable:
         return m
 
 
+def injected_start(mp: MapTable, n_agents: int, first_point: int = 3, stride: int = 3, jitter_seed: int = 4):
+    """Deterministic start for more agents than the reference's rejection sampler can place (BASELINE config 4: 32 agents on the
+    on-ramp map; SURVEY.md section 7): agent i on path i mod n_paths at centre-line point first_point + stride * (i // n_paths) with the
+    centre line's yaw there, plus a few millimetres / milliradians of jitter so that no two mutual distances tie exactly.  Returns
+    ``(predefined_ref_path_idx, init_state)`` in the form ``Parameters`` takes them (the reference's world_state_rt_sim.py:99-126 path:
+    zero speed / steering, same start in every env).  tests/golden/gen/gen_golden.py builds the config-4 fixture with the same rule."""
+    jit = np.random.default_rng(jitter_seed).uniform(-1.0, 1.0, (n_agents, 3))
+    first, count = mp.list_first[0], mp.list_count[0]
+    idx, st = [], []
+    for i in range(n_agents):
+        pid = i % count
+        gp = first + pid
+        n, ny = int(mp.n_center[gp]), int(mp.n_yaw[gp])
+        k = min(first_point + stride * (i // count), n - 8)
+        idx.append(pid)
+        st.append([float(mp.center[gp, k, 0]) + 4e-3 * jit[i, 0], float(mp.center[gp, k, 1]) + 4e-3 * jit[i, 1],
+                   float(mp.yaw[gp, min(k, ny - 1)]) + 2e-2 * jit[i, 2]])
+    return idx, st
+
+
 _cache = {}
 
 

@@ -68,6 +68,13 @@ class RolloutExchange:
         self.collective = self.world > 1 or self.force
         self.dst = dst
         self.N, self.D, self.T = n_agents, obs_dim, int(chunk_steps)
+        if self.collective and self.world > 1:
+            # the collectives below size every peer's part like the local one: the shards of one exchange must hold the same number of envs
+            # (shard_range spreads a remainder over the first ranks -- pad the batch or pick a divisible one instead)
+            counts = [None] * self.world
+            dist.all_gather_object(counts, int(local_envs), group=group)
+            if any(c != counts[0] for c in counts):
+                raise ValueError(f"RolloutExchange needs equal env counts on every rank, got {counts}")
         shape = (self.T, local_envs, slab_width(n_agents, obs_dim))
         self.chunks = [torch.empty(shape, dtype=torch.float32, device=device) for _ in range(2)]
         self.recv = None
@@ -80,7 +87,8 @@ class RolloutExchange:
             self.recv = [[torch.empty(shape, dtype=torch.float32, device=device) for _ in range(self.world)] for _ in range(2)]
         self.pending = [None, None]
         self.cur, self.t = 0, 0
-        self.completed = []  # indices of chunk buffers whose gather has been issued, in order
+        self.completed = []  # (buffer index, valid steps) of every chunk whose exchange has been issued, in order
+        self.valid_steps = [0, 0]  # steps recorded in each buffer when it was shipped (a final partial chunk ships whole, rows beyond are stale)
 
     def slot(self, writer_streams=None) -> torch.Tensor:
         """The ``[B, W]`` row block the NEXT step must be recorded into (pass it to ``SigmaEnv.set_slab``).  ``writer_streams``:
@@ -95,22 +103,30 @@ class RolloutExchange:
             self.pending[self.cur] = None
         return self.chunks[self.cur][self.t]
 
-    def advance(self):
-        """Call after the step that filled ``slot()`` has been enqueued; ships the chunk when it is full."""
+    def advance(self, writer_streams=None):
+        """Call after the step that filled ``slot()`` has been enqueued; ships the chunk when it is full.  ``writer_streams``: as in ``slot``."""
         self.t += 1
         if self.t == self.T:
-            self.flush()
+            self.flush(writer_streams)
 
-    def flush(self):
+    def flush(self, writer_streams=None):
+        """Ships the current chunk (``valid_steps[k]`` of its T rows are new).  The collective is issued on torch's current stream, which is
+        first ordered behind ``writer_streams`` (the streams whose kernels wrote the rows)."""
         if self.t == 0:
             return
         k = self.cur
+        if writer_streams:
+            cur = torch.cuda.current_stream(self.chunks[k].device)
+            for st in writer_streams:
+                if st != cur:
+                    cur.wait_stream(st)
+        self.valid_steps[k] = self.t
         if self.collective and self.mode == "alltoall":
             self.pending[k] = dist.all_to_all_single(self.recv[k].view(-1), self.chunks[k].view(-1), group=self.group, async_op=True)
         elif self.collective:
             self.pending[k] = dist.gather(self.chunks[k], self.recv[k] if self.rank == self.dst else None, dst=self.dst, group=self.group,
                                           async_op=True)
-        self.completed.append(k)
+        self.completed.append((k, self.t))
         self.cur ^= 1
         self.t = 0
 

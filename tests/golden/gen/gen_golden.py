@@ -149,14 +149,38 @@ class CbfHook:
         return rec
 
 
-def run_traj(name, T, B, seed, mode_pattern, no_reset=False, hook=None, **pkw):
+def injected_start(scenario_type, n_agents, first_point=3, stride=3):
+    """Deterministic initial state for more agents than the reference's rejection sampler can place (BASELINE
+    config 4): agent i on path i mod n_paths, centre-line point first_point + stride * (i // n_paths), yaw of the centre line there.
+    Returned in the form Parameters.predefined_ref_path_idx / Parameters.init_state take (world_state_rt_sim.py:99-126)."""
+    probe = refshim.RefEnv(Parameters(n_agents=2, scenario_type=scenario_type, is_obs_noise=False, num_vmas_envs=1,
+                                      is_challenging_initial_state_buffer=False), 1)
+    paths = probe.scenario.map.parser.reference_paths
+    jit = np.random.default_rng(4).uniform(-1.0, 1.0, (n_agents, 3))  # a few millimetres / milliradians: no two distances tie exactly
+    idx, st = [], []                                                   # (torch.topk's order among exactly equal distances is unspecified)
+    for i in range(n_agents):
+        pid = i % len(paths)
+        cl, yaw = paths[pid]["center_line"], paths[pid]["center_line_yaw"].reshape(-1)
+        k = min(first_point + stride * (i // len(paths)), cl.shape[0] - 8)
+        idx.append(pid)
+        st.append([float(cl[k, 0]) + 4e-3 * jit[i, 0], float(cl[k, 1]) + 4e-3 * jit[i, 1], float(yaw[min(k, yaw.shape[0] - 1)]) + 2e-2 * jit[i, 2]])
+    return idx, st
+
+
+def run_traj(name, T, B, seed, mode_pattern, no_reset=False, hook=None, inject=None, **pkw):
     torch.manual_seed(seed)
+    np.random.seed(seed)
+    import random as _random
+    _random.seed(seed)
     gen = torch.Generator().manual_seed(seed + 1000)
     kw = dict(
         is_obs_noise=False, is_apply_mask=False, max_steps=128, num_vmas_envs=B,
         is_challenging_initial_state_buffer=False, is_testing_mode=False,
     )
     kw.update(pkw)
+    if inject is not None:
+        kw["predefined_ref_path_idx"], kw["init_state"] = injected_start(kw["scenario_type"], kw["n_agents"], **inject)
+        torch.manual_seed(seed)
     p = Parameters(**kw)
     env = refshim.RefEnv(p, B)
     sc = env.scenario
@@ -505,6 +529,11 @@ TRAJS = {
                                is_use_mtv_distance=False, rew_method="distance", is_apply_mask=True),
     "roundabout6_mask": dict(T=40, B=2, seed=26, mode_pattern=[1, 0], n_agents=6, scenario_type="roundabout_2", dt=0.1,
                              is_use_mtv_distance=True, rew_method="ttc", is_apply_mask=True),
+    # BASELINE config 4: 32 agents on the on-ramp map.  The reference's rejection sampler cannot place them, so the
+    # start is injected (Parameters.predefined_ref_path_idx / init_state); vehicles overlap from the first step on, every env is "done" at
+    # every step and none is reset: non-reset steps only, as the survey prescribes for this configuration
+    "onramp32_c2c": dict(T=16, B=3, seed=27, mode_pattern=[1, 0, 1], no_reset=True, inject=dict(first_point=3, stride=3), n_agents=32,
+                         scenario_type="on_ramp_1", dt=0.05, is_use_mtv_distance=False, rew_method="distance"),
     # "clf" nominal controller (cbf_qp.py:2616-2628): the margins are evaluated at a P controller's action instead of the policy's
     "onramp4_cbf_clf": dict(T=24, B=3, seed=23, mode_pattern=[1, 0, 1], hook="cbf", n_agents=4, scenario_type="on_ramp_1", dt=0.05,
                             is_use_mtv_distance=False, rew_method="cbf", is_using_cbf_training=True, is_solve_qp=False, nom_controller_type="clf"),

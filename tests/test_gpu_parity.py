@@ -255,6 +255,58 @@ def test_full_size_properties(N, B):
     ora.close()
 
 
+def test_config4_onramp_32_agents_8192_envs():
+    """BASELINE config 4 on its own map: on_ramp_1, 32 agents x 8192 envs, injected start (the reference cannot place 32 agents there:
+    SURVEY.md section 7), non-loop paths with entry / exit segments.  One launch per step incl. the bounded device-side resets (finished envs
+    and agents that left through an exit); HIP == oracle on EVERY env, masks / indices bit-exact."""
+    from sigmarl_amd.maps import injected_start
+
+    N, B = 32, 8192
+    mp = load_map("on_ramp_1")
+    idx, st = injected_start(mp, N)
+    p = Parameters(n_agents=N, scenario_type="on_ramp_1", is_use_mtv_distance=False, rew_method="distance", is_apply_mask=False, is_obs_noise=False,
+                   dt=0.05, predefined_ref_path_idx=idx, init_state=st)
+    cfg = make_config(p, mp, B)
+    assert cfg.has_entry_exit
+    pf, pc = mp.list_first[0], mp.list_count[0]
+    dev = _hip_env(cfg, mp)
+    ora = ob.OracleEnv(cfg, mp)
+    ids = np.zeros((B, N, 4), np.int32)
+    ids[..., 0] = np.asarray([mp.global_path(0, q) for q in idx], np.int32)[None, :]
+    ids[..., 2] = np.asarray(idx, np.int32)[None, :]
+    st8 = np.zeros((B, N, 8), np.float32)
+    st8[..., 0:3] = np.asarray(st, np.float32)[None, :, :]
+    ei, ai = np.repeat(np.arange(B, dtype=np.int32), N), np.tile(np.arange(N, dtype=np.int32), B)
+    for e in (dev, ora):
+        e.reset(ei, ai, ids.reshape(-1, 4), st8.reshape(-1, 8), 1)
+        e.observe()
+    _compare_all(dev, ora, "injected start")
+    rng = np.random.default_rng(3)
+    n_exit = n_req = n_done = 0
+    for t in range(4):
+        act = np.stack([rng.uniform(0, 1, (B, N)), rng.uniform(-0.25, 0.25, (B, N))], axis=-1).astype(np.float32)
+        dev.step_autoreset(act, 5, t, pf, pc)
+        ora.step(act)
+        cf = ora.get(capi.BUF_COL_FLAGS)
+        n_exit += int(cf[..., 2].sum()); n_req += int(cf[..., 3].sum()); n_done += int(ora.get(capi.BUF_DONE).sum())
+        ora.auto_reset(5, t, pf, pc)
+        _compare_all(dev, ora, f"config 4 step {t}")
+    assert n_done > 0  # 32 vehicles on this map overlap: envs finish and restart through the bounded sampler
+    dev.close()
+    ora.close()
+
+
+def test_injected_start_rule_matches_the_golden_generator():
+    """sigmarl_amd.maps.injected_start == the start tests/golden/gen/gen_golden.py injected into the reference for traj_onramp32_c2c."""
+    import traj_replay as tr
+    from sigmarl_amd.maps import injected_start
+
+    z, meta = tr.load_fixture("onramp32_c2c")
+    idx, st = injected_start(load_map("on_ramp_1"), 32)
+    assert list(meta["predefined_ref_path_idx"]) == idx
+    assert np.abs(np.asarray(meta["init_state"]) - np.asarray(st)).max() <= 1e-6
+
+
 def test_rollout_slab_is_written_by_the_step_kernel():
     """sigmaenv_set_slab: the per-step record [obs | reward | done] equals the individual buffers (ragged tile: N=5, B=33)."""
     import torch

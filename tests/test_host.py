@@ -189,9 +189,9 @@ for t in range(T):
         ref.append((full.get(capi.BUF_OBS), full.get(capi.BUF_REWARD), full.get(capi.BUF_DONE).astype(bool)))
 ex.flush(); ex.wait_all()
 if rank == 0:
-    assert ex.completed == [0, 1]
+    assert ex.completed == [(0, CH), (1, T - CH)]  # (buffer, valid steps): the final partial chunk says how many of its rows are new
     t = 0
-    for k, n_steps in zip(ex.completed, (CH, T - CH)):
+    for k, n_steps in ex.completed:
         chunk = torch.cat(ex.gathered(k), 1)  # [CH, TOTAL, W]: ranks own contiguous env ranges
         obs, rew, done = unpack_slab(chunk, N, env.D)
         for q in range(n_steps):
@@ -212,10 +212,15 @@ for t in range(2):
     full2.step(act)
     ref2.append((full2.get(capi.BUF_OBS), full2.get(capi.BUF_REWARD), full2.get(capi.BUF_DONE).astype(bool)))
 ex2.wait_all()
-mine = ex2.time_slice(ex2.completed[0])          # [1, TOTAL, W]: step `rank` of the chunk, every env of both ranks
+mine = ex2.time_slice(ex2.completed[0][0])          # [1, TOTAL, W]: step `rank` of the chunk, every env of both ranks
 obs, rew, done = unpack_slab(mine, N, env2.D)
 assert tuple(obs.shape[:2]) == (1, TOTAL)
 assert np.array_equal(obs[0].numpy(), ref2[rank][0]) and np.array_equal(rew[0].numpy(), ref2[rank][1]) and np.array_equal(done[0].numpy(), ref2[rank][2])
+try:  # shards of different size cannot share one exchange (ADVICE r1): loud error, no hang
+    RolloutExchange(3 + rank, N, env.D, 2, "cpu", dst=0)
+    raise SystemExit("unequal shards were accepted")
+except ValueError:
+    pass
 dist.barrier()
 if rank == 0: print("SHARD_OK")
 dist.destroy_process_group()

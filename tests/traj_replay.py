@@ -17,7 +17,7 @@ from sigmarl_amd.params import Parameters, make_config
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 TRAJ_NAMES = ["cpm16_c2c", "cpm16_mtv", "intersection4_c2c", "onramp6_mtv", "cpm16_c2c_noreset", "cpm8_mtv_noreset", "cpmmixed4_c2c",
-              "cpm16_cbf", "intersection4_cbf", "onramp4_cbf_clf", "cpm16_mask", "intersection4_mask", "roundabout6_mask"]
+              "cpm16_cbf", "intersection4_cbf", "onramp4_cbf_clf", "cpm16_mask", "intersection4_mask", "roundabout6_mask", "onramp32_c2c"]
 # The reference rounds the pseudo distance to fp16 and differentiates it numerically (pseudo_distance.py:118, cbf_qp.py:624-644): a
 # one-ulp difference in a float32 circle centre (torch's SLEEF cos/sin vs the correctly rounded ones of oracle and HIP path) can flip
 # an fp16 rounding and move a margin by up to ~5e-3.  Against the reference goldens the CBF quantities are therefore checked as:
@@ -149,7 +149,7 @@ def compare_snapshot(rep: Report, env, z, prefix, t, envs=None, with_reward=Fals
         rep.f("act_clamped", sel(env.get(capi.BUF_ACTION)), ref("act_clamped"))
 
 
-def apply_initial_reset(env, z, mp):
+def apply_initial_reset(env, z, mp, meta=None):
     B, N = z["init_pos"].shape[:2]
     env_idx = np.repeat(np.arange(B), N)
     agent_idx = np.tile(np.arange(N), B)
@@ -157,6 +157,10 @@ def apply_initial_reset(env, z, mp):
     ids[..., 1] = z["init_scenario_id"]
     ids[..., 2] = z["init_path_id"]
     ids[..., 3] = z["init_point_id"]
+    if meta is not None and meta.get("predefined_ref_path_idx") is not None:
+        # injected start (world_state_rt_sim.py:99-126): the reference copies the polylines of the predefined path but leaves its
+        # path_id / point_id tensors untouched (zeros), so the fixture's snapshot of them does not name the paths in use
+        ids[..., 2] = np.asarray(meta["predefined_ref_path_idx"], np.int32)[None, :]
     for b in range(B):
         for i in range(N):
             ids[b, i, 0] = mp.global_path(ids[b, i, 1], ids[b, i, 2])
@@ -188,7 +192,7 @@ def apply_events(env, z, mp, t):
 def replay(env, z, meta, mp, steps=None, check_next=True) -> Report:
     rep = Report()
     T = int(meta["T"]) if steps is None else min(int(steps), int(meta["T"]))
-    apply_initial_reset(env, z, mp)
+    apply_initial_reset(env, z, mp, meta)
     compare_snapshot(rep, env, z, "init_", None)
     with_cbf = "cbf_in_state" in z.files
     if with_cbf:
