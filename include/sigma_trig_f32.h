@@ -1,91 +1,34 @@
-/* sigma_trig_f32.h -- the fp32 sin / cos / tan / atan / atan2 of the arithmetic contract, shared by the HIP kernels
+/* sigma_trig_f32.h -- the fp32 sin / cos / tan / atan of the arithmetic contract, shared by the HIP kernels
  * (sigmarl_amd/csrc) and the CPU oracle (oracle/).
  *
  * What the reference's arithmetic is (measured in the build container, tools/torch_trig_probe.py): PyTorch-CPU evaluates float32
- *   - atan2 with SLEEF's 1.0-ULP function (Sleef_atan2f16_u10 of the SLEEF 3.6 bundled with torch 2.10; 0 differing results of 4e6),
- *   - sin / cos / tan / atan with something else: neither the u10 nor the u35 SLEEF functions exported by libtorch_cpu.so reproduce
- *     torch.sin / cos / tan / atan (1.9 % / 2.2 % / 12 % / 1.8 % of the results differ from the u10 functions), the results are within
- *     one ulp of the correctly rounded value (sin / cos differ from it in 4.9 % of the cases, tan in 0.6 %, atan in 0.05 %): the MKL
- *     vector math library the build links (closed source, not restatable).
- * Contract:
- *   - sin / cos / tan / atan: the CORRECTLY ROUNDED fp32 value, obtained as (float) of an fp64 evaluation.  Both sides run the same
- *     fp64 algorithm below (3-term Cody-Waite reduction by pi/2, the sine / cosine / arctangent kernels of fdlibm in Horner form; every
- *     operation an IEEE fp64 operation or an explicit fma), so host and device agree bit for bit by construction; its error is about one
- *     fp64 ulp, i.e. the result is the correctly rounded fp32 value for all but ~1e-8 of the arguments (0 of 4e6 sampled arguments per
- *     function differ from (float)libm(double), tests/test_trig.py).  Within one ulp of torch.  Arguments beyond 2^30 return NaN.
- *   - atan2: SLEEF's published algorithm (xatan2f_u1 / atan2kf_u1 of sleefsimdsp.c with the FMA double-float helpers of df.h) restated
- *     operation by operation: the SAME BITS as torch.atan2 (pinned by tests/golden/trig_f32.npz, generator
- *     tests/golden/gen/gen_trig_golden.py).
+ * sin / cos / tan / atan with a vector math library that is neither of the SLEEF functions libtorch_cpu.so exports (1.9 % / 2.2 % / 12 % /
+ * 1.8 % of torch's results differ from Sleef_{sin,cos,tan,atan}f16_u10, more from the u35 forms) -- the MKL vector math the build links,
+ * closed source and not restatable.  Its results are within one ulp of the correctly rounded value (sin / cos differ from it in 4.9 % of
+ * the cases, tan in 0.6 %, atan in 0.05 %).  (atan2, which only the oracle's observation needs, is SLEEF's u10 function in the vectorised
+ * body of a tensor and glibc's atan2f in its tail of < 16 elements -- the oracle uses the correctly rounded value there as well.)
  *
- * Compiles as C99 (gcc -mfma -ffp-contract=off) and as HIP device code (-ffp-contract=off): every fused operation is an explicit
- * fma / fmaf, every other operation a single IEEE operation; `/` is the correctly rounded division on both sides.
+ * Contract: sin / cos / tan / atan are the CORRECTLY ROUNDED fp32 value, obtained as (float) of an fp64 evaluation.  Both sides run the
+ * same fp64 algorithm below (3-term Cody-Waite reduction by pi/2, the sine / cosine / arctangent kernels of fdlibm in Horner form; every
+ * operation an IEEE fp64 operation or an explicit fma), so host and device agree bit for bit by construction; its error is about one
+ * fp64 ulp, i.e. the result is the correctly rounded fp32 value for all but ~1e-8 of the arguments (0 of 4e6 sampled arguments per
+ * function differ from (float)libm(double), tests/test_trig.py).  Within one ulp of torch (tests/golden/trig_f32.npz).  Arguments beyond
+ * 2^30 return NaN.  About 35 fp64 operations per sine / cosine pair: a quarter of the general-purpose OCML routine it replaces on the device.
+ *
+ * Compiles as C99 (gcc -mfma -ffp-contract=off) and as HIP device code (-ffp-contract=off): every fused operation is an explicit fma,
+ * every other operation a single IEEE operation; `/` is the correctly rounded division on both sides.
  */
 #ifndef SIGMA_TRIG_F32_H
 #define SIGMA_TRIG_F32_H
 
 #include <math.h>
 #include <stdint.h>
-#include <string.h>
 
 #if defined(__HIPCC__) || defined(__HIP_DEVICE_COMPILE__)
 #define SIGMA_TRIG_FN __host__ __device__ static __forceinline__
 #else
 #define SIGMA_TRIG_FN static inline
 #endif
-
-typedef struct { float x, y; } sigma_df_t;
-
-SIGMA_TRIG_FN uint32_t sigma_f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
-SIGMA_TRIG_FN float sigma_u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
-SIGMA_TRIG_FN float sigma_mulsign(float x, float y) { return sigma_u2f(sigma_f2u(x) ^ (sigma_f2u(y) & 0x80000000u)); }
-
-/* ---- double-float helpers (sleef/src/libm/df.h, the ENABLE_FMA_SP forms) ------------------------------------------ */
-SIGMA_TRIG_FN sigma_df_t sigma_df(float x, float y) { sigma_df_t r; r.x = x; r.y = y; return r; }
-SIGMA_TRIG_FN sigma_df_t sigma_dfnormalize(sigma_df_t t) { float s = t.x + t.y; return sigma_df(s, (t.x - s) + t.y); }
-SIGMA_TRIG_FN sigma_df_t sigma_dfneg(sigma_df_t t) { return sigma_df(-t.x, -t.y); }
-/* |x| >= |y| */
-SIGMA_TRIG_FN sigma_df_t sigma_dfadd_f_f(float x, float y) { float s = x + y; return sigma_df(s, (x - s) + y); }
-SIGMA_TRIG_FN sigma_df_t sigma_dfadd2_f_f(float x, float y) {
-  float s = x + y, v = s - x;
-  return sigma_df(s, (x - (s - v)) + (y - v));
-}
-SIGMA_TRIG_FN sigma_df_t sigma_dfadd_f2_f(sigma_df_t x, float y) { float s = x.x + y; return sigma_df(s, ((x.x - s) + y) + x.y); }
-SIGMA_TRIG_FN sigma_df_t sigma_dfadd2_f2_f(sigma_df_t x, float y) {
-  float s = x.x + y, v = s - x.x;
-  float t = (x.x - (s - v)) + (y - v);
-  return sigma_df(s, t + x.y);
-}
-SIGMA_TRIG_FN sigma_df_t sigma_dfadd_f_f2(float x, sigma_df_t y) { float s = x + y.x; return sigma_df(s, ((x - s) + y.x) + y.y); }
-SIGMA_TRIG_FN sigma_df_t sigma_dfadd_f2_f2(sigma_df_t x, sigma_df_t y) {
-  float s = x.x + y.x;
-  return sigma_df(s, (((x.x - s) + y.x) + x.y) + y.y);
-}
-SIGMA_TRIG_FN sigma_df_t sigma_dfmul_f2_f2(sigma_df_t x, sigma_df_t y) {
-  float s = x.x * y.x;
-  return sigma_df(s, fmaf(x.x, y.y, fmaf(x.y, y.x, fmaf(x.x, y.x, -s))));
-}
-SIGMA_TRIG_FN float sigma_dfmul_f_f2_f2(sigma_df_t x, sigma_df_t y) { return fmaf(x.x, y.x, fmaf(x.y, y.x, x.x * y.y)); }
-SIGMA_TRIG_FN sigma_df_t sigma_dfmul_f2_f(sigma_df_t x, float y) {
-  float s = x.x * y;
-  return sigma_df(s, fmaf(x.y, y, fmaf(x.x, y, -s)));
-}
-SIGMA_TRIG_FN sigma_df_t sigma_dfsqu(sigma_df_t x) {
-  float s = x.x * x.x;
-  return sigma_df(s, fmaf(x.x + x.x, x.y, fmaf(x.x, x.x, -s)));
-}
-SIGMA_TRIG_FN sigma_df_t sigma_dfrec_f2(sigma_df_t d) {
-  float s = 1.0f / d.x;
-  return sigma_df(s, s * fmaf(-d.y, s, fmaf(-d.x, s, 1.0f)));
-}
-SIGMA_TRIG_FN sigma_df_t sigma_dfdiv(sigma_df_t n, sigma_df_t d) {
-  float t = 1.0f / d.x;
-  float s = n.x * t;
-  float u = fmaf(t, n.x, -s);
-  float v = fmaf(-d.y, t, fmaf(-d.x, t, 1.0f));
-  return sigma_df(s, fmaf(s, v, fmaf(n.y, t, u)));
-}
-
-
 
 /* ---- sin / cos in fp64: 3-term Cody-Waite reduction by pi/2 (exact products for |n| < 2^20, graceful beyond), the kernels of fdlibm
  * k_sin.c / k_cos.c in Horner form.  Arguments beyond 2^30 (and NaN / inf) return NaN. ---- */
@@ -155,44 +98,5 @@ SIGMA_TRIG_FN float sigma_sinf(float d) { double s, c; sigma_sincos_f64((double)
 SIGMA_TRIG_FN float sigma_cosf(float d) { double s, c; sigma_sincos_f64((double)d, &s, &c); return (float)c; }
 SIGMA_TRIG_FN float sigma_tanf(float d) { double s, c; sigma_sincos_f64((double)d, &s, &c); return (float)(s / c); }
 SIGMA_TRIG_FN float sigma_atanf(float d) { return (float)sigma_atan_f64((double)d); }
-
-/* atan2kf_u1: atan(y / x) as a double-float, for y >= 0 */
-SIGMA_TRIG_FN sigma_df_t sigma_atan2kf_u1(sigma_df_t y, sigma_df_t x) {
-  int q = 0;
-  if (x.x < 0.0f) { q = -2; x = sigma_dfneg(x); }
-  sigma_df_t s, t;
-  if (x.x < y.x) { q += 1; s = sigma_dfneg(x); t = y; }
-  else { s = y; t = x; }
-  s = sigma_dfdiv(s, t);
-  t = sigma_dfsqu(s);
-  t = sigma_dfnormalize(t);
-  float u = -0.00176397908944636583328247f;
-  u = fmaf(u, t.x, 0.0107900900766253471374512f);
-  u = fmaf(u, t.x, -0.0309564601629972457885742f);
-  u = fmaf(u, t.x, 0.0577365085482597351074219f);
-  u = fmaf(u, t.x, -0.0838950723409652709960938f);
-  u = fmaf(u, t.x, 0.109463557600975036621094f);
-  u = fmaf(u, t.x, -0.142626821994781494140625f);
-  u = fmaf(u, t.x, 0.199983194470405578613281f);
-  t = sigma_dfmul_f2_f2(t, sigma_dfadd_f_f(-0.333332866430282592773438f, u * t.x));
-  t = sigma_dfmul_f2_f2(s, sigma_dfadd_f_f2(1.0f, t));
-  t = sigma_dfadd_f2_f2(sigma_dfmul_f2_f(sigma_df(1.5707963705062866211f, -4.3711388286737928865e-08f), (float)q), t);
-  return t;
-}
-
-/* Sleef_atan2f*_u10 (xatan2f_u1) */
-SIGMA_TRIG_FN float sigma_atan2f(float y, float x) {
-  const float FLT_MIN_ = 1.17549435082228750797e-38f;
-  if (fabsf(x) < 2.9387372783541830947e-39f) { y *= (float)(1ULL << 24); x *= (float)(1ULL << 24); }  /* underflow guard of xatan2f_u1 */
-  sigma_df_t d = sigma_atan2kf_u1(sigma_df(fabsf(y), 0.0f), sigma_df(x, 0.0f));
-  float r = d.x + d.y;
-  (void)FLT_MIN_;
-  r = sigma_mulsign(r, x);
-  if (isinf(x) || x == 0.0f) r = 1.570796326794896557998982f - (isinf(x) ? (sigma_mulsign(1.0f, x) * 1.570796326794896557998982f) : 0.0f);
-  if (isinf(y)) r = 1.570796326794896557998982f - (isinf(x) ? (sigma_mulsign(1.0f, x) * (float)(3.14159265358979323846 / 4)) : 0.0f);
-  if (y == 0.0f) r = (sigma_f2u(x) >> 31) ? 3.14159265358979323846f : 0.0f;
-  if (isnan(x) || isnan(y)) return NAN;
-  return sigma_mulsign(r, y);
-}
 
 #endif /* SIGMA_TRIG_F32_H */

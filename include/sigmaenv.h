@@ -207,6 +207,11 @@ int sigmaenv_sync(sigmaenv_t* h);
  * since the previous call; n_launches receives the count.  Profiling aid for bench.py. */
 int sigmaenv_step_time_ms(sigmaenv_t* h, double* avg_ms, int32_t* n_launches);
 
+/* The device side of the arithmetic contract's trigonometry (include/sigma_trig_f32.h; torch.sin / cos / tan / atan as called by
+ * sigmarl/dynamics.py:103-111,161-168 and helper_scenario.py:795-810), evaluated on arrays: kind 0 sin, 1 cos, 2 tan, 3 atan of
+ * in[0..n) -> out[0..n) (device pointers, f32).  Lets the GPU test-suite hold the device functions to the same bits as the host's. */
+int sigmaenv_trig_selftest(sigmaenv_t* h, int32_t kind, int32_t n, const float* in, float* out);
+
 /* ---- policy in the loop ------------------------------------------------------------------------------
  * The actor of sigmarl/modules/decision_making_module.py:34-82 (torchrl MultiAgentMLP: Linear(D,256) Tanh Linear(256,256) Tanh
  * Linear(256,256) Tanh Linear(256,4), shared by all agents; NormalParamExtractor "biased_softplus_1.0"; TanhNormal between low and high)

@@ -18,8 +18,7 @@
  *     (-ffp-contract=off) EXCEPT torch.norm over a length-2 dim, which PyTorch-CPU
  *     evaluates as sqrt(fma(y, y, x*x)) [measured in the build container];
  *   - sin/cos/tan/atan are the correctly rounded fp32 value, (float) of a shared fp64 evaluation
- *     (include/sigma_trig_f32.h; the reference's MKL vector math is within 1 ulp of it); atan2 is
- *     SLEEF's 1.0-ULP algorithm restated there, bit-identical to torch.atan2;
+ *     (include/sigma_trig_f32.h; the reference's vector math is within 1 ulp of it); atan2 likewise, through libm;
  *   - argmin/top-k ties resolve to the lowest index (torch.min semantics).
  *
  * Every function cites the reference lines it follows (paths relative to
@@ -55,13 +54,13 @@ typedef struct sigmaenv_oracle {
 } oracle_t;
 
 /* ---- scalar helpers ------------------------------------------------------------------------------------------- */
-/* sin / cos / tan / atan: correctly rounded fp32 through the shared fp64 algorithm; atan2: SLEEF's algorithm == torch.atan2 bit for bit
- * (include/sigma_trig_f32.h states what was measured about the reference's own trig) */
+/* sin / cos / tan / atan: correctly rounded fp32 through the shared fp64 algorithm (include/sigma_trig_f32.h states what was measured
+ * about the reference's own trig); atan2 (observation only; the HIP path has none): correctly rounded through libm */
 static inline float cr_sin(float x) { return sigma_sinf(x); }
 static inline float cr_cos(float x) { return sigma_cosf(x); }
 static inline float cr_tan(float x) { return sigma_tanf(x); }
 static inline float cr_atan(float x) { return sigma_atanf(x); }
-static inline float cr_atan2(float y, float x) { return sigma_atan2f(y, x); }
+static inline float cr_atan2(float y, float x) { return (float)atan2((double)y, (double)x); }
 /* torch.norm(..., dim=<len-2 dim>) on PyTorch-CPU == sqrt(fma(y,y,x*x)) */
 static inline float norm2(float x, float y) { return sqrtf(fmaf(y, y, x * x)); }
 static inline float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
@@ -617,6 +616,18 @@ static inline uint32_t rng_u32(uint64_t seed, uint64_t counter, uint32_t env, ui
   return h;
 }
 #define AUTO_RESET_MAX_TRIES 64
+/* Exclusive upper end of the centre-line points try `t` (0-based) may draw from (world_state_rt_sim.py:253-263): the first half of the
+ * path in training; in testing mode the range starts at the path's beginning and grows with the tries -- end_point_idx starts at 3 and
+ * gains random_count (= t + 1) per try, i.e. 3 + (t + 1)(t + 2) / 2 -- capped by the half.  At least one point (3) is always allowed. */
+static inline int reset_end_point(int testing, int t, int n) {
+  int half = n / 2;
+  int end = half;
+  if (testing) {
+    long grow = 3 + (long)(t + 1) * (t + 2) / 2;
+    end = grow < half ? (int)grow : half;
+  }
+  return end < 4 ? 4 : end;
+}
 
 /* Device-style auto reset of one env: rejection sampling of world_state_rt_sim.py:215-311 (non-testing mode: point in
  * [3, n/2), min centre distance 1.5*sqrt(l^2+w^2)), bounded to AUTO_RESET_MAX_TRIES per agent, then :143-213 and the tail. */
@@ -632,8 +643,7 @@ static void auto_reset_env(oracle_t* o, int b, uint64_t seed, uint64_t counter, 
     for (int t = 0; t < AUTO_RESET_MAX_TRIES; ++t) {
       path = path_first + (int)(((uint64_t)rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, 2u * t) * (uint64_t)(uint32_t)path_count) >> 32);
       int n = o->n_center[path];
-      int end = n / 2;
-      if (end < 4) end = 4;
+      int end = reset_end_point(c->is_testing_mode, t, n);
       pt = 3 + (int)(((uint64_t)rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, 2u * t + 1u) * (uint64_t)(uint32_t)(end - 3)) >> 32);
       float px = o->center[((size_t)path * o->P + pt) * 2], py = o->center[((size_t)path * o->P + pt) * 2 + 1];
       s[0] = px; s[1] = py;
@@ -803,8 +813,7 @@ static void auto_reset_agents(oracle_t* o, int b, uint64_t seed, uint64_t counte
     for (int t = 0; t < AUTO_RESET_MAX_TRIES; ++t) {
       path = path_first + (int)(((uint64_t)rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, 2000u + 2u * t) * (uint64_t)(uint32_t)path_count) >> 32);
       int n = o->n_center[path];
-      int end = n / 2;
-      if (end < 4) end = 4;
+      int end = reset_end_point(c->is_testing_mode, t, n);
       pt = 3 + (int)(((uint64_t)rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, 2001u + 2u * t) * (uint64_t)(uint32_t)(end - 3)) >> 32);
       px = o->center[((size_t)path * o->P + pt) * 2]; py = o->center[((size_t)path * o->P + pt) * 2 + 1];
       int ok = 1;

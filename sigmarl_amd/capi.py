@@ -126,6 +126,7 @@ _SIGS = {
 _PRODUCT_ONLY = {
     "step_time_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "set_slab": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "trig_selftest": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "step_autoreset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32]),
     "step_autoreset_many": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32]),
     "actor_create": (C.c_int, [C.c_int32] + [C.c_void_p] * 10 + [C.POINTER(C.c_void_p)]),

@@ -27,6 +27,14 @@
 
 using namespace sigmadev;
 
+// Phase stamps and ablation switches exist in the profile build only (make prof -> libsigmaenv_prof.so, used by tools/): the product
+// library carries no debug branch, no stamp and reads no debug environment variable.
+#ifdef SIGMAENV_PROFILE
+#define PROF_TS2(g, tid, k) do { if ((g).dbg_ts2 && (tid) == 0) (g).dbg_ts2[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PROF_TS2(g, tid, k) do { } while (0)
+#endif
+
 // weighting_ref_directions = linspace(1, 0.2, 3) / sum (road_traffic.py:536-543); bit patterns of the reference's tensor
 __device__ __constant__ uint32_t W_REF_BITS[3] = {0x3F0E38E3u, 0x3EAAAAABu, 0x3DE38E39u};
 
@@ -587,7 +595,7 @@ __device__ inline void observe_tile(const sigmaenv_config_t& c, const Smem& s, c
     const int q = fdiv(v, g.mN);
     return env_sel[q] * N + (v - q * N);
   };
-#define TSO(k) do { if (ts_base >= 0 && g.dbg_ts && threadIdx.x == 0) g.dbg_ts[(size_t)blockIdx.x * 16 + ts_base + (k)] = __builtin_readcyclecounter(); } while (0)
+#define TSO(k) do { } while (0)
   const float n_pos = (float)((double)c.length * 10.0);   // normalizers.pos, road_traffic.py:588-592
   const float n_v = c.max_speed;                            // :596
   const float n_dl = (float)((double)c.lane_width * 3.0);   // :599-601 (distance_lanelet also normalises the agent distances)
@@ -736,13 +744,23 @@ __device__ inline void observe_tile(const sigmaenv_config_t& c, const Smem& s, c
 struct ResetDraw {
   uint64_t seed, counter;
   int path_first, path_count;
+  int testing;  // is_testing_mode: the candidate range starts at the path's beginning and grows with the tries
 };
+// exclusive upper end of the centre-line points try `tr` may draw from (world_state_rt_sim.py:253-263; specification shared with the oracle)
+__device__ __forceinline__ int reset_end_point(int testing, int tr, int n) {
+  const int half = n / 2;
+  int end = half;
+  if (testing) {
+    const long long grow = 3 + (long long)(tr + 1) * (tr + 2) / 2;
+    end = grow < half ? (int)grow : half;
+  }
+  return end < 4 ? 4 : end;
+}
 __device__ __forceinline__ void reset_candidate(const DevMap& m, const ResetDraw& rd, int b, int i, int tr, int& path, int& pt, float& px, float& py,
                                                 uint32_t draw0 = 0u) {
   path = rd.path_first + (int)__umulhi(rng_u32(rd.seed, rd.counter, (uint32_t)b, (uint32_t)i, draw0 + 2u * tr), (uint32_t)rd.path_count);
   int n = m.n_center[path];
-  int end = n / 2;
-  if (end < 4) end = 4;
+  const int end = reset_end_point(rd.testing, tr, n);
   pt = 3 + (int)__umulhi(rng_u32(rd.seed, rd.counter, (uint32_t)b, (uint32_t)i, draw0 + 2u * tr + 1u), (uint32_t)(end - 3));
   const float2 xy = reinterpret_cast<const float2*>(m.center)[(size_t)path * m.P + pt];
   px = xy.x;
@@ -760,435 +778,6 @@ __device__ inline void auto_reset_tile(const sigmaenv_config_t& c, const DevMap&
                                        const unsigned long long* s_mask, const int* s_full, uint64_t seed, uint64_t counter, int path_first,
                                        int path_count, int obs_mode, const ResetPrefetch& pre, int g_cap = 64);
 #define MAX_G 64
-#ifndef STEP_MIN_WAVES
-#define STEP_MIN_WAVES 4  // <= 128 VGPRs: 4 workgroups per CU resident, 16 workgroups per CU at 16x4096 = 4 full rounds
-#endif
-__global__ void __launch_bounds__(256, STEP_MIN_WAVES) sigmaenv_step_kernel(sigmaenv_config_t c, DevMap m, DevBufs g, const float* __restrict__ actions, int G, int dbg_skip,
-                                                                              uint64_t seed, uint64_t counter, int path_first, int path_count,
-                                                                              float* __restrict__ slab) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const Tile t(c, G);
-  const int N = t.N;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
-  Smem s(smem_raw, G * N, N, t.K, t.D);
-#define TS(k) do { if (g.dbg_ts && tid == 0) g.dbg_ts[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
-  int* pair_ctr = reinterpret_cast<int*>(smem_raw + ((Smem::bytes(G * N, N, t.K, t.D) + 15) & ~(size_t)15)) + MAX_G * 3 + 1;  // after s_mask / s_full / s_any
-  if (tid == blockDim.x - 1) *pair_ctr = 0;  // visible to everyone after the barrier that ends phase A
-  {  // pair table rows, by threads that have nothing to do in phase A: row i holds (i, i+1) .. (i, N-1)
-    const int i = (int)blockDim.x - 2 - tid;
-    if (i >= 0 && i < N - 1) {
-      const int off = i * (2 * N - i - 1) / 2;
-      for (int j = i + 1; j < N; ++j) s.pidx[off + j - i - 1] = (uint16_t)(i | (j << 8));
-    }
-  }
-  TS(0);
-  // ---- A: dynamics + vertices (one lane per agent; slots <= 64 so this is wavefront 0) -------------------------------
-  if (tid < t.slots && !(dbg_skip & 16)) {
-    const int sl = tid;
-    const size_t gi = t.a0 + sl;
-    float st[8], uc[2];
-    // every load of the phase is requested first (the stores below would otherwise fence the later loads behind them)
-    const float4* gs = reinterpret_cast<const float4*>(g.state + gi * 8);
-    const float4 s0 = gs[0], s1 = gs[1];
-    const float2 u = reinterpret_cast<const float2*>(actions)[gi];
-    const int pth = g.path[gi * 4];
-    // last step's vertices: agent 0's corner queries and the whole mtv matrix still see them, because update_distances
-    // runs before update_vertices (world_state_rt_sim.py:439-448)
-    const float2* gv = reinterpret_cast<const float2*>(g.vertices + gi * 10);
-    float2 vo[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) vo[k] = gv[k];
-    // last step's closest-point indices: the pruned scan derives its distance upper bounds from them
-    const int cp0 = g.closest[gi * 3 + 0], cp1 = g.closest[gi * 3 + 1], cp2 = g.closest[gi * 3 + 2];
-    // inputs of the reward phase that do not depend on this step
-    const float2 pp = reinterpret_cast<const float2*>(g.prev_pos)[gi];
-    const float2* gst = reinterpret_cast<const float2*>(g.short_term + gi * NS * 2);
-    float2 spo[NS];
-#pragma unroll
-    for (int k = 0; k < NS; ++k) spo[k] = gst[k];
-    const int loop_flag = m.is_loop[pth];
-    const int4 tm = reinterpret_cast<const int4*>(g.timer)[t.env0 + fdiv(sl, g.mN)];  // step count and counters of the env
-    st[0] = s0.x; st[1] = s0.y; st[2] = s0.z; st[3] = s0.w; st[4] = s1.x; st[5] = s1.y; st[6] = s1.z; st[7] = s1.w;
-    bicycle_step(c, st, u.x, u.y, uc);
-    TS(6);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) s.st[sl * 8 + k] = st[k];
-    reinterpret_cast<float2*>(g.action)[gi] = make_float2(uc[0], uc[1]);
-    float4* go = reinterpret_cast<float4*>(g.state + gi * 8);
-    go[0] = make_float4(st[0], st[1], st[2], st[3]);
-    go[1] = make_float4(st[4], st[5], st[6], st[7]);
-#pragma unroll
-    for (int k = 0; k < 5; ++k) { s.vold[sl * 10 + 2 * k] = vo[k].x; s.vold[sl * 10 + 2 * k + 1] = vo[k].y; }
-    float v[10];
-    rect_vertices(c, st[0], st[1], st[2], v, &s.cs[sl * 2]);
-    float2* gvo = reinterpret_cast<float2*>(g.vertices + gi * 10);
-#pragma unroll
-    for (int k = 0; k < 5; ++k) { s.vnew[sl * 10 + 2 * k] = v[2 * k]; s.vnew[sl * 10 + 2 * k + 1] = v[2 * k + 1]; gvo[k] = make_float2(v[2 * k], v[2 * k + 1]); }
-    s.path[sl] = pth;
-    s.thr[sl * 3] = pp.x; s.thr[sl * 3 + 1] = pp.y;
-#pragma unroll
-    for (int k = 0; k < NS; ++k) { s.shrt[sl * NS * 2 + 2 * k] = spo[k].x; s.shrt[sl * NS * 2 + 2 * k + 1] = spo[k].y; }
-    s.flags[sl * 4 + 1] = loop_flag;
-    s.thr[sl * 3 + 2] = __int_as_float(tm.x);
-    s.flags[sl * 4 + 2] = tm.y;  // counters: the first agent's lane of every env keeps them for the done() bookkeeping
-    s.near[sl * (t.K > 0 ? t.K : 1)] = tm.z;  // (the nearest-neighbour list is only filled by the observation phase)
-    s.cp[sl * 3 + 0] = cp0; s.cp[sl * 3 + 1] = cp1; s.cp[sl * 3 + 2] = cp2;
-  }
-  __syncthreads();
-  TS(7);
-  // candidate-chunk masks of the scan, one lane per (agent, polyline); the last lanes first, so that wavefront 0 (which has just
-  // integrated the dynamics alone) gets the pair phase below to itself when there are fewer tasks than lanes
-  if (m.nch > 0) {
-    for (int task = (int)blockDim.x - 1 - tid; task < t.slots * 3; task += blockDim.x) scan_mask_task<true>(m, s, task, true, N);
-  }
-  TS(1);
-
-  // ---- B1: mutual distances + agent-agent collisions (one lane per ordered pair) -------------------------------------
-  const float diag = sqrtf(c.world_x_dim * c.world_x_dim + c.world_y_dim * c.world_y_dim);  // helper_scenario.py:1140-1143
-  // The matrices are symmetric: one lane per UNORDERED pair (i < j; s.pidx maps the pair number to (i, j)) computes the distance and
-  // the collision flag and writes both entries.  The pairs are handed out in batches of 64 from an LDS counter: the wavefront that has
-  // no candidate masks to compute (it integrated the dynamics alone) starts at once and takes the larger share, the others join.
-  const int TP = N * (N - 1) / 2;
-  const int n_pairs = t.nenv * TP;
-  for (int sl = tid; sl < t.slots; sl += blockDim.x) {  // diagonal (helper_scenario.py:1140-1143)
-    const int i = sl - fdiv(sl, g.mN) * N;
-    s.dist[sl * DIST_STRIDE(N) + i] = diag;
-    g.dist_agents[(t.a0 + sl) * N + i] = diag;
-    s.col[sl * COL_STRIDE(N) + i] = 0;
-    g.col_agents[(t.a0 + sl) * N + i] = 0;
-  }
-  for (;;) {
-    int base = 0;
-    if (lane == 0) base = atomicAdd(pair_ctr, 64);
-    base = __builtin_amdgcn_readfirstlane(base);
-    if (base >= n_pairs || (dbg_skip & 1)) break;
-    const int p = base + lane;
-    const bool in_range = p < n_pairs;
-    int si = 0, sj = 0, i = 0, j = 0;
-    bool near = false;
-    if (in_range) {
-      const int e = fdiv(p, g.mTP);
-      const unsigned ij = s.pidx[p - e * TP];
-      i = (int)(ij & 0xFFu); j = (int)(ij >> 8);
-      si = e * N + i; sj = e * N + j;
-      const float d = pair_distance(c, s.st, s.vold, si, sj);
-      s.dist[si * DIST_STRIDE(N) + j] = d;
-      s.dist[sj * DIST_STRIDE(N) + i] = d;
-      g.dist_agents[(t.a0 + si) * N + j] = d;
-      g.dist_agents[(t.a0 + sj) * N + i] = d;
-      uint8_t col = 0;
-      if (c.distance_type == SIGMAENV_DIST_C2C) {
-        // world_state_rt_sim.py:382-393; rectangles whose circumcircles are disjoint cannot produce a proper edge crossing
-        // (DESIGN.md "Pruned scan"): no collision; close pairs are tested below
-        near = !(d > 2.0f * m.rect_radius + 1e-4f);
-      } else {
-        col = (d == 0.0f) ? 1 : 0;  // :394-396
-      }
-      if (!near) {
-        s.col[si * COL_STRIDE(N) + j] = col; s.col[sj * COL_STRIDE(N) + i] = col;
-        g.col_agents[(t.a0 + si) * N + j] = col; g.col_agents[(t.a0 + sj) * N + i] = col;
-      }
-    }
-    // the 16 (edge of A, edge of B) tests of a close pair, one per lane, four pairs per pass (interX, helper_scenario.py:1165-1196)
-    unsigned long long todo = __ballot(near);
-    while (todo) {
-      const int q = lane >> 4, tt = lane & 15;
-      unsigned long long rest = todo;
-      int src = -1;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {  // the q-th pending pair of this pass (wavefront-uniform bit peeling)
-        const int b = rest ? (__ffsll((long long)rest) - 1) : -1;
-        if (k == q) src = b;
-        rest &= rest - 1ull;
-      }
-      todo = rest;
-      const int a_sl = __shfl(si, src < 0 ? 0 : src, 64), b_sl = __shfl(sj, src < 0 ? 0 : src, 64);
-      bool hit = false;
-      if (src >= 0) {
-        const float* va = s.vnew + a_sl * 10 + 2 * (tt >> 2);
-        const float* vb = s.vnew + b_sl * 10 + 2 * (tt & 3);
-        const Edge e = make_edge(va[0], va[1], va[2], va[3]);
-        const float dx2 = vb[2] - vb[0], dy2 = vb[3] - vb[1];
-        const float S2 = dx2 * vb[1] - dy2 * vb[0];
-        hit = edge_hits_segment(e, vb[0], vb[1], vb[2], vb[3], dx2, dy2, S2);
-      }
-      const unsigned long long hb = __ballot(hit);
-      if (src >= 0 && tt == 0) {
-        const uint8_t col = ((hb >> (q * 16)) & 0xFFFFull) ? 1 : 0;
-        const int ea = fdiv(a_sl, g.mN) * N;
-        const int ja = b_sl - ea, jb = a_sl - ea;  // column of B in A's row and of A in B's row
-        s.col[a_sl * COL_STRIDE(N) + ja] = col;
-        s.col[b_sl * COL_STRIDE(N) + jb] = col;
-        g.col_agents[(t.a0 + a_sl) * N + ja] = col;
-        g.col_agents[(t.a0 + b_sl) * N + jb] = col;
-      }
-    }
-  }
-
-  __syncthreads();  // the candidate masks (written by other lanes) must be visible to the scan
-  TS(2);
-  // ---- B2: distance queries + boundary collisions (two agents per wavefront; full-scan fallback one agent per wavefront) ----
-  const int wave_u = __builtin_amdgcn_readfirstlane(wave);  // wavefront-uniform: the pair bookkeeping of the scan stays on the scalar unit
-  if (dbg_skip & 2) {
-  } else if (m.nch > 0) {
-    int rA = (2 * wave_u) % N;  // agent index of the pair's first slot, advanced with the pair (scalar unit, no division per pair)
-    const int r_step = (2 * n_waves) % N;
-    if (m.fast_div) {
-      for (int pr = wave_u; 2 * pr < t.slots; pr += n_waves) {
-        pair_scan<true, true>(m, c, s, 2 * pr, (2 * pr + 1 < t.slots) ? 3 : 1, lane, true, N, rA);
-        rA += r_step;
-        if (rA >= N) rA -= N;
-      }
-    } else {
-      for (int pr = wave_u; 2 * pr < t.slots; pr += n_waves) {
-        pair_scan<true, false>(m, c, s, 2 * pr, (2 * pr + 1 < t.slots) ? 3 : 1, lane, true, N, rA);
-        rA += r_step;
-        if (rA >= N) rA -= N;
-      }
-    }
-  } else {
-    for (int sl = wave; sl < t.slots; sl += n_waves) {
-      const int i = sl % N;
-      const float* si = s.st + sl * 8;
-      const float* qv = (i == 0) ? (s.vold + sl * 10) : (s.vnew + sl * 10);  // agent 0 queries its corners at last step's vertices
-      AgentScan r;
-      agent_scan_full<true>(m, c, s.path[sl], lane, si[0], si[1], qv, s.vnew + sl * 10, r);
-      if (lane == 0) {
-        s.dref[sl] = r.d_ref;
-#pragma unroll
-        for (int q = 0; q < 5; ++q) { s.dleft[sl * 5 + q] = r.dl[q]; s.dright[sl * 5 + q] = r.dr[q]; }
-        s.cp[sl * 3 + 0] = r.cp_ref; s.cp[sl * 3 + 1] = r.cp_l; s.cp[sl * 3 + 2] = r.cp_r;
-        s.flags[sl * 4 + 0] = r.hit ? 1 : 0;
-      }
-    }
-  }
-  __syncthreads();
-  TS(3);
-
-  // ---- C: reward, short-term path, per-env done()/counters via ballots (wavefront 0, one lane per agent) --------------
-  if (wave == 0 && !(dbg_skip & 4)) {
-    const bool act = tid < t.slots;
-    const int sl = act ? tid : 0;
-    const int e = fdiv(sl, g.mN), i = sl - e * N;
-    const size_t gi = t.a0 + sl;
-    const size_t BN = (size_t)c.n_envs * N;
-    int col_a = 0, col_l = 0, goal = 0, entry = 0;
-    if (act) {
-      const float* si = s.st + sl * 8;
-      const float2 pp = make_float2(s.thr[sl * 3], s.thr[sl * 3 + 1]);
-      float w[3];
-      w[0] = __uint_as_float(W_REF_BITS[0]); w[1] = __uint_as_float(W_REF_BITS[1]); w[2] = __uint_as_float(W_REF_BITS[2]);
-      float mvx = si[0] - pp.x, mvy = si[1] - pp.y;                  // road_traffic.py:972-974
-      float acc = 0.0f;
-#pragma unroll
-      for (int k = 0; k < NS; ++k) {  // the short-term path of the PREVIOUS step (:976-984), staged in LDS by phase A
-        const float2 sp = make_float2(s.shrt[sl * NS * 2 + 2 * k], s.shrt[sl * NS * 2 + 2 * k + 1]);
-        float rx = sp.x - pp.x, ry = sp.y - pp.y;
-        float mp = mvx * rx + mvy * ry;
-        acc = acc + mp * w[k];
-      }
-      float denom = (float)((double)c.max_speed * (double)c.dt);
-      float rew = 0.0f;
-      rew += acc / denom * c.reward_progress;                        // :986-991
-      {  // entry / exit segments of non-loop paths (world_state_rt_sim.py:413-424) and the boundary minimum (world_state_rt.py:648-656)
-        const int pth = s.path[sl];
-        if (!s.flags[sl * 4 + 1]) {
-          const float* lb = m.left + (size_t)pth * m.P * 2;
-          const float* rb = m.right + (size_t)pth * m.P * 2;
-          const int nl = m.n_left[pth], nr = m.n_right[pth];
-          entry = interx_rect_seg(s.vnew + sl * 10, lb[0], lb[1], rb[0], rb[1]) ? 1 : 0;
-          goal = interx_rect_seg(s.vnew + sl * 10, lb[2 * (nl - 1)], lb[2 * (nl - 1) + 1], rb[2 * (nr - 1)], rb[2 * (nr - 1) + 1]) ? 1 : 0;
-        }
-        float mbnd = INFINITY;
-#pragma unroll
-        for (int q = 0; q < 5; ++q) mbnd = fminf(mbnd, s.dleft[sl * 5 + q]);
-#pragma unroll
-        for (int q = 0; q < 5; ++q) mbnd = fminf(mbnd, s.dright[sl * 5 + q]);
-        s.dbound[sl] = mbnd;
-      }
-      float reward_goal = (float)goal * c.reward_reach_goal;
-      if ((N & 3) == 0) {  // the row of collision bytes is word aligned (COL_STRIDE): N / 4 LDS reads instead of N  (:1008-1013)
-        const uint32_t* cw = reinterpret_cast<const uint32_t*>(s.col + sl * COL_STRIDE(N));
-        uint32_t any = 0u;
-        for (int j = 0; j < N / 4; ++j) any |= cw[j];
-        col_a = any != 0u;
-      } else {
-        for (int j = 0; j < N; ++j) col_a |= s.col[sl * COL_STRIDE(N) + j];
-      }
-      float pca = (float)col_a * c.penalty_collide_with_agents;
-      col_l = s.flags[sl * 4 + 0];
-      float pcl = (float)col_l * c.penalty_collide_with_boundaries;  // :1021-1026
-      float pen_lane = decreasing_lin(s.dbound[sl], c.threshold_near_boundary_low, c.threshold_near_boundary_high) * c.penalty_near_boundary;
-      bool has_near = false;
-      float near_other = 0.0f;
-      if (c.is_testing_mode) {                                       // :1050-1055
-        rew += reward_goal; rew += pca; rew += pcl;
-      } else {
-        if (c.rew_flags & SIGMAENV_REW_EXACT_SPARSE) { rew += pca; rew += pcl; }
-        if (c.rew_flags & SIGMAENV_REW_TTC) {                        // :1064-1084
-          float p = ttc_penalty(c, s.st + e * N * 8, N, i);
-          near_other = p; has_near = true;
-          rew += p; rew += pen_lane; rew += pca; rew += pcl;
-          if (c.rew_flags & SIGMAENV_REW_HAS_SPARSE) { rew += pca; rew += pcl; }
-        }
-        if (c.rew_flags & SIGMAENV_REW_DISTANCE) {                   // :1086-1110
-          float ssum = 0.0f;
-          {  // decreasing_lin (helper_scenario.py:960-996) with the division by the constant (x1 - x0) through its reciprocal (exact, see
-             // div_shared; the numerator is 0 or at least an ulp of the thresholds)
-            const float x0 = c.threshold_near_other_agents_low, x1 = c.threshold_near_other_agents_high;
-            const float denom = x1 - x0;
-            const bool fast = denom >= 0x1p-60f && denom <= 0x1p60f;
-            const float rcp = fast ? shared_rcp(denom) : 0.0f;
-            for (int j0 = 0; j0 < N; j0 += 4) {
-              float d[4];
-#pragma unroll
-              for (int u2 = 0; u2 < 4; ++u2) d[u2] = s.dist[sl * DIST_STRIDE(N) + min(j0 + u2, N - 1)];
-#pragma unroll
-              for (int u2 = 0; u2 < 4; ++u2) {
-                if (j0 + u2 < N) {
-                  const float x = clampf(d[u2], x0, x1);
-                  const float q = fast ? div_shared(x - x0, denom, rcp) : (x - x0) / denom;
-                  ssum += 1.0f - q;
-                }
-              }
-            }
-          }
-          float p = ssum * c.penalty_near_other_agents;
-          near_other = p; has_near = true;
-          rew += p; rew += pen_lane;
-          if (c.rew_flags & SIGMAENV_REW_HAS_SPARSE) { rew += pca; rew += pcl; }
-        }
-        if (c.rew_flags & SIGMAENV_REW_CBF_QP) {                     // :1112-1139 with is_solve_qp == True
-          // deviation of the applied (clamped) action from world_state.nominal_action_*, which sigmaenv_cbf_qp left behind
-          const float2 nomv = reinterpret_cast<const float2*>(g.cbf_nominal)[gi];
-          const float2 ua = reinterpret_cast<const float2*>(actions)[gi];
-          const float cur0 = clampf(ua.x, -c.max_speed, c.max_speed), cur1 = clampf(ua.y, -c.max_steering, c.max_steering);
-          const float pv = c.penalty_deviate_from_cbf_vel * (fabsf(cur0 - nomv.x) / c.max_speed);
-          const float ps = c.penalty_deviate_from_cbf_steer * (fabsf(cur1 - nomv.y) / c.max_steering);
-          rew += pv + ps;
-          if (c.rew_flags & SIGMAENV_REW_HAS_SPARSE) { rew += pca; rew += pcl; }
-        }
-        if (c.rew_flags & SIGMAENV_REW_CBF) {                        // :1112-1151 with is_solve_qp == False
-          // the three margin channels CBFQP.update_qp wrote before this step (sigmaenv_cbf_rewards)
-          const float cbf_rew = ((g.reward_info[5 * BN + gi] + g.reward_info[6 * BN + gi]) + g.reward_info[4 * BN + gi]) / 3.0f;
-          rew += cbf_rew;
-          if (c.rew_flags & SIGMAENV_REW_HAS_SPARSE) { rew += pca; rew += pcl; }
-        }
-      }
-      TS(14);
-      float r = clampf(rew, -1.0f, 1.0f);                            // :1249
-      g.reward[gi] = r;
-      s.rew[sl] = r;
-      // RewardInfo.reset() at the top of every reward() zeroes all agents' entries except three fields
-      // (helper_scenario.py:128-138): only the last agent's values of the other fields survive the loop.
-      bool last = (i == N - 1);
-      g.reward_info[1 * BN + gi] = last ? reward_goal : 0.0f;
-      g.reward_info[7 * BN + gi] = last ? pca : 0.0f;
-      g.reward_info[8 * BN + gi] = last ? pcl : 0.0f;
-      g.reward_info[11 * BN + gi] = last ? r : 0.0f;
-      if (has_near) g.reward_info[4 * BN + gi] = near_other;
-      // update_state_after_rewarding: new short-term path (world_state_rt_sim.py:450-454)
-      int path = s.path[sl];
-      float sp[NS * 2];
-      short_term_path(m.center + (size_t)path * m.P * 2, s.npts[sl * 3], s.flags[sl * 4 + 1] != 0, s.cp[sl * 3], sp);
-      if (sp[0] == 12345.0f) TS(15);
-      TS(15);
-      float2* gso = reinterpret_cast<float2*>(g.short_term + gi * NS * 2);
-#pragma unroll
-      for (int k = 0; k < NS; ++k) { s.shrt[sl * NS * 2 + 2 * k] = sp[2 * k]; s.shrt[sl * NS * 2 + 2 * k + 1] = sp[2 * k + 1]; gso[k] = make_float2(sp[2 * k], sp[2 * k + 1]); }
-      reinterpret_cast<float2*>(g.prev_pos)[gi] = make_float2(si[0], si[1]);  // state_buffer.add, road_traffic.py:1226-1240
-      g.dist_ref[gi] = s.dref[sl];
-#pragma unroll
-      for (int q = 0; q < 5; ++q) { g.dist_left[gi * 5 + q] = s.dleft[sl * 5 + q]; g.dist_right[gi * 5 + q] = s.dright[sl * 5 + q]; }
-      g.dist_bound[gi] = s.dbound[sl];
-      g.closest[gi * 3 + 0] = s.cp[sl * 3 + 0]; g.closest[gi * 3 + 1] = s.cp[sl * 3 + 1]; g.closest[gi * 3 + 2] = s.cp[sl * 3 + 2];
-    }
-    // timer, counters, done(), reset requests (road_traffic.py:954-962,998-1002,1030-1035,1368-1487): per-env reductions by ballot
-    const unsigned long long env_mask = ((N >= 64) ? ~0ull : ((1ull << N) - 1ull)) << (e * N);
-    const unsigned long long b_ca = __ballot(act && col_a), b_cl = __ballot(act && col_l), b_goal = __ballot(act && goal);
-    const unsigned long long b_any = __ballot(act && (col_a | col_l | goal));
-    if (act) {
-      const int b = t.env0 + e;
-      const int step = __float_as_int(s.thr[sl * 3 + 2]) + 1;
-      const int max_reached = (step == c.max_steps - 1);
-      const int any_ca = (b_ca & env_mask) != 0ull, any_cl = (b_cl & env_mask) != 0ull;
-      const int done = c.is_testing_mode ? max_reached : (max_reached | any_ca | any_cl);
-      int rq = 0;
-      if (c.is_testing_mode) rq = col_a | col_l | entry | goal;
-      else if (c.has_entry_exit) rq = entry | goal;
-      reinterpret_cast<uchar4*>(g.col_flags)[gi] = make_uchar4((uint8_t)col_l, (uint8_t)entry, (uint8_t)goal, (uint8_t)((rq && !done) ? 1 : 0));
-      s.flags[sl * 4 + 3] = (rq && !done) ? 1 : 0;
-      if (i == 0) {
-        g.timer[b * 4] = step;
-        g.timer[b * 4 + 1] = s.flags[sl * 4 + 2] + __popcll(b_any & env_mask);
-        g.timer[b * 4 + 2] = s.near[sl * (t.K > 0 ? t.K : 1)] + __popcll(b_goal & env_mask);
-        g.done[b] = (uint8_t)done;
-        s.rew[G * N + e] = done ? 1.0f : 0.0f;
-      }
-    }
-  }
-  __syncthreads();
-  TS(4);
-
-  // fused resets: the start candidates of a finished env only depend on the random stream and the map, so the wavefront that
-  // will re-place env `wave` requests them now and the two dependent loads complete behind the observation phase
-  ResetPrefetch pre;
-  pre.have = false;
-  pre.path = 0; pre.pt = 3; pre.x = 0.f; pre.y = 0.f;
-  if (path_count > 0 && wave < t.nenv && s.rew[G * N + wave] != 0.0f) {
-    const int TRp = 64 / N > 0 ? 64 / N : 1;
-    const int ca = lane / TRp, ctr = lane - ca * TRp;
-    const ResetDraw rd{seed, counter, path_first, path_count};
-    if (ca < N) reset_candidate(m, rd, t.env0 + wave, ca, ctr, pre.path, pre.pt, pre.x, pre.y);
-    pre.have = true;
-  }
-  // ---- D: observations ---------------------------------------------------------------------------------------------
-  if (!(dbg_skip & 8)) observe_tile(c, s, g, t, 8);
-  if (slab) {  // rollout record of this step (observation AFTER the step, reward, done), one contiguous row per env
-    const int ND = N * t.D, W = ND + N + 1;
-    if ((ND & 3) == 0) {
-      // observation part: whole float4s out of the (16-byte aligned) LDS rows, 16-byte stores at the row's 4-byte alignment
-      const int Q = ND >> 2;  // float4s per env
-      for (int k = tid; k < t.nenv * Q; k += blockDim.x) {
-        const int e = k / Q, q = k - e * Q;  // Q is a power-of-two multiple for the default widths; the division is per float4, not per float
-        const float4 v = reinterpret_cast<const float4*>(s.obs + e * ND)[q];
-        *reinterpret_cast<F4u*>(slab + (size_t)(t.env0 + e) * W + 4 * q) = F4u{v.x, v.y, v.z, v.w};
-      }
-      for (int k = tid; k < t.nenv * (N + 1); k += blockDim.x) {  // rewards and the done flag
-        const int e = k / (N + 1), r = k - e * (N + 1);
-        slab[(size_t)(t.env0 + e) * W + ND + r] = (r < N) ? s.rew[e * N + r] : s.rew[G * N + e];
-      }
-    } else {
-      for (int k = tid; k < t.nenv * W; k += blockDim.x) {
-        int e = fdiv(k, g.mW), r = k - e * W;
-        float v = (r < ND) ? s.obs[e * ND + r] : ((r < ND + N) ? s.rew[e * N + (r - ND)] : s.rew[G * N + e]);
-        slab[(size_t)(t.env0 + e) * W + r] = v;
-      }
-    }
-  }
-  TS(5);
-#undef TS
-  // ---- fused device-side resets (sigmaenv_step_autoreset): the tile is still in LDS, the record of this step is written -------
-  if (path_count > 0) {
-    unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(smem_raw + ((Smem::bytes(G * N, N, t.K, t.D) + 15) & ~(size_t)15));
-    int* s_full = reinterpret_cast<int*>(s_mask + MAX_G);
-    int* s_any = s_full + MAX_G;
-    if (tid == 0) *s_any = 0;
-    __syncthreads();  // also: the slab rows above have read s.obs / s.rew
-    if (tid < t.nenv) {
-      const int dn = s.rew[G * N + tid] != 0.0f;
-      unsigned long long rq = 0ull;
-      if (!dn && (c.is_testing_mode || c.has_entry_exit)) {
-        for (int i = 0; i < N; ++i) rq |= (unsigned long long)(s.flags[(tid * N + i) * 4 + 3] != 0) << i;
-      }
-      s_mask[tid] = dn ? ((N >= 64) ? ~0ull : ((1ull << N) - 1ull)) : rq;
-      s_full[tid] = dn;
-      if (dn || rq) *s_any = 1;
-    }
-    __syncthreads();
-    if (*s_any) auto_reset_tile(c, m, g, s, t, s_mask, s_full, seed, counter, path_first, path_count, 2, pre);
-  }
-}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // observation only (observation() called again after resets)
@@ -1243,7 +832,7 @@ __device__ inline void reset_derive_body(const sigmaenv_config_t& c, const DevMa
                                          const unsigned long long* agent_mask, const int* full, int with_obs) {
   const int N = t.N;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
-#define TS2(k) do { if (g.dbg_ts2 && tid == 0) g.dbg_ts2[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+#define TS2(k) PROF_TS2(g, tid, k)
   for (int sl = tid; sl < t.slots; sl += blockDim.x) {
     int e = sl / N, i = sl - e * N;
     if ((agent_mask[e] >> i) & 1ull) {
@@ -1317,7 +906,7 @@ __device__ inline void reset_finish_body(const sigmaenv_config_t& c, const DevBu
                                          const unsigned long long* agent_mask, const int* full, int with_obs, int g_cap) {
   const int N = t.N;
   const int tid = Grp<WAVE>::tid();
-#define TS2(k) do { if (g.dbg_ts2 && tid == 0) g.dbg_ts2[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+#define TS2(k) PROF_TS2(g, tid, k)
   const float diag = sqrtf(c.world_x_dim * c.world_x_dim + c.world_y_dim * c.world_y_dim);
   for (int p = tid; p < t.slots * N; p += Grp<WAVE>::size()) {
     int si = fdiv(p, g.mN), j = p - si * N;
@@ -1539,8 +1128,8 @@ __device__ inline void auto_reset_tile(const sigmaenv_config_t& c, const DevMap&
                                        int path_count, int obs_mode, const ResetPrefetch& pre, int g_cap) {
   const int N = t.N;
   const int tid = Grp<WAVE>::tid(), lane = tid & 63, wave = tid >> 6, n_waves = Grp<WAVE>::size() >> 6;
-  const ResetDraw rd{seed, counter, path_first, path_count};
-#define TS2(k) do { if (g.dbg_ts2 && tid == 0) g.dbg_ts2[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+  const ResetDraw rd{seed, counter, path_first, path_count, c.is_testing_mode};
+#define TS2(k) PROF_TS2(g, tid, k)
   TS2(1);
   const float min_d = sqrtf((float)((double)c.length * (double)c.length + (double)c.width * (double)c.width)) * 1.5f;  // road_traffic.py:679-684
   const float min_d_sq = min_d * min_d;
@@ -1641,8 +1230,10 @@ __global__ void __launch_bounds__(512) sigmaenv_auto_reset_kernel(sigmaenv_confi
   unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(smem_raw + ((Smem::bytes(G * N, N, t.K, t.D) + 15) & ~(size_t)15));
   int* s_full = reinterpret_cast<int*>(s_mask + MAX_G);
   int* s_any = s_full + MAX_G;
-#define TS2(k) do { if (g.dbg_ts2 && tid == 0) g.dbg_ts2[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+#define TS2(k) PROF_TS2(g, tid, k)
+#ifdef SIGMAENV_PROFILE
   if (g.dbg_ts2 && tid < 16) g.dbg_ts2[(size_t)blockIdx.x * 16 + tid] = 0ull;
+#endif
   TS2(0);
 #undef TS2
   if (tid == 0) *s_any = 0;
@@ -1687,8 +1278,6 @@ struct sigmaenv {
   int G = 1;      // environments per workgroup (G * N <= 64 agent slots) of the block kernels (reset / observe)
   int wave_G = 1, wave_wpb = 1, wave_grid = 1;  // step kernel: environments per wavefront tile, wavefronts per workgroup, workgroups
   size_t wave_tile_lds = 0;
-  bool use_block_step = false;  // SIGMAENV_STEP_KERNEL=block: the workgroup-per-tile step kernel (A/B baseline)
-  int dbg_skip = 0;  // SIGMAENV_DEBUG_SKIP: phase-ablation bit mask for profiling experiments (results invalid when non-zero)
   int grid = 1;
   void* bufs[SIGMAENV_BUF_COUNT] = {nullptr};
   size_t buf_bytes[SIGMAENV_BUF_COUNT] = {0};
@@ -1726,6 +1315,13 @@ static int dev_alloc(sigmaenv* h, void** p, size_t bytes) {
   e = hipMemsetAsync(*p, 0, bytes, h->stream);
   if (e != hipSuccess) { h->err = std::string("hipMemsetAsync: ") + hipGetErrorString(e); return SIGMAENV_EHIP; }
   return SIGMAENV_OK;
+}
+
+static void dev_free(sigmaenv* h, void* p) {
+  if (!p) return;
+  for (size_t k = 0; k < h->allocs.size(); ++k)
+    if (h->allocs[k] == p) { h->allocs.erase(h->allocs.begin() + (long)k); break; }
+  (void)hipFree(p);
 }
 
 extern "C" int sigmaenv_obs_dim(int32_t n_nearing) { return 1 + 2 * NS + 3 + n_nearing * 11; }
@@ -1919,7 +1515,7 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
     if (tab_smem > 64 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_start_table_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tab_smem);
     hipLaunchKernelGGL(sigmaenv_start_table_kernel, dim3((np * P + 63) / 64), dim3(256), tab_smem, h->stream, h->cfg, h->map, d_tab);
-    HIPCHK(h, hipGetLastError());
+    if (hipGetLastError() != hipSuccess) { sigmaenv_destroy(h); return SIGMAENV_EHIP; }
     h->map.start_table = d_tab;
   }
   const size_t BN = (size_t)B * N;
@@ -1960,10 +1556,12 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
 #ifdef SIGMAENV_PROFILE
   if (const char* e = getenv("SIGMAENV_DEBUG_SKIP")) g.dbg_skip = atoi(e);
 #endif
+#ifdef SIGMAENV_PROFILE
   if (const char* e = getenv("SIGMAENV_TIMESTAMPS")) {
     if (atoi(e) == 1) { ALLOC(g.dbg_ts, (size_t)B * 16 * sizeof(unsigned long long)); (void)hipMemsetAsync(g.dbg_ts, 0, (size_t)B * 128, h->stream); }
-    if (atoi(e) == 2) { ALLOC(g.dbg_ts2, (size_t)B * 16 * sizeof(unsigned long long)); hipMemsetAsync(g.dbg_ts2, 0, (size_t)B * 128, h->stream); }
+    if (atoi(e) == 2) { ALLOC(g.dbg_ts2, (size_t)B * 16 * sizeof(unsigned long long)); (void)hipMemsetAsync(g.dbg_ts2, 0, (size_t)B * 128, h->stream); }
   }
+#endif
 #undef ALLOC
 #undef H2D
   hipDeviceProp_t prop;
@@ -1980,7 +1578,6 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
     int v = atoi(e);
     if (v >= 64 && v <= 256 && v % 64 == 0) h->block = v;
   }
-  if (const char* e = getenv("SIGMAENV_DEBUG_SKIP")) h->dbg_skip = atoi(e);
   if (const char* e = getenv("SIGMAENV_TIMING_STRIDE")) { int v = atoi(e); if (v >= 1) h->timing_stride = v; }
   h->grid = (B + h->G - 1) / h->G;
   h->reset_block = 256;  // measured at 16 x 4096: 512-thread reset workgroups are slower (more early-exit launch cost, lower occupancy)
@@ -1990,7 +1587,6 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
   }
   h->smem_bytes = ((Smem::bytes(h->G * N, N, K, h->D) + 15) & ~(size_t)15) + MAX_G * 8 + MAX_G * 4 + 16 + (MAX_G + 1) * 4;  // masks, flags, counters, env list
   if (h->smem_bytes > 64 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem_bytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_observe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem_bytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_reset_derive_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem_bytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_auto_reset_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem_bytes);
@@ -2017,7 +1613,6 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_wave_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_wave_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     }
-    if (const char* e = getenv("SIGMAENV_STEP_KERNEL")) h->use_block_step = (strcmp(e, "block") == 0);
   }
   if (hipStreamSynchronize(h->stream) != hipSuccess) { sigmaenv_destroy(h); return SIGMAENV_EHIP; }
   *out = h;
@@ -2074,6 +1669,7 @@ extern "C" int sigmaenv_reset(sigmaenv_t* h, int32_t n, const int32_t* env_idx, 
 
 static int launch_step(sigmaenv* h, const float* actions, uint64_t seed, uint64_t counter, int path_first, int path_count) {
   if (!h || !actions) return SIGMAENV_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));  // handles on several GPUs may live in one process: every entry point that enqueues work selects its device
   int slot = -1;
   // HIP-event bracketing of a SAMPLE of the launches (every timing_stride-th): every event pair costs a few microseconds of
   // queue time, bracketing all launches would slow down the very region it measures
@@ -2088,10 +1684,7 @@ static int launch_step(sigmaenv* h, const float* actions, uint64_t seed, uint64_
     h->ev_used.push_back(slot);
     HIPCHK(h, hipEventRecord(h->ev_pool[slot].first, h->stream));
   }
-  if (h->use_block_step)
-    hipLaunchKernelGGL(sigmaenv_step_kernel, dim3(h->grid), dim3(h->block), h->smem_bytes, h->stream, h->cfg, h->map, h->buf, actions, h->G,
-                       h->dbg_skip, seed, counter, path_first, path_count, h->buf.slab);
-  else {
+  {
     // instantiations: exact shared-reciprocal division or plain `/` in the scan (DevMap::fast_div), lane pair per agent in the dynamics or not
     const bool par = 2 * h->wave_G * h->N <= 64;
     auto kern = h->map.fast_div ? (par ? sigmaenv_step_wave_kernel<true, true> : sigmaenv_step_wave_kernel<true, false>)
@@ -2128,6 +1721,7 @@ extern "C" int sigmaenv_step_autoreset_many(sigmaenv_t** hs, int32_t n, const fl
 
 extern "C" int sigmaenv_observe(sigmaenv_t* h) {
   if (!h) return SIGMAENV_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));
   hipLaunchKernelGGL(sigmaenv_observe_kernel, dim3(h->grid), dim3(h->block), h->smem_bytes, h->stream, h->cfg, h->buf, h->G);
   HIPCHK(h, hipGetLastError());
   return SIGMAENV_OK;
@@ -2135,6 +1729,7 @@ extern "C" int sigmaenv_observe(sigmaenv_t* h) {
 
 extern "C" int sigmaenv_auto_reset(sigmaenv_t* h, uint64_t seed, uint64_t counter, int32_t path_first, int32_t path_count) {
   if (!h || path_first < 0 || path_count < 1 || path_first + path_count > h->n_paths) return SIGMAENV_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));
   hipLaunchKernelGGL(sigmaenv_auto_reset_kernel, dim3(h->B), dim3(h->reset_block), h->smem_bytes, h->stream, h->cfg, h->map, h->buf, seed, counter,
                      (int)path_first, (int)path_count, 1);
   HIPCHK(h, hipGetLastError());
@@ -2150,6 +1745,7 @@ extern "C" int sigmaenv_get(sigmaenv_t* h, sigmaenv_buf_t which, void** dev_ptr,
 
 extern "C" int sigmaenv_sync(sigmaenv_t* h) {
   if (!h) return SIGMAENV_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return SIGMAENV_OK;
 }
@@ -2195,6 +1791,21 @@ extern "C" int sigmaenv_step_time_ms(sigmaenv_t* h, double* avg_ms, int32_t* n_l
   *n_launches = (int32_t)h->ev_used.size();
   if (*n_launches) *avg_ms = total / *n_launches;
   h->ev_used.clear();
+  return SIGMAENV_OK;
+}
+
+__global__ void sigmaenv_trig_selftest_kernel(int kind, int n, const float* __restrict__ in, float* __restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const float x = in[k];
+  out[k] = kind == 0 ? cr_sin(x) : (kind == 1 ? cr_cos(x) : (kind == 2 ? cr_tan(x) : cr_atan(x)));
+}
+extern "C" int sigmaenv_trig_selftest(sigmaenv_t* h, int32_t kind, int32_t n, const float* in, float* out) {
+  if (!h || !in || !out || n < 0 || kind < 0 || kind > 3) return SIGMAENV_EINVAL;
+  if (n == 0) return SIGMAENV_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  hipLaunchKernelGGL(sigmaenv_trig_selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, (int)kind, (int)n, in, out);
+  HIPCHK(h, hipGetLastError());
   return SIGMAENV_OK;
 }
 

@@ -411,7 +411,11 @@ class ScenarioRoadTraffic(BaseScenario):
         """[B] bool (road_traffic.py:1368-1487) + the per-agent resets the reference performs here (:1435-1447, :1456-1473)."""
         is_done = self.env.done.to(torch.bool)
         if self.device_side_resets:
-            lid = 0 if self.parameters.scenario_type != "cpm_mixed" else 1
+            if self.parameters.scenario_type == "cpm_mixed":
+                # the reference draws the sub-scenario (path list) of every reset env from cpm_scenario_probabilities and keeps it for the
+                # env's per-agent resets (world_state_rt_sim.py:313-358); the device sampler takes ONE path list per launch
+                raise NotImplementedError("device_side_resets is not available for scenario_type 'cpm_mixed' (per-env path lists)")
+            lid = 0
             self.env.auto_reset(seed=int(getattr(self.parameters, "random_seed", 0)), path_first=self.map.list_first[lid],
                                 path_count=self.map.list_count[lid])
             self._auto_reset_done_this_step = True

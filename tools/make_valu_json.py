@@ -1,0 +1,39 @@
+#!/usr/bin/env python
+"""Builds profiles/valu_latest.json -- the issue-side figures of the step kernel that bench.py reports next to the HBM roofline
+ -- from the SQ passes of tools/pmc_passes.sh (per-launch averages over the step kernel's dispatches):
+  valu_insts_per_launch        SQ_INSTS_VALU (wavefront instructions)
+  valu_busy_cycles_per_launch  SQ_ACTIVE_INST_VALU x 4 (the counter ticks in quad-cycles, MI355X guide "cycle constants"), summed over SIMDs
+  fp32_flops_per_launch        (ADD_F32 + MUL_F32 + TRANS_F32 + 2 FMA_F32) x mean active lanes per VALU instruction
+                               (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU / 4 ... approximated by thread-cycles per instruction, <= 64)
+bench.py scales them by its own launch rate: valu_issue_frac = busy cycles per second / (1024 SIMDs x clock), fp32_flop_frac = flops per
+second / 157.3e12.  Usage: tools/make_valu_json.py <pmc_outdir> <n_agents> <envs_per_launch> <out.json> [scenario] [source-note]"""
+import csv, glob, json, os, sys, collections
+
+out_dir, n_agents, envs, dst = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+scenario = sys.argv[5] if len(sys.argv) > 5 else "cpm_entire"
+note = sys.argv[6] if len(sys.argv) > 6 else "profiles/valu_latest.json (rocprofv3 --pmc SQ passes, tools/pmc_passes.sh)"
+acc = collections.defaultdict(list)
+for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+    for row in csv.DictReader(open(f)):
+        if "sigmaenv_step_wave_kernel" in row.get("Kernel_Name", ""):
+            acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
+avg = {k: sum(v) / len(v) for k, v in acc.items()}
+valu = avg["SQ_INSTS_VALU"]
+lanes = min(64.0, avg["SQ_THREAD_CYCLES_VALU"] / max(1.0, avg["SQ_ACTIVE_INST_VALU"]) / 4.0 * 4.0) if "SQ_THREAD_CYCLES_VALU" in avg else 64.0
+lanes = min(64.0, avg.get("SQ_THREAD_CYCLES_VALU", 64.0 * valu) / valu)
+fp32 = avg.get("SQ_INSTS_VALU_ADD_F32", 0) + avg.get("SQ_INSTS_VALU_MUL_F32", 0) + avg.get("SQ_INSTS_VALU_TRANS_F32", 0) + 2 * avg.get("SQ_INSTS_VALU_FMA_F32", 0)
+rec = {
+    "kernel": "sigmaenv_step_wave_kernel", "scenario": scenario, "n_agents": n_agents, "envs_per_launch": envs, "source": note,
+    "n_simd": 1024, "clock_hz": 2.4e9,
+    "valu_insts_per_launch": valu, "salu_insts_per_launch": avg.get("SQ_INSTS_SALU"), "lds_insts_per_launch": avg.get("SQ_INSTS_LDS"),
+    "valu_busy_cycles_per_launch": 4.0 * avg["SQ_ACTIVE_INST_VALU"],
+    "mean_active_lanes_per_valu_inst": lanes,
+    "fp32_arith_insts_per_launch": avg.get("SQ_INSTS_VALU_ADD_F32", 0) + avg.get("SQ_INSTS_VALU_MUL_F32", 0) + avg.get("SQ_INSTS_VALU_FMA_F32", 0) + avg.get("SQ_INSTS_VALU_TRANS_F32", 0),
+    "int32_insts_per_launch": avg.get("SQ_INSTS_VALU_INT32"), "int64_insts_per_launch": avg.get("SQ_INSTS_VALU_INT64"),
+    "f64_insts_per_launch": avg.get("SQ_INSTS_VALU_ADD_F64", 0) + avg.get("SQ_INSTS_VALU_MUL_F64", 0) + avg.get("SQ_INSTS_VALU_FMA_F64", 0) + avg.get("SQ_INSTS_VALU_TRANS_F64", 0),
+    "fp32_flops_per_launch": fp32 * lanes,
+    "wave_cycles_per_launch": 4.0 * avg.get("SQ_WAVE_CYCLES", 0), "wait_any_frac": avg.get("SQ_WAIT_ANY", 0) / max(1.0, avg.get("SQ_WAVE_CYCLES", 1)),
+    "lds_bank_conflict_frac": avg.get("SQ_LDS_BANK_CONFLICT", 0) / max(1.0, avg.get("SQ_LDS_IDX_ACTIVE", 1)),
+}
+json.dump(rec, open(dst, "w"), indent=1)
+print(json.dumps(rec))

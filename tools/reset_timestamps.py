@@ -3,6 +3,7 @@
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["SIGMAENV_TIMESTAMPS"] = "2"
+os.environ.setdefault("SIGMAENV_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sigmarl_amd", "csrc", "libsigmaenv_prof.so"))  # profile build (make -C sigmarl_amd/csrc prof)
 import numpy as np, torch
 from sigmarl_amd.env import SigmaEnv
 from sigmarl_amd.params import Parameters
