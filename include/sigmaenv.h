@@ -260,7 +260,7 @@ typedef struct sigmaenv_cbf_config {
   double circle_x[SIGMAENV_CBF_MAX_CIRCLES]; /* centres along the length axis (y = 0), :58-70 */
   double l_r, l_wb;         /* constants.py:634-635 (compute_dstate_2nd_time, cbf_qp.py:667-695) */
   float min_speed, min_steering; /* constants.py:637-640; the maxima, acceleration and steering-rate limits come from the env config */
-  float reserved2[2];
+  double steering_rate_max;       /* constants.py:645-646 in double (pi / 2; the minimum is its negative): the QP's box and the "clf" controller's clip are float64 in the reference */
   double k_clf_speed, k_clf_heading, ref_speed; /* "clf" nominal controller, cbf_qp.py:408-417 (defaults 1, 1, 1 m/s) */
   /* centralized CBF-QP (sigmaenv_cbf_qp), cbf_qp.py:409-433, 914-927 */
   double qp_w_acc, qp_w_steer;   /* nom_weight = diag(10, 1): tracking cost sum ((u - u_nom) @ nom_weight)^2 */

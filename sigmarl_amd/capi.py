@@ -69,7 +69,7 @@ class CbfConfig(C.Structure):
         ("dt_taylor", C.c_double), ("lambda_ttcbf", C.c_double), ("h_nom", C.c_double), ("fd_step", C.c_double),
         ("safety_buffer", C.c_double), ("circle_radius", C.c_double), ("circle_x", C.c_double * CBF_MAX_CIRCLES),
         ("l_r", C.c_double), ("l_wb", C.c_double), ("min_speed", C.c_float), ("min_steering", C.c_float),
-        ("reserved2", C.c_float * 2), ("k_clf_speed", C.c_double), ("k_clf_heading", C.c_double), ("ref_speed", C.c_double),
+        ("steering_rate_max", C.c_double), ("k_clf_speed", C.c_double), ("k_clf_heading", C.c_double), ("ref_speed", C.c_double),
         ("qp_w_acc", C.c_double), ("qp_w_steer", C.c_double), ("qp_w_lane", C.c_double), ("qp_w_pair", C.c_double), ("qp_w_clf", C.c_double),
         ("qp_w_lambda", C.c_double), ("lam_clf", C.c_double), ("is_apply_cbf_action", C.c_int32), ("reserved3", C.c_int32),
     ]

@@ -101,6 +101,7 @@ def make_cbf_config(p, n_circles: int | None = None):
         c.circle_x[i] = start + i * step  # :64-69
     c.l_r, c.l_wb = A["l_r"], A["l_wb"]
     c.min_speed, c.min_steering = A["min_speed"], A["min_steering"]
+    c.steering_rate_max = float(A["max_steering_rate"])
     c.nominal = {"rl": 0, "clf": 1}[p.nom_controller_type]
     c.k_clf_speed = float(getattr(p, "k_clf_speed", 1.0))  # cbf_qp.py:408-417 (read with getattr there as well)
     c.k_clf_heading = float(getattr(p, "k_clf_heading", 1.0))

@@ -487,6 +487,42 @@ def gen_cbf_functions():
         for (i, j, ci, cj), gval in m["pair_margin"].items():
             P[e, i, j, ci, cj] = gval
         c.update_qp(td)
+    # G10: the constraint data of the centralized QP on the same states -- the ADAPTIVE branches of
+    # ttcbf_lane_affine_coeffs / ttcbf_pair_affine_coeffs (cbf_qp.py:2337-2447: A, b0 and h kept apart, as update_centralized_cbf_qp
+    # :1103-1180 fills them into the cvxpy parameters), the nominal controls of both controller types (:1062-1090) and the CLF errors
+    # (:442-459) for reference points given as inputs.  Called on the very methods; nothing is solved (cvxpy / OSQP are absent).
+    g10_lane = np.zeros((B, N, C, 2, 4))
+    g10_pair = np.full((B, N, N, C, C, 6), np.nan)
+    g10_unom = np.zeros((B, N, 2))
+    g10_ref = (state[..., 0:2] + (torch.rand(B, N, 2, generator=g) - 0.5) * 1.2).to(torch.float32)
+    g10_clf = np.zeros((B, N, 4))  # e_head, e_speed, u1_nom, u2_nom of the "clf" controller
+    for e in range(B):
+        c = CBFQP(env=fake, env_idx=e)
+        c.time_pseudo_dis = 0
+        c.adaptive_lambda = True
+        d_safe = float(2.0 * c.circle_radius + c.safety_buffer)
+        states = [torch.cat([ag[i].state.pos[e], ag[i].state.rot[e], ag[i].state.speed[e], ag[i].state.steering[e]], dim=-1) for i in range(N)]
+        circles = [c.get_circle_centers(s_) for s_ in states]
+        kins = [c.linearized_center_kinematics_coeffs(s_) for s_ in states]
+        for i in range(N):
+            _, u_nom_i = c.rl_action_to_u(rl_actions=act[e, i].clone(), v=states[i][3], steering=states[i][4])
+            g10_unom[e, i] = u_nom_i.detach().cpu().numpy().reshape(2)
+            e_h, e_v = c._clf_errors_for_agent(states[i], g10_ref[e, i])
+            g10_clf[e, i] = (e_h, e_v, np.clip(c.k_clf_speed * e_v, c.a_min, c.a_max), np.clip(c.k_clf_heading * e_h, c.steering_rate_min, c.steering_rate_max))
+            for ci in range(C):
+                smL, gL, HL, smR, gR, HR = c.estimate_agent_2_lane_safety_margin(circles[i][ci][0:2], int(path_id[e, i]))
+                for side, (sm, gg, HH) in enumerate(((smL, gL, HL), (smR, gR, HR))):
+                    A_, b0_, h_ = c.ttcbf_lane_affine_coeffs(kins[i], ci, sm, gg, HH, c.dt_taylor, None)
+                    g10_lane[e, i, ci, side] = (A_[0, 0], A_[0, 1], b0_[0], h_[0])
+        for i in range(N - 1):
+            for j in range(i + 1, N):
+                for ci in range(C):
+                    for cj in range(C):
+                        delta = circles[i][ci][0:2] - circles[j][cj][0:2]
+                        Ai, Aj, b0_, h_ = c.ttcbf_pair_affine_coeffs(kins[i], kins[j], ci, cj, float(delta[0].item()), float(delta[1].item()),
+                                                                     d_safe * d_safe, c.dt_taylor, None)
+                        g10_pair[e, i, j, ci, cj] = (Ai[0, 0], Ai[0, 1], Aj[0, 0], Aj[0, 1], b0_[0], h_[0])
+    out["g10_lane"], out["g10_pair"], out["g10_unom"], out["g10_ref"], out["g10_clf"] = g10_lane, g10_pair, g10_unom, np_(g10_ref), g10_clf
     ri = sc.reward_info
     out["p2_state"], out["p2_path"], out["p2_act"] = np_(state), np_(path_id).astype(np.int32), np_(act)
     out["p2_lane_left"], out["p2_lane_right"], out["p2_pair"] = L, R, P

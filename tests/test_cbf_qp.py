@@ -4,6 +4,8 @@ cvxpy / OSQP are absent from the build container: the solution cannot be compare
 conditions of the original problem at the returned point, the closed-form elimination of (lambda, s) against a brute-force search, and
 agreement with an independent scipy optimiser on a small instance.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -38,8 +40,8 @@ def qp_case(make_env, N=16, B=None, nominal="rl", adaptive_lambda=False, Cc=3, s
 def check_kkt(env, u, con, unom, nominal, tol=1e-9):
     N, Cc = env.N, int(env.cbf_cfg.n_circles)
     cfg, cc = env.cfg, env.cbf_cfg
-    lo = np.tile([cfg.min_acc, cfg.min_steering_rate], N).astype(np.float64)
-    hi = np.tile([cfg.max_acc, cfg.max_steering_rate], N).astype(np.float64)
+    lo = np.tile([cfg.min_acc, -cc.steering_rate_max], N).astype(np.float64)
+    hi = np.tile([cfg.max_acc, cc.steering_rate_max], N).astype(np.float64)
     w = np.tile([cc.qp_w_acc, cc.qp_w_steer], N)
     st = env.get(0)  # BUF_STATE
     short = env.get(4)  # BUF_SHORT_TERM
@@ -119,8 +121,8 @@ def test_qp_matches_independent_scipy_optimiser_on_a_small_instance():
     check_kkt(env, u, con, unom, "rl")
     cfg = env.cfg
     n, m = 2 * N, con.shape[1]
-    lo = np.tile([cfg.min_acc, cfg.min_steering_rate], N).astype(np.float64)
-    hi = np.tile([cfg.max_acc, cfg.max_steering_rate], N).astype(np.float64)
+    lo = np.tile([cfg.min_acc, -cc.steering_rate_max], N).astype(np.float64)
+    hi = np.tile([cfg.max_acc, cc.steering_rate_max], N).astype(np.float64)
     w = np.tile([cc.qp_w_acc, cc.qp_w_steer], N)
     n_lane = N * Cc * 2
     n_changed = 0
@@ -150,3 +152,117 @@ def test_qp_matches_independent_scipy_optimiser_on_a_small_instance():
         n_changed += int(np.abs(u[b] - unom[b]).max() > 1e-6)
     assert n_changed >= 3
     env.close()
+
+
+def g10_reference_rows(z, B, N, Cc):
+    """The reference's QP constraint data of cbf_functions.npz (G10) in the oracle's row order: lane rows (i, circle, side), then pair rows
+    (i < j, ci, cj); columns (i, j, a0..a3, b0, h)."""
+    lane, pair = z["g10_lane"][:B, :N, :Cc], z["g10_pair"][:B, :N, :N, :Cc, :Cc]
+    rows = []
+    for i in range(N):
+        for ci in range(Cc):
+            for side in range(2):
+                r = np.zeros((B, 8))
+                r[:, 0], r[:, 1] = i, -1
+                r[:, 2:4], r[:, 6], r[:, 7] = lane[:, i, ci, side, 0:2], lane[:, i, ci, side, 2], lane[:, i, ci, side, 3]
+                rows.append(r)
+    for i in range(N - 1):
+        for j in range(i + 1, N):
+            for ci in range(Cc):
+                for cj in range(Cc):
+                    r = np.zeros((B, 8))
+                    r[:, 0], r[:, 1] = i, j
+                    r[:, 2:6], r[:, 6], r[:, 7] = pair[:, i, j, ci, cj, 0:4], pair[:, i, j, ci, cj, 4], pair[:, i, j, ci, cj, 5]
+                    rows.append(r)
+    return np.stack(rows, axis=1)
+
+
+def check_g10(con, unom, z, B, N, Cc):
+    """QP data against the reference (G10).  The pair rows and the nominal controls involve no float16: they agree to rounding (the circle
+    centres are float32 cos / sin of the yaw: torch's value and the correctly rounded one differ by an ulp in ~5 % of the cases, which moves a
+    row by ~1e-7 relative).  The lane rows contain the float16 pseudo-distance stencils: as for the margins (traj_replay.CBF_*), a one-ulp
+    centre difference can flip a float16 rounding, so they are held to the same outlier rule."""
+    import traj_replay as tr
+
+    want = g10_reference_rows(z, B, N, Cc)
+    n_lane = N * Cc * 2
+    assert np.array_equal(con[..., 0:2], want[..., 0:2])
+    scale = np.maximum(1.0, np.abs(want[..., 2:]))
+    err = np.abs(con[..., 2:] - want[..., 2:]) / scale
+    pair_err = err[:, n_lane:]
+    assert pair_err.max() <= 2e-6, pair_err.max()
+    assert (pair_err <= 1e-9).mean() >= 0.80, (pair_err <= 1e-9).mean()
+    assert np.abs(unom - z["g10_unom"][:B, :N]).max() <= 1e-5  # float32 arithmetic of rl_action_to_u
+    lane_err = err[:, :n_lane]
+    assert (lane_err > tr.CBF_TOL).mean() <= tr.CBF_OUTLIER_FRAC, (lane_err > tr.CBF_TOL).mean()
+    assert lane_err.max() <= 0.5  # (a flipped float16 stencil value moves a finite-difference Hessian entry by up to 0.25 / step^2 * 2^-11)
+    return dict(pair_max=float(pair_err.max()), pair_exact=float((pair_err <= 1e-9).mean()), lane_outliers=float((lane_err > tr.CBF_TOL).mean()),
+                lane_max=float(lane_err.max()))
+
+
+def test_qp_constraint_data_matches_the_reference_g10():
+    """lane / pair rows (A, b0, h of the adaptive branches, cbf_qp.py:2337-2447) and the nominal controls the oracle builds for
+    the centralized QP == what the reference's own methods return on the 48 x 16 set-state fixture."""
+    z, meta = _cbf_fixture()
+    env, act = qp_case(ob.OracleEnv, N=16, nominal="rl", adaptive_lambda=True)
+    _, _, _, con, unom = env.cbf_qp(act, with_data=True)
+    stats = check_g10(con, unom, z, meta["B"], 16, 3)
+    env.close()
+    assert stats["pair_exact"] > 0.8
+
+
+def test_clf_errors_and_nominal_controls_match_the_reference_g10():
+    """The "clf" nominal controller (cbf_qp.py:442-459, :1070-1090): heading / speed errors and the clipped P-controller controls for reference
+    points given as inputs (written into the short-term path buffer, whose third point the controller tracks)."""
+    z, meta = _cbf_fixture()
+    env, act = qp_case(ob.OracleEnv, N=16, nominal="clf", adaptive_lambda=True)
+    st_view = env.get(4, copy=False)  # BUF_SHORT_TERM [B, N, 3, 2]
+    st_view[:, :, 2, :] = z["g10_ref"]
+    _, _, _, con, unom = env.cbf_qp(act, with_data=True)
+    want = z["g10_clf"]
+    assert np.abs(unom - want[..., 2:4]).max() <= 1e-9
+    env.close()
+
+
+def compare_with_original_problem(env, u, con, unom, nominal, n_env):
+    """max |u - u*| over the first n_env envs, u* = the interior-point solution of the ORIGINAL problem (tests/qp_original.py)."""
+    from qp_original import build_original_qp, solve_original
+
+    N, Cc = env.N, int(env.cbf_cfg.n_circles)
+    cfg, cc = env.cfg, env.cbf_cfg
+    lo = np.tile([cfg.min_acc, -cc.steering_rate_max], N).astype(np.float64)
+    hi = np.tile([cfg.max_acc, cc.steering_rate_max], N).astype(np.float64)
+    w = np.tile([cc.qp_w_acc, cc.qp_w_steer], N)
+    st, short = env.get(0), env.get(4)
+    worst = 0.0
+    for b in range(n_env):
+        clf_e, clf_v = np.zeros(2 * N), np.zeros(2 * N)  # the CLF rows exist in both modes (zero data with the "rl" controller, :1095-1101)
+        if nominal == "clf":
+            desired = np.arctan2(short[b, :, 2, 1].astype(np.float64) - st[b, :, 1], short[b, :, 2, 0].astype(np.float64) - st[b, :, 0])
+            e_h = (desired - st[b, :, 2].astype(np.float64) + np.pi) % (2 * np.pi) - np.pi
+            e_v = cc.ref_speed - st[b, :, 3].astype(np.float64)
+            clf_e = np.stack([e_v, e_h], -1).reshape(-1)
+            clf_v = cc.lam_clf * 0.5 * clf_e ** 2
+        P, q, A, l, uu, n = build_original_qp(con[b], unom[b].reshape(-1), lo, hi, w, cc.qp_w_lane, cc.qp_w_pair, cc.qp_w_lambda, N * Cc * 2, clf_e, clf_v, cc.qp_w_clf)
+        assert P.shape[0] == 2 * N + 2 * len(con[b]) + 2 * N  # u, s, lambda, s_clf: 2416 at 16 agents x 3 circles (SURVEY.md section 8a row a16)
+        x, inf = solve_original(P, q, A, l, uu)
+        assert inf["primal"] <= 1e-8 and inf["dual"] <= 1e-6 and inf["gap"] <= 1e-12, (b, inf)
+        worst = max(worst, float(np.abs(x[:n] - u[b].reshape(-1)).max()))
+    return worst
+
+
+@pytest.mark.parametrize("nominal", ["rl", "clf"])
+def test_qp_matches_an_independent_solver_of_the_original_problem(nominal):
+    """The minimiser of the 32-unknown reduced problem == the solution of the ORIGINAL problem at full size (16 agents, 3 circles: 2416
+    variables, 1208 + 2416 rows in OSQP's standard form, lambda penalty of Parameters.adaptive_lambda) by the interior-point solver of
+    tests/qp_original.py, which shares no code or reformulation with the product's solver: controls within 1e-5 (OSQP's tolerance in the
+    reference) on all 48 envs of the set-state fixture."""
+    n_env = int(os.environ.get("SIGMA_QP_ORIGINAL_ENVS", "48"))
+    env, act = qp_case(ob.OracleEnv, N=16, B=n_env, nominal=nominal, adaptive_lambda=True)
+    safe, u, info, con, unom = env.cbf_qp(act, with_data=True)
+    assert con.shape[1] == 1176 and 2 * 16 + 2 * 1176 + 2 * 16 == 2416
+    worst = compare_with_original_problem(env, u, con, unom, nominal, n_env)
+    n_changed = int((np.abs(u - unom).max(axis=(1, 2)) > 1e-6).sum())
+    env.close()
+    assert worst <= 1e-5, worst
+    assert n_changed >= n_env // 4

@@ -392,3 +392,65 @@ def test_cbf_qp_is_bitwise_repeatable():
         outs.append((u.clone(), safe.clone()))
     assert all(torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]) for o in outs[1:])
     dev.close()
+
+
+def test_cbf_qp_hip_minimiser_vs_independent_solver_of_the_original_problem():
+    """u of the HIP kernel == the interior-point solution of the ORIGINAL 2416-variable problem (tests/qp_original.py) within 1e-5 on the 48
+    envs of the set-state fixture (16 agents, 3 circles, lambda penalty)."""
+    from test_cbf_qp import compare_with_original_problem, qp_case
+
+    dev, act = qp_case(_hip_env, N=16, B=48, nominal="rl", adaptive_lambda=True)
+    ora, _ = qp_case(ob.OracleEnv, N=16, B=48, nominal="rl", adaptive_lambda=True)
+    _, u_d, info_d = dev.cbf_qp(act)
+    _, _, _, con, unom = ora.cbf_qp(act, with_data=True)
+    assert info_d[:, 1].all()
+    worst = compare_with_original_problem(ora, u_d, con, unom, "rl", 48)
+    dev.close()
+    ora.close()
+    assert worst <= 1e-5, worst
+
+
+def test_cbf_qp_full_size_4096_envs():
+    """BASELINE config 5 at its size (16 agents x 4096 envs): every env's QP converges, the minimisers of the first and the last 96 envs equal
+    the oracle's on the same states, and they pass the KKT check of the original problem."""
+    import torch
+    from sigmarl_amd.env import SigmaEnv
+    from test_cbf_qp import check_kkt
+
+    B, N, S = 4096, 16, 96
+    p = Parameters(n_agents=N, scenario_type="cpm_entire", rew_method="cbf", dt=0.05, is_solve_qp=True, is_using_cbf_training=True,
+                   is_apply_mask=False, is_obs_noise=False, is_use_mtv_distance=False, adaptive_lambda=True)
+    env = SigmaEnv(p, n_envs=B, device="cuda:0")
+    env.reset_random(seed=12)
+    env.cbf_attach()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    safe = torch.empty((B, N, 2), device="cuda")
+    u = torch.empty((B, N, 2), dtype=torch.float64, device="cuda")
+    info = torch.empty((B, 2), dtype=torch.int32, device="cuda")
+    for t in range(4):
+        act = torch.stack([torch.rand(B, N, generator=g, device="cuda") * 1.4 - 0.2, torch.rand(B, N, generator=g, device="cuda") * 1.0 - 0.5], -1).contiguous()
+        env.cbf_qp(act, safe, u, info)
+        if t < 3:
+            env.step_autoreset(act, seed=3)
+    env.sync()
+    assert bool(info[:, 1].all()), int((info[:, 1] == 0).sum())
+    assert int(info[:, 0].max()) <= 60
+    assert bool(torch.isfinite(u).all()) and bool(torch.isfinite(safe).all())
+    mp = env.map
+    seg_l, seg_r = cbf.load_segment_tables(mp)
+    n_changed = 0
+    for lo in (0, B - S):
+        ora = ob.OracleEnv(make_config(p, mp, S), mp)
+        ora.cbf_attach(cbf.make_cbf_config(p), seg_l, seg_r)
+        st = env.buffer(capi.BUF_STATE)[lo:lo + S].cpu().numpy()
+        pa = env.buffer(capi.BUF_PATH)[lo:lo + S].cpu().numpy()
+        ora.reset(np.repeat(np.arange(S), N), np.tile(np.arange(N), S), pa.reshape(-1, 4), st.reshape(-1, 8), 1)
+        safe_o, u_o, info_o, con, unom = ora.cbf_qp(act[lo:lo + S].cpu().numpy(), with_data=True)
+        u_d = u[lo:lo + S].cpu().numpy()
+        assert np.abs(u_d - u_o).max() <= 1e-7, (lo, np.abs(u_d - u_o).max())
+        assert np.abs(safe[lo:lo + S].cpu().numpy() - safe_o).max() <= 1e-6
+        check_kkt(ora, u_d, con, unom, "rl", tol=1e-8)
+        n_changed += int((np.abs(u_d - unom).max(axis=(1, 2)) > 1e-6).sum())
+        ora.close()
+    assert n_changed >= 10
+    env.close()
