@@ -235,3 +235,21 @@ def test_two_rank_sharding_gloo(tmp_path):
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                           "--master-port", "29517", str(script), ROOT], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "SHARD_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+@pytest.mark.parametrize("tag,testing", [("train", False), ("test", True)])
+def test_device_sampler_specification_matches_the_reference_distribution(tag, testing):
+    """The counter-based reset sampler (oracle side of the specification the HIP kernels share) draws (path, point, speed) with the marginals of
+    the reference's torch-RNG rejection sampler (world_state_rt_sim.py:215-311), in training and in testing mode (range growing with the tries),
+    and never violates the minimum spacing: two-sample chi-square tests against tests/golden/reset_distribution.npz."""
+    import oracle_binding as ob
+    import reset_distribution_check as rdc
+    from sigmarl_amd.maps import load_map
+    from sigmarl_amd.params import Parameters, make_config
+
+    mp = load_map("cpm_entire")
+    p = Parameters(n_agents=16, scenario_type="cpm_entire", is_apply_mask=False, is_obs_noise=False, is_testing_mode=testing)
+    env = ob.OracleEnv(make_config(p, mp, 512), mp)
+    got = rdc.sample_histograms(env, mp, rounds=4)
+    env.close()
+    rdc.compare(tag, got)

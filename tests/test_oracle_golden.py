@@ -1,8 +1,8 @@
 """Pins the CPU oracle against golden vectors produced by RUNNING the reference (tests/golden/gen/gen_golden.py).
 
-Bar: bit-exact for masks and indices, <= 1e-5 abs for fp32 states / rewards / observations.  The mtv distance is the
-one documented exception (5e-5): the reference's formulation projects world coordinates (~4.5 m) onto axes normalised from
-0.107 m edges, which amplifies the 1-ulp difference between SLEEF and correctly-rounded trig ~40x ("Tolerances").
+Bar: bit-exact for masks and indices, <= 1e-5 abs for fp32 states / rewards / observations -- the mtv distance included (observed
+worst case 4.3e-6): the reference's formulation projects world coordinates (~4.5 m) onto axes normalised from
+0.107 m edges, which amplifies the 1-ulp difference between torch's and the correctly rounded trig ~40x ("Tolerances").
 """
 import ctypes as C
 import os
@@ -19,7 +19,7 @@ from sigmarl_amd.maps import load_map
 from sigmarl_amd.params import Parameters, make_config
 
 FTOL = 1e-5
-MTV_TOL = 5e-5
+MTV_TOL = 1e-5
 
 
 @pytest.fixture(scope="module")
