@@ -535,6 +535,98 @@ def gen_cbf_functions():
           "rew nonzero", (out["p2_rew"] != 0).sum(axis=(1, 2)), "1000s", int((out["p1_left_f16"] == np.float16(1000).view(np.uint16)).sum()))
 
 
+def gen_adversarial():
+    """Adversarial inputs for the collision PRUNING of the HIP path: the strict-sign interX predicate
+    (helper_scenario.py:1148-1229) evaluated by the reference on configurations where a pruned far segment / far rectangle could matter --
+    rectangle edges exactly collinear with long straight boundary stretches (so that far boundary segments are collinear with an edge),
+    offsets of a few ulps around touching, and vehicles in line whose side edges are collinear at centre distances around and far beyond
+    the circumcircle sum.  Stored: poses, the reference's vertices and its hit flags (rectangle x left / right boundary of the path,
+    rectangle x rectangle).  The oracle (full scan) is held to these flags, the HIP kernels to the oracle on the same poses."""
+    from sigmarl.constants import AGENTS
+    from sigmarl.helper_scenario import get_rectangle_vertices, interX
+
+    p = Parameters(n_agents=2, scenario_type="cpm_entire", is_obs_noise=False, is_apply_mask=False, num_vmas_envs=1, is_use_mtv_distance=False)
+    env = refshim.RefEnv(p, 1)
+    ws = env.scenario.world_state
+    paths = env.scenario.map.parser.reference_paths
+    ext = ws.ref_paths_map_related.point_extended_all
+    W, L = AGENTS["width"], AGENTS["length"]
+    g = torch.Generator().manual_seed(41)
+    poses, pids, verts, hl, hr = [], [], [], [], []
+    for pid in range(len(paths)):
+        rp = paths[pid]
+        ws._reset_agent_related_ref_path(0, 0, rp, pid, ext)
+        ra = ws.ref_paths_agent_related
+        lb, rb = ra.left_boundary[0, 0].clone(), ra.right_boundary[0, 0].clone()
+        nl, nr = int(ra.n_points_left_b[0, 0]), int(ra.n_points_right_b[0, 0])
+        for side, (poly, n) in enumerate(((lb, nl), (rb, nr))):
+            d = poly[1:n] - poly[: n - 1]
+            for ax in (0, 1):  # stretches where one coordinate is EXACTLY constant
+                same = (d[:, ax] == 0).numpy()
+                k = 0
+                while k < len(same):
+                    if not same[k]:
+                        k += 1
+                        continue
+                    k0 = k
+                    while k < len(same) and same[k]:
+                        k += 1
+                    if k - k0 < 8:
+                        continue
+                    c0 = float(poly[k0, ax])              # the constant coordinate of the stretch
+                    other = 1 - ax
+                    lo_, hi_ = float(poly[k0, other]), float(poly[k, other])
+                    yaw = 0.0 if ax == 1 else math.pi / 2  # vehicle along the stretch
+                    for frac in (0.15, 0.5, 0.85):
+                        along = lo_ + frac * (hi_ - lo_)
+                        for sgn in (-1.0, 1.0):
+                            for off in (0.0, 1e-7, -1e-7, 6e-8, -6e-8, 1e-6, -1e-6, 1e-4, -1e-4, 3e-3):
+                                for dyaw in (0.0, 1e-7, -1e-7, 1e-4):
+                                    pos = [0.0, 0.0]
+                                    pos[ax] = np.float32(c0 + sgn * (W / 2) + off)
+                                    pos[other] = np.float32(along)
+                                    poses.append([pos[0], pos[1], np.float32(yaw + dyaw)])
+                                    pids.append(pid)
+                    break
+                else:
+                    continue
+            if len(poses) > 6000:
+                break
+        if len(poses) > 6000:
+            break
+    poses = torch.tensor(np.asarray(poses, np.float32))
+    pids = np.asarray(pids, np.int32)
+    vv = get_rectangle_vertices(poses[:, 0:2], poses[:, 2:3], W, L, True)
+    hits_l, hits_r = np.zeros(len(pids), bool), np.zeros(len(pids), bool)
+    for pid in np.unique(pids):
+        ws._reset_agent_related_ref_path(0, 0, paths[pid], int(pid), ext)
+        ra = ws.ref_paths_agent_related
+        m = torch.from_numpy(pids == pid)
+        M = int(m.sum())
+        hits_l[m.numpy()] = np_(interX(vv[m], ra.left_boundary[0, 0].unsqueeze(0).expand(M, -1, -1), False))
+        hits_r[m.numpy()] = np_(interX(vv[m], ra.right_boundary[0, 0].unsqueeze(0).expand(M, -1, -1), False))
+    out = dict(b_pose=np_(poses), b_path=pids, b_vertices=np_(vv), b_hit_left=hits_l, b_hit_right=hits_r)
+    # vehicles in line: collinear side edges, centre distances around 2 R (R = circumradius) and far beyond; small lateral / yaw perturbations
+    R2 = 2.0 * math.sqrt((L / 2) ** 2 + (W / 2) ** 2)
+    pa, pb = [], []
+    for base_yaw in (0.0, math.pi / 2, 0.7):
+        for dist in (0.2, 0.2200001, 0.22, 0.2199999, 0.23, R2 - 1e-6, R2, R2 + 1e-6, R2 + 9e-5, R2 + 1.1e-4, 0.3, 0.6, 1.5, 3.0):
+            for lat in (0.0, 1e-7, -1e-7, 1e-6, W, W + 1e-7, W - 1e-7):
+                for dyaw in (0.0, 1e-7, 1e-4):
+                    c, s_ = math.cos(base_yaw), math.sin(base_yaw)
+                    a = [2.0, 2.0, base_yaw]
+                    b = [2.0 + dist * c - lat * s_, 2.0 + dist * s_ + lat * c, base_yaw + dyaw]
+                    pa.append(a); pb.append(b)
+    pa, pb = torch.tensor(np.asarray(pa, np.float32)), torch.tensor(np.asarray(pb, np.float32))
+    va = get_rectangle_vertices(pa[:, 0:2], pa[:, 2:3], W, L, True)
+    vb = get_rectangle_vertices(pb[:, 0:2], pb[:, 2:3], W, L, True)
+    out.update(r_pose_a=np_(pa), r_pose_b=np_(pb), r_vertices_a=np_(va), r_vertices_b=np_(vb), r_hit=np_(interX(va, vb, False)))
+    path = os.path.join(OUT, "adversarial.npz")
+    np.savez_compressed(path, **out)
+    print("adversarial", f"{os.path.getsize(path)/1e6:.2f} MB", "boundary cases", len(pids), "paths", len(np.unique(pids)), "hits L/R", int(hits_l.sum()), int(hits_r.sum()),
+          "pairs", len(pa), "pair hits", int(out["r_hit"].sum()))
+
+
 TRAJS = {
     "cpm16_c2c": dict(T=32, B=4, seed=11, mode_pattern=[1, 0, 1, 1], n_agents=16, scenario_type="cpm_entire", dt=0.05,
                       is_use_mtv_distance=False, rew_method="distance"),
@@ -576,11 +668,13 @@ TRAJS = {
 }
 
 if __name__ == "__main__":
-    names = sys.argv[1:] or (["functions", "cbf_functions"] + list(TRAJS))
+    names = sys.argv[1:] or (["functions", "cbf_functions", "adversarial"] + list(TRAJS))
     for nme in names:
         if nme == "functions":
             gen_functions()
         elif nme == "cbf_functions":
             gen_cbf_functions()
+        elif nme == "adversarial":
+            gen_adversarial()
         else:
             run_traj(nme, **TRAJS[nme])

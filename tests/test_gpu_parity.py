@@ -4,6 +4,8 @@
 Bar: masks / indices / counters bit-exact; fp32 states, rewards, observations within 1e-5 abs (mtv distance included, against
 the reference goldens only, see test_oracle_golden.py; HIP vs oracle share the arithmetic contract and are held to 1e-5).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -319,6 +321,68 @@ def test_device_sampler_matches_the_reference_distribution(tag, testing):
     got = rdc.sample_histograms(dev, mp, rounds=2)
     dev.close()
     rdc.compare(tag, got)
+
+
+def test_adversarial_collinear_configurations_pruned_scan_equals_full_scan():
+    """The collision PRUNING under the configurations built to break it (tests/golden/adversarial.npz, generated by the reference): rectangle
+    edges exactly collinear with long straight boundary stretches and a few ulps around touching; vehicles in line with collinear side edges
+    at centre distances around and far beyond the circumcircle sum.  Every pose becomes an env at rest (zero action: the pose is kept bit for
+    bit); the HIP kernels (pruned boundary scan, circumcircle pre-test of pairs) must give the oracle's flags (full scan), and -- wherever
+    the vertices computed from the pose equal the reference's bit for bit -- the reference's."""
+    z = np.load(os.path.join(tr.GOLDEN_DIR, "adversarial.npz"))
+    mp = load_map("cpm_entire")
+    first = mp.list_first[0]
+    p = Parameters(n_agents=2, scenario_type="cpm_entire", is_use_mtv_distance=False, rew_method="distance", is_apply_mask=False, is_obs_noise=False, dt=0.05)
+    # (1) rectangle x boundaries: agent 0 carries the adversarial pose, agent 1 is parked elsewhere on the same path
+    pose, pid = z["b_pose"], z["b_path"].astype(np.int64)
+    B = len(pose)
+    cfg = make_config(p, mp, B)
+    dev, ora = _hip_env(cfg, mp), ob.OracleEnv(cfg, mp)
+    st8 = np.zeros((B, 2, 8), np.float32)
+    st8[:, 0, 0:3] = pose
+    gp = first + pid
+    far = np.minimum(mp.n_center[gp] - 5, 60)
+    st8[:, 1, 0:2] = mp.center[gp, far]
+    st8[:, 1, 2] = mp.yaw[gp, np.minimum(far, mp.n_yaw[gp] - 1)]
+    ids = np.zeros((B, 2, 4), np.int32)
+    ids[..., 0] = gp[:, None]
+    ids[..., 2] = pid[:, None]
+    ids[:, 1, 3] = far
+    ei, ai = np.repeat(np.arange(B, dtype=np.int32), 2), np.tile(np.arange(2, dtype=np.int32), B)
+    act = np.zeros((B, 2, 2), np.float32)
+    for e in (dev, ora):
+        e.reset(ei, ai, ids.reshape(-1, 4), st8.reshape(-1, 8), 1)
+        e.step(act)
+    _compare_all(dev, ora, "adversarial boundary poses")
+    assert np.array_equal(ora.get(capi.BUF_STATE)[:, 0, 0:3], pose)  # at rest the step keeps the pose bit for bit
+    same_v = (ora.get(capi.BUF_VERTICES)[:, 0].view(np.uint32) == z["b_vertices"].view(np.uint32)).all(axis=(1, 2))
+    want = z["b_hit_left"] | z["b_hit_right"]
+    got = ora.get(capi.BUF_COL_FLAGS)[:, 0, 0].astype(bool)
+    assert same_v.sum() > 0.8 * B and np.array_equal(got[same_v], want[same_v])
+    assert np.array_equal(dev.get(capi.BUF_COL_FLAGS)[:, 0, 0].astype(bool)[same_v], want[same_v])
+    dev.close()
+    ora.close()
+    # (2) rectangle x rectangle: the two vehicles of an env are the pair
+    pa, pb = z["r_pose_a"], z["r_pose_b"]
+    B = len(pa)
+    cfg = make_config(p, mp, B)
+    dev, ora = _hip_env(cfg, mp), ob.OracleEnv(cfg, mp)
+    st8 = np.zeros((B, 2, 8), np.float32)
+    st8[:, 0, 0:3], st8[:, 1, 0:3] = pa, pb
+    ids = np.zeros((B, 2, 4), np.int32)
+    ids[..., 0] = first
+    ei, ai = np.repeat(np.arange(B, dtype=np.int32), 2), np.tile(np.arange(2, dtype=np.int32), B)
+    act = np.zeros((B, 2, 2), np.float32)
+    for e in (dev, ora):
+        e.reset(ei, ai, ids.reshape(-1, 4), st8.reshape(-1, 8), 1)
+        e.step(act)
+    _compare_all(dev, ora, "adversarial pairs")
+    vo = ora.get(capi.BUF_VERTICES)
+    same_v = (vo[:, 0].view(np.uint32) == z["r_vertices_a"].view(np.uint32)).all(axis=(1, 2)) & (vo[:, 1].view(np.uint32) == z["r_vertices_b"].view(np.uint32)).all(axis=(1, 2))
+    got_o, got_d = ora.get(capi.BUF_COL_AGENTS)[:, 0, 1].astype(bool), dev.get(capi.BUF_COL_AGENTS)[:, 0, 1].astype(bool)
+    assert same_v.sum() > 0.7 * B and np.array_equal(got_o[same_v], z["r_hit"][same_v]) and np.array_equal(got_d[same_v], z["r_hit"][same_v])
+    dev.close()
+    ora.close()
 
 
 def test_rollout_slab_is_written_by_the_step_kernel():

@@ -232,3 +232,30 @@ def test_trajectory_fixtures_cover_events():
         for k in tot:
             tot[k] += meta[k]
     assert tot["n_done"] > 50 and tot["n_col_lane"] > 50 and tot["n_col_agents"] > 10 and tot["n_exit"] >= 1
+
+
+def test_adversarial_collinear_configurations_match_the_reference():
+    """tests/golden/adversarial.npz: rectangle edges exactly collinear with long straight boundary stretches (far boundary segments collinear with
+    an edge), offsets of a few ulps around touching, vehicles in line with collinear side edges at centre distances around and beyond the
+    circumcircle sum -- the configurations in which a PRUNED far segment / far rectangle could change the strict-sign interX predicate
+    (helper_scenario.py:1148-1229).  The oracle scans everything: with the reference's own vertices its flags must equal the reference's."""
+    z = np.load(os.path.join(tr.GOLDEN_DIR, "adversarial.npz"))
+    lib = ob.load_oracle()
+    mp = load_map("cpm_entire")
+    env = ob.OracleEnv(_cfg(), mp)
+    _, left, right = env.path_table()
+    env.close()
+    first = mp.list_first[0]
+    for pid in np.unique(z["b_path"]):
+        sel = z["b_path"] == pid
+        v = np.ascontiguousarray(z["b_vertices"][sel], np.float32)
+        for poly, want in ((left[first + pid], z["b_hit_left"][sel]), (right[first + pid], z["b_hit_right"][sel])):
+            hit = np.zeros(len(v), np.uint8)
+            poly = np.ascontiguousarray(poly, np.float32)
+            lib.fn_interx(len(v), ob.ptr(v), 5, 10, ob.ptr(poly), len(poly), 0, ob.ptr(hit))
+            assert np.array_equal(hit.astype(bool), want), (int(pid), int((hit.astype(bool) != want).sum()))
+    va, vb = np.ascontiguousarray(z["r_vertices_a"], np.float32), np.ascontiguousarray(z["r_vertices_b"], np.float32)
+    hit = np.zeros(len(va), np.uint8)
+    lib.fn_interx(len(va), ob.ptr(va), 5, 10, ob.ptr(vb), 5, 10, ob.ptr(hit))
+    assert np.array_equal(hit.astype(bool), z["r_hit"])
+    assert z["b_hit_left"].sum() > 500 and (~z["b_hit_left"]).sum() > 500 and z["r_hit"].sum() > 50
