@@ -667,14 +667,46 @@ TRAJS = {
                             is_use_mtv_distance=False, rew_method="cbf", is_using_cbf_training=True, is_solve_qp=False, nom_controller_type="clf"),
 }
 
+def content_hash(path):
+    """sha256 over the fixture's CONTENT (sorted keys, dtype, shape, raw bytes): independent of the zip container's timestamps."""
+    import hashlib
+
+    z = np.load(path)
+    h = hashlib.sha256()
+    for k in sorted(z.files):
+        a = np.ascontiguousarray(z[k])
+        h.update(k.encode()); h.update(str(a.dtype).encode()); h.update(str(a.shape).encode()); h.update(a.tobytes())
+    return h.hexdigest()
+
+
+def generate_one(nme):
+    if nme == "functions":
+        gen_functions()
+    elif nme == "cbf_functions":
+        gen_cbf_functions()
+    elif nme == "adversarial":
+        gen_adversarial()
+    else:
+        run_traj(nme, **TRAJS[nme])
+
+
 if __name__ == "__main__":
+    # THE recipe for the committed fixtures:   python tests/golden/gen/gen_golden.py
+    # Every fixture is generated in its OWN interpreter (fresh RNG / module state, PYTHONHASHSEED=0), so the bytes do not depend on which
+    # fixtures were generated before it; then tests/golden/MANIFEST.json (content hashes) is rewritten.  `--one <name>` is the worker form.
+    import subprocess
+
+    if len(sys.argv) >= 3 and sys.argv[1] == "--one":
+        generate_one(sys.argv[2])
+        sys.exit(0)
     names = sys.argv[1:] or (["functions", "cbf_functions", "adversarial"] + list(TRAJS))
+    envv = dict(os.environ, PYTHONHASHSEED="0")
     for nme in names:
-        if nme == "functions":
-            gen_functions()
-        elif nme == "cbf_functions":
-            gen_cbf_functions()
-        elif nme == "adversarial":
-            gen_adversarial()
-        else:
-            run_traj(nme, **TRAJS[nme])
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), "--one", nme], env=envv)
+    man_path = os.path.join(OUT, "MANIFEST.json")
+    man = json.load(open(man_path)) if os.path.exists(man_path) else {}
+    for f in sorted(os.listdir(OUT)):
+        if f.endswith(".npz"):
+            man[f] = content_hash(os.path.join(OUT, f))
+    json.dump(man, open(man_path, "w"), indent=1, sort_keys=True)
+    print("manifest:", man_path, len(man), "fixtures")

@@ -259,3 +259,20 @@ def test_adversarial_collinear_configurations_match_the_reference():
     lib.fn_interx(len(va), ob.ptr(va), 5, 10, ob.ptr(vb), 5, 10, ob.ptr(hit))
     assert np.array_equal(hit.astype(bool), z["r_hit"])
     assert z["b_hit_left"].sum() > 500 and (~z["b_hit_left"]).sum() > 500 and z["r_hit"].sum() > 50
+
+
+def test_fixtures_match_the_committed_manifest():
+    """tests/golden/MANIFEST.json (written by the ONE generation command, `python tests/golden/gen/gen_golden.py`, which runs every fixture in
+    its own interpreter) holds a content hash of every fixture: the committed bytes are the recipe's output, not an earlier revision's."""
+    import hashlib
+
+    man = json.load(open(os.path.join(tr.GOLDEN_DIR, "MANIFEST.json")))
+    names = sorted(f for f in os.listdir(tr.GOLDEN_DIR) if f.endswith(".npz"))
+    assert sorted(man) == names
+    for f in names:
+        z = np.load(os.path.join(tr.GOLDEN_DIR, f))
+        h = hashlib.sha256()
+        for k in sorted(z.files):
+            a = np.ascontiguousarray(z[k])
+            h.update(k.encode()); h.update(str(a.dtype).encode()); h.update(str(a.shape).encode()); h.update(a.tobytes())
+        assert h.hexdigest() == man[f], f
