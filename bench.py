@@ -206,7 +206,7 @@ class GpuRun:
             mlp = make_mlp(self.D)
             for k, e in enumerate(self.envs):
                 with torch.cuda.stream(self.streams[k]):
-                    self.actors.append(Actor(mlp, low=[-1.0, -0.6109], high=[1.0, 0.6109]))  # -/+ (max_speed, max_steering)
+                    self.actors.append(Actor(mlp, low=[-1.0, -0.6109], high=[1.0, 0.6109], precision=args.policy_precision))  # -/+ (max_speed, max_steering)
                     self.act_bufs.append(torch.zeros((Bs, N, 2), dtype=torch.float32, device=device))
         self.safe_bufs = [torch.zeros((Bs, N, 2), dtype=torch.float32, device=device) for _ in range(S)] if args.cbf_qp else []
         self.W = N * (self.D + 1) + 1
@@ -341,6 +341,8 @@ def main():
                     "(envs are independent: same total work per step; the tail of one shard's launch -- its reset-heavy wavefronts -- overlaps the other's)")
     ap.add_argument("--policy", action="store_true", help="widening (SURVEY 8f-3): the actor MLP runs on the device before every step "
                     "(sigmaenv_actor_forward) instead of replaying precomputed actions; reported in config.policy")
+    ap.add_argument("--policy-precision", choices=["fp32", "bf16"], default="fp32", help="--policy: the reference's fp32 arithmetic (exact, MFMA f32) or the bf16 "
+                    "inference variant")
     ap.add_argument("--cbf", action="store_true", help="widening (SURVEY 8f-4): rew_method='cbf' with the QP-free CBF margin reward "
                     "(sigmaenv_cbf_rewards before every step); reported in config.cbf")
     ap.add_argument("--cbf-qp", action="store_true", help="BASELINE config 5: rew_method='cbf' with the centralized CBF-QP safety filter solved for "
@@ -437,7 +439,7 @@ def main():
                         + ("(one launch)" if run.fused else "(two launches)" if not args.no_reset else "(resets disabled)")
                         + ((" + rollout record" + ((" + " + run.gather.mode) if run.gather.collective else "")) if run.gather else ""),
             "n_agents": N, "envs_per_gpu": B, "envs_total": B * world, "distance": args.distance, "scenario": args.scenario, "env_shards_per_gpu": S,
-            "policy": ("actor MLP 32-256-256-256-4 on device before every step" if args.policy
+            "policy": (f"actor MLP 32-256-256-256-4 ({args.policy_precision}) on device before every step" if args.policy
                        else "none in the timed region (precomputed actions resident in HBM)"),
             **({"cbf": ("centralized CBF-QP safety filter of every env (sigmaenv_cbf_qp: 2 N controls, lane + pair constraints, projected "
                         "Newton in float64) solved before every step; the step penalises the deviation from the safe action" if args.cbf_qp else

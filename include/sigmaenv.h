@@ -230,6 +230,21 @@ void sigmaenv_actor_destroy(sigmaenv_actor_t* a);
 int sigmaenv_actor_forward(sigmaenv_t* h, sigmaenv_actor_t* a, const float* obs, float* actions, float* log_prob, float* loc_scale, uint64_t seed,
                            uint64_t counter, int32_t deterministic);
 
+/* ---- the reference's networks in the reference's precision ------------------------------------------------------------------------
+ * Exact-fp32 shared-parameter MLP on the matrix cores (v_mfma_f32_32x32x2_f32: an fp32 fma chain), Tanh between the layers, hidden width 256:
+ *   actor   sigmarl/modules/decision_making_module.py:34-52   dims = {obs_dim, 256, 256, 256, 4}, one row per agent
+ *   critic  sigmarl/modules/optimization_module.py:16-32      dims = {n_agents * obs_dim, 256, 256, 256, 1}, one row per env (MAPPO, centralised:
+ *           the observations of all agents of the env concatenated -- exactly a row of SIGMAENV_BUF_OBS viewed as [B, N * D]; the one output
+ *           is the state value of every agent of the env)
+ * weights[l]: torch.nn.Linear layout [dims[l+1], dims[l]] row-major fp32 (host pointers), biases[l]: [dims[l+1]].
+ * sigmaenv_actor_forward_f32 = this MLP + the distribution head of sigmaenv_actor_forward (same outputs); scratch: device f32 [B * N * 4]. */
+typedef struct sigmaenv_mlp32 sigmaenv_mlp32_t;
+int sigmaenv_mlp32_create(int32_t n_layers, const int32_t* dims, const float* const* weights, const float* const* biases, sigmaenv_mlp32_t** out);
+void sigmaenv_mlp32_destroy(sigmaenv_mlp32_t* m);
+int sigmaenv_mlp32_forward(sigmaenv_t* h, sigmaenv_mlp32_t* m, const float* in, int32_t rows, float* out);
+int sigmaenv_actor_forward_f32(sigmaenv_t* h, sigmaenv_mlp32_t* m, const float* obs, float* scratch, const float* low, const float* high, float* actions,
+                               float* log_prob, float* loc_scale, uint64_t seed, uint64_t counter, int32_t deterministic);
+
 /* n_steps x (sigmaenv_actor_forward; sigmaenv_step_autoreset) enqueued back to back (SyncDataCollectorCustom.rollout,
  * sigmarl/helper_training.py:687-788, without its per-step Python): actions_buf device f32 [B,N,2] scratch; optional records:
  * slab_base device f32 [n_steps, B, N*(D+1)+1], logp_base device f32 [n_steps, B, N], actions_rec device f32 [n_steps, B, N, 2].

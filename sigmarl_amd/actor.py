@@ -2,8 +2,12 @@
 
 ``Actor`` wraps ``sigmaenv_actor_*`` / ``sigmaenv_rollout`` of the C-ABI: the actor network of
 ``sigmarl/modules/decision_making_module.py:34-82`` (torchrl ``MultiAgentMLP(depth=3, num_cells=256, activation=Tanh, share_params=True)``
-+ ``NormalParamExtractor`` + ``TanhNormal``) as one MFMA kernel (bf16 weights / activations, fp32 accumulation).  Weights come from any
-``torch.nn.Sequential`` of four ``Linear`` layers (the parameter layout torchrl's shared-parameter MLP has), or from plain arrays.
++ ``NormalParamExtractor`` + ``TanhNormal``).  Two precisions:
+  ``precision="fp32"`` (default)  the reference's own arithmetic: exact-fp32 MLP on the matrix cores (``sigmaenv_actor_forward_f32``)
+  ``precision="bf16"``            the fast inference variant: bf16 weights / activations, fp32 accumulation, one fused MFMA kernel; also what
+                                  ``sigmaenv_rollout`` (policy + step without the host in the loop) runs
+``Critic`` is the MAPPO critic of ``sigmarl/modules/optimization_module.py:16-32`` (centralised, shared parameters) in exact fp32.
+Weights come from any ``torch.nn.Sequential`` of four ``Linear`` layers (the parameter layout torchrl's shared-parameter MLP has).
 """
 from __future__ import annotations
 
@@ -22,9 +26,71 @@ def make_mlp(obs_dim: int = 32, hidden: int = 256, n_out: int = 4) -> torch.nn.S
                                torch.nn.Linear(hidden, hidden), torch.nn.Tanh(), torch.nn.Linear(hidden, n_out))
 
 
-class Actor:
-    def __init__(self, mlp: torch.nn.Module, low, high, lib: capi.Library | None = None):
+class Mlp32:
+    """``sigmaenv_mlp32_*``: a Tanh MLP with hidden width 256 in exact fp32 (matrix cores); ``forward(env, x[rows, in_dim]) -> [rows, out_dim]``."""
+
+    def __init__(self, mlp: torch.nn.Module, lib: capi.Library | None = None):
         self.lib = lib or capi.load_library()
+        lin = [m for m in mlp.modules() if isinstance(m, torch.nn.Linear)]
+        if not (2 <= len(lin) <= 4) or any(m.out_features != 256 for m in lin[:-1]) or lin[-1].out_features > 32:
+            raise ValueError("expected 2-4 Linear layers with hidden width 256 and at most 32 outputs")
+        self.in_dim, self.out_dim = lin[0].in_features, lin[-1].out_features
+        dims = np.asarray([self.in_dim] + [m.out_features for m in lin], np.int32)
+        ws = [np.ascontiguousarray(m.weight.detach().cpu().numpy(), np.float32) for m in lin]
+        bs = [np.ascontiguousarray(m.bias.detach().cpu().numpy(), np.float32) for m in lin]
+        self._keep = (dims, ws, bs)
+        PA = C.c_void_p * len(lin)
+        wp, bp = PA(*[w.ctypes.data for w in ws]), PA(*[b.ctypes.data for b in bs])
+        h = C.c_void_p()
+        rc = self.lib.mlp32_create(len(lin), dims.ctypes.data_as(C.c_void_p), wp, bp, C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"sigmaenv_mlp32_create failed with code {rc}")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mlp32_destroy(self.h)
+            self.h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def forward(self, env: SigmaEnv, x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] == self.in_dim):
+            raise TypeError(f"input must be a contiguous float32 CUDA tensor [..., {self.in_dim}]")
+        rows = x.numel() // self.in_dim
+        if out is None:
+            out = torch.empty((*x.shape[:-1], self.out_dim), dtype=torch.float32, device=x.device)
+        rc = self.lib.mlp32_forward(env.h, self.h, C.c_void_p(x.data_ptr()), rows, C.c_void_p(out.data_ptr()))
+        if rc != 0:
+            raise RuntimeError(f"sigmaenv_mlp32_forward failed with code {rc}: {env.lib.last_error(env.h).decode()}")
+        return out
+
+
+class Critic(Mlp32):
+    """The MAPPO critic (optimization_module.py:16-32): ``MultiAgentMLP(centralised=True, share_params=True, depth=3, num_cells=256, Tanh)`` --
+    one shared MLP on the concatenated observations of all agents of an env; its output is the state value of every agent of that env."""
+
+    def values(self, env: SigmaEnv, obs: torch.Tensor | None = None) -> torch.Tensor:
+        """[B, N, 1] state values of ``env.obs`` (or ``obs [B, N, D]``)."""
+        o = env.obs if obs is None else obs
+        if self.in_dim != env.N * env.D:
+            raise ValueError(f"critic input width {self.in_dim} != n_agents * obs_dim = {env.N * env.D}")
+        v = self.forward(env, o.reshape(env.B, env.N * env.D))
+        return v.reshape(env.B, 1, 1).expand(env.B, env.N, 1)
+
+
+class Actor:
+    def __init__(self, mlp: torch.nn.Module, low, high, lib: capi.Library | None = None, precision: str = "fp32"):
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' (the reference's arithmetic) or 'bf16' (fast inference variant)")
+        self.precision = precision
+        self.lib = lib or capi.load_library()
+        self._mlp32 = Mlp32(mlp, self.lib)  # the exact network (also kept by the bf16 variant: a caller may ask for either per call)
+        self._scratch4 = None
         lin = [m for m in mlp.modules() if isinstance(m, torch.nn.Linear)]
         if len(lin) != 4 or lin[1].in_features != 256 or lin[2].out_features != 256 or lin[3].out_features != 4:
             raise ValueError("expected Linear(D,256), Linear(256,256), Linear(256,256), Linear(256,4)")
@@ -44,6 +110,8 @@ class Actor:
         if getattr(self, "h", None):
             self.lib.actor_destroy(self.h)
             self.h = None
+        if getattr(self, "_mlp32", None) is not None:
+            self._mlp32.close()
 
     def __del__(self):  # pragma: no cover
         try:
@@ -52,9 +120,18 @@ class Actor:
             pass
 
     def forward(self, env: SigmaEnv, actions: torch.Tensor, log_prob: torch.Tensor | None = None, loc_scale: torch.Tensor | None = None,
-                obs: torch.Tensor | None = None, seed: int = 0, counter: int = 0, deterministic: bool = False):
+                obs: torch.Tensor | None = None, seed: int = 0, counter: int = 0, deterministic: bool = False, precision: str | None = None):
         """actions[B,N,2] := policy(env.obs or ``obs``); enqueued on the env's stream."""
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+        if (precision or self.precision) == "fp32":
+            if self._scratch4 is None or self._scratch4.shape[0] != env.B * env.N or self._scratch4.device != env.device:
+                self._scratch4 = torch.empty((env.B * env.N, 4), dtype=torch.float32, device=env.device)
+            lo, hi = self._keep[-2], self._keep[-1]
+            rc = self.lib.actor_forward_f32(env.h, self._mlp32.h, p(obs), p(self._scratch4), lo.ctypes.data_as(C.c_void_p), hi.ctypes.data_as(C.c_void_p),
+                                            p(actions), p(log_prob), p(loc_scale), int(seed), int(counter), int(bool(deterministic)))
+            if rc != 0:
+                raise RuntimeError(f"sigmaenv_actor_forward_f32 failed with code {rc}: {env.lib.last_error(env.h).decode()}")
+            return actions
         rc = self.lib.actor_forward(env.h, self.h, p(obs), p(actions), p(log_prob), p(loc_scale), int(seed), int(counter), int(bool(deterministic)))
         if rc != 0:
             raise RuntimeError(f"sigmaenv_actor_forward failed with code {rc}: {env.lib.last_error(env.h).decode()}")

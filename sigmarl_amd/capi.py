@@ -132,6 +132,11 @@ _PRODUCT_ONLY = {
     "actor_create": (C.c_int, [C.c_int32] + [C.c_void_p] * 10 + [C.POINTER(C.c_void_p)]),
     "actor_destroy": (None, [C.c_void_p]),
     "actor_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32]),
+    "mlp32_create": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "mlp32_destroy": (None, [C.c_void_p]),
+    "mlp32_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "actor_forward_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
+                                    C.c_int32]),
     "rollout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32,
                           C.c_int32, C.c_int32]),
 }

@@ -1810,4 +1810,5 @@ extern "C" int sigmaenv_trig_selftest(sigmaenv_t* h, int32_t kind, int32_t n, co
 }
 
 #include "sigmaenv_actor.inc"
+#include "sigmaenv_mlp32.inc"
 #include "sigmaenv_cbf.inc"

@@ -1,4 +1,5 @@
-"""The on-device actor (MFMA kernel) against torch.nn in fp32 and against a bf16-emulating restatement; rollouts without the host."""
+"""The on-device networks: the exact-fp32 actor / critic (matrix cores, fp32 fma chains) against torch.nn in fp32; the bf16 inference variant against
+torch.nn and a bf16-emulating restatement; the distribution head; rollouts without the host."""
 import numpy as np
 import pytest
 
@@ -26,7 +27,7 @@ def _emulated(mlp, obs):
     return x
 
 
-def _setup(B=64, N=16, seed=0, **pkw):
+def _setup(B=64, N=16, seed=0, precision="bf16", **pkw):
     import torch
     from sigmarl_amd.actor import Actor, make_mlp
     from sigmarl_amd.env import SigmaEnv
@@ -42,7 +43,7 @@ def _setup(B=64, N=16, seed=0, **pkw):
             if isinstance(m, torch.nn.Linear):
                 m.weight.mul_(1.7)
                 m.bias.uniform_(-0.3, 0.3)
-    actor = Actor(mlp, low=[-1.0, -0.6], high=[1.0, 0.6])
+    actor = Actor(mlp, low=[-1.0, -0.6], high=[1.0, 0.6], precision=precision)
     return torch, env, mlp, actor
 
 
@@ -59,8 +60,8 @@ def test_actor_matches_torch_and_the_bf16_restatement():
     out_emul = _emulated(mlp, obs.cpu().numpy())
     with torch.no_grad():
         out_f32 = mlp(obs.cpu()).numpy()
-    bias = np.log(np.e - 1.0)
-    sp = lambda v: np.maximum(np.log1p(np.exp(v + bias)), 1e-4)  # noqa: E731
+    bias = np.log(np.expm1(0.99))  # torchrl's biased_softplus(1.0): softplus(x + inv_softplus(1.0 - 0.01)) + 0.01, clamped at 1e-4
+    sp = lambda v: np.maximum(np.log1p(np.exp(v + bias)) + 0.01, 1e-4)  # noqa: E731
     # loc and scale against the bf16-emulating restatement (tolerance: fp32 accumulation order + an occasional flipped bf16 rounding)
     assert np.abs(ls_h[:, :2] - out_emul[:, :2]).max() <= 2e-2
     assert np.abs(ls_h[:, 2:] - sp(out_emul[:, 2:])).max() <= 2e-2
@@ -73,6 +74,78 @@ def test_actor_matches_torch_and_the_bf16_restatement():
     assert np.abs(a - exp).max() <= 1e-5
     env.close()
     actor.close()
+
+
+@pytest.mark.parametrize("scaled", [False, True])
+def test_fp32_actor_matches_torch_nn(scaled):
+    """The exact-fp32 actor (sigmaenv_actor_forward_f32: v_mfma_f32_32x32x2_f32, an fp32 fma chain) == torch.nn in fp32 within 1e-5 on the
+    default initialisation (and within 1e-4 relative with 1.7 x larger weights, where the pre-activations are ~10): loc, scale and the
+    deterministic action."""
+    import torch
+    from sigmarl_amd.actor import Actor, make_mlp
+    from sigmarl_amd.env import SigmaEnv
+    from sigmarl_amd.params import Parameters
+
+    torch.manual_seed(4)
+    env = SigmaEnv(Parameters(n_agents=16, scenario_type="cpm_entire", is_use_mtv_distance=False, is_apply_mask=False, is_obs_noise=False), n_envs=70, device="cuda:0")
+    env.reset_random(seed=3)
+    mlp = make_mlp(env.D)
+    if scaled:
+        with torch.no_grad():
+            for m in mlp:
+                if isinstance(m, torch.nn.Linear):
+                    m.weight.mul_(1.7)
+                    m.bias.uniform_(-0.3, 0.3)
+    actor = Actor(mlp, low=[-1.0, -0.6], high=[1.0, 0.6])  # precision "fp32" is the default
+    R = env.B * env.N
+    obs = (torch.rand((R, env.D), device="cuda") * 2 - 1) * 1.5
+    act = torch.zeros((env.B, env.N, 2), device="cuda")
+    ls = torch.zeros((env.B, env.N, 4), device="cuda")
+    actor.forward(env, act, None, ls, obs=obs, deterministic=True)
+    env.sync()
+    with torch.no_grad():
+        out = mlp(obs.cpu()).numpy()
+    ls_h = ls.reshape(R, 4).cpu().numpy()
+    tol = 1e-5 if not scaled else 1e-4
+    assert np.abs(ls_h[:, :2] - out[:, :2]).max() <= tol * max(1.0, np.abs(out[:, :2]).max())
+    sp = np.maximum(np.log1p(np.exp(out[:, 2:] + np.log(np.expm1(0.99)))) + 0.01, 1e-4)
+    assert np.abs(ls_h[:, 2:] - sp).max() <= tol * max(1.0, sp.max())
+    a = act.reshape(R, 2).cpu().numpy()
+    assert np.abs(a - np.tanh(out[:, :2]).clip(-1 + 1e-6, 1 - 1e-6) * np.array([1.0, 0.6], np.float32)).max() <= 2e-5
+    # the environment's own observation buffer as input (obs=None): same network on env.obs
+    actor.forward(env, act, None, ls, deterministic=True)
+    env.sync()
+    with torch.no_grad():
+        out2 = mlp(env.obs.reshape(R, env.D).cpu()).numpy()
+    assert np.abs(ls.reshape(R, 4).cpu().numpy()[:, :2] - out2[:, :2]).max() <= tol * max(1.0, np.abs(out2[:, :2]).max())
+    env.close()
+    actor.close()
+
+
+def test_fp32_critic_matches_torch_nn():
+    """The MAPPO critic (optimization_module.py:16-32: centralised, shared parameters, N D -> 256 -> 256 -> 256 -> 1, Tanh) in exact fp32 ==
+    torch.nn in fp32 within 1e-5 on the default initialisation; one value per env, handed to every agent."""
+    import torch
+    from sigmarl_amd.actor import Critic
+    from sigmarl_amd.env import SigmaEnv
+    from sigmarl_amd.params import Parameters
+
+    torch.manual_seed(6)
+    N = 16
+    env = SigmaEnv(Parameters(n_agents=N, scenario_type="cpm_entire", is_use_mtv_distance=False, is_apply_mask=False, is_obs_noise=False), n_envs=77, device="cuda:0")
+    env.reset_random(seed=5)
+    net = torch.nn.Sequential(torch.nn.Linear(N * env.D, 256), torch.nn.Tanh(), torch.nn.Linear(256, 256), torch.nn.Tanh(), torch.nn.Linear(256, 256), torch.nn.Tanh(),
+                              torch.nn.Linear(256, 1))
+    critic = Critic(net)
+    v = critic.values(env)
+    env.sync()
+    assert tuple(v.shape) == (env.B, N, 1)
+    with torch.no_grad():
+        want = net(env.obs.reshape(env.B, N * env.D).cpu()).numpy()
+    assert np.abs(v[:, 0, 0].cpu().numpy() - want[:, 0]).max() <= 1e-5
+    assert torch.equal(v[:, 0], v[:, N - 1])
+    env.close()
+    critic.close()
 
 
 def test_sampling_statistics_and_log_prob():
@@ -95,8 +168,10 @@ def test_sampling_statistics_and_log_prob():
     x = np.arctanh(y)
     z = (x - loc) / sc                                                    # recovered standard normals
     assert abs(z.mean()) < 0.05 and abs(z.std() - 1.0) < 0.05 and abs(np.corrcoef(z[:, 0], z[:, 1])[0, 1]) < 0.05
-    ref_lp = (-0.5 * z * z - np.log(sc) - 0.5 * np.log(2 * np.pi) - np.log(1 - y * y + 1e-6) - np.log(half)).sum(1)
+    jac = 2.0 * (np.log(2.0) - x - np.logaddexp(0.0, -2.0 * x))          # log |d tanh / dx| in the stable form torch's TanhTransform uses
+    ref_lp = (-0.5 * z * z - np.log(sc) - 0.5 * np.log(2 * np.pi) - jac - np.log(half)).sum(1)
     assert np.abs(lp.reshape(R).cpu().numpy() - ref_lp).max() <= 5e-3
+    assert abs(float(sc[0]) - 1.0) < 0.5 and float(sc.min()) >= 0.01   # scale(raw) = softplus(raw + b) + 0.01: never below the 0.01 floor
     env.close()
     actor.close()
 
@@ -106,7 +181,7 @@ def test_rollout_without_the_host_equals_stepwise_calls():
     from sigmarl_amd.shard import slab_width
     torch, env, mlp, actor = _setup(B=96, N=16, seed=1)
     torch2, env2, _, _ = _setup(B=96, N=16, seed=1)
-    actor2 = __import__("sigmarl_amd.actor", fromlist=["Actor"]).Actor(mlp, low=[-1.0, -0.6], high=[1.0, 0.6])
+    actor2 = __import__("sigmarl_amd.actor", fromlist=["Actor"]).Actor(mlp, low=[-1.0, -0.6], high=[1.0, 0.6], precision="bf16")
     T, W = 6, slab_width(env.N, env.D)
     slab = torch.zeros((T, env.B, W), device="cuda")
     lp = torch.zeros((T, env.B, env.N), device="cuda")
@@ -137,7 +212,7 @@ def test_rollout_with_cbf_margin_reward_equals_stepwise_calls():
     kw = dict(rew_method="cbf_sparse", is_solve_qp=False, is_using_cbf_training=True)
     torch, env, mlp, actor = _setup(B=48, N=16, seed=2, **kw)
     _, env2, _, _ = _setup(B=48, N=16, seed=2, **kw)
-    actor2 = __import__("sigmarl_amd.actor", fromlist=["Actor"]).Actor(mlp, low=[-1.0, -0.6], high=[1.0, 0.6])
+    actor2 = __import__("sigmarl_amd.actor", fromlist=["Actor"]).Actor(mlp, low=[-1.0, -0.6], high=[1.0, 0.6], precision="bf16")
     for e in (env, env2):
         e.cbf_attach()
     T, W = 5, slab_width(env.N, env.D)
@@ -169,7 +244,7 @@ def test_rollout_with_cbf_qp_equals_stepwise_calls():
     kw = dict(rew_method="cbf", is_solve_qp=True, is_using_cbf_training=True, is_apply_cbf_action=True)
     torch, env, mlp, actor = _setup(B=24, N=8, seed=5, **kw)
     _, env2, _, _ = _setup(B=24, N=8, seed=5, **kw)
-    actor2 = __import__("sigmarl_amd.actor", fromlist=["Actor"]).Actor(mlp, low=[-1.0, -0.6], high=[1.0, 0.6])
+    actor2 = __import__("sigmarl_amd.actor", fromlist=["Actor"]).Actor(mlp, low=[-1.0, -0.6], high=[1.0, 0.6], precision="bf16")
     for e in (env, env2):
         e.cbf_attach()
     T, W = 4, slab_width(env.N, env.D)
