@@ -123,6 +123,8 @@ class Actor:
                 obs: torch.Tensor | None = None, seed: int = 0, counter: int = 0, deterministic: bool = False, precision: str | None = None):
         """actions[B,N,2] := policy(env.obs or ``obs``); enqueued on the env's stream."""
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+        if obs is None:
+            env._warn_noise_free("the on-device actor")
         if (precision or self.precision) == "fp32":
             if self._scratch4 is None or self._scratch4.shape[0] != env.B * env.N or self._scratch4.device != env.device:
                 self._scratch4 = torch.empty((env.B * env.N, 4), dtype=torch.float32, device=env.device)

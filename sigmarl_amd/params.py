@@ -108,6 +108,12 @@ def check_supported(p: Parameters) -> None:
         bad.append("reset_agent_fixed_duration>0")
     if p.is_challenging_initial_state_buffer:
         bad.append("is_challenging_initial_state_buffer=True")
+    # flags that change the observation layout or the distance definition elsewhere in the reference (opponent modelling pads the observation
+    # with predicted actions, observation_provider_rt.py:606-611; prioritised MARL adds action propagation; pseudo distances replace the boundary
+    # distances): none of them is built -- reject instead of silently running the default
+    for flag in ("is_using_opponent_modeling", "is_using_prioritized_marl", "is_using_pseudo_distance"):
+        if getattr(p, flag, False):
+            bad.append(f"{flag}=True")
     if p.is_using_cbf_training or p.is_using_cbf_testing or "cbf" in p.rew_method:
         # built: the centralized QP (is_solve_qp=True) and the QP-free margin reward (sigmarl/cbf_qp.py:2534-2560); not the grouped QPs
         if p.is_grouping_agents:
