@@ -1174,41 +1174,42 @@ __device__ inline void auto_reset_tile(const sigmaenv_config_t& c, const DevMap&
     if (pre.have && e == wave) { cpath = pre.path; cpt = pre.pt; cx = pre.x; cy = pre.y; }
     else if (has_c) reset_candidate(m, rd, b, ca, ctr, cpath, cpt, cx, cy);
     bool cok = has_c;  // still feasible w.r.t. every agent accepted so far
+    int my_path = 0, my_pt = 3;  // lane i keeps agent i's accepted start (registers only: the common case touches LDS once, after the loop)
     for (int i = 0; i < N; ++i) {
-      const int sl = e * N + i;
       unsigned long long feas = __ballot(cok && ca == i);
       int path, pt;
       float px, py;
       if (feas) {  // first feasible among the precomputed tries (they are tries 0..TR-1 in lane order)
-        int wl = __ffsll((long long)feas) - 1;
-        path = __shfl(cpath, wl, 64); pt = __shfl(cpt, wl, 64); px = __shfl(cx, wl, 64); py = __shfl(cy, wl, 64);
+        const int wl = __builtin_amdgcn_readfirstlane(__ffsll((long long)feas) - 1);
+        path = __builtin_amdgcn_readlane(cpath, wl); pt = __builtin_amdgcn_readlane(cpt, wl);
+        px = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cx), wl)); py = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cy), wl));
       } else {     // rare: tries TR..63 of this agent, all lanes at once; none feasible -> the last try (as the bounded loop would)
         int p2, q2;
         float x2, y2;
         reset_candidate(m, rd, b, i, lane, p2, q2, x2, y2);
         bool ok = lane >= TR;
+        wave_sync();  // the accepted positions of agents 0..i-1 (written below by lane 0)
         for (int j = 0; j < i; ++j) {
           float dx = x2 - s.st[(e * N + j) * 8], dy = y2 - s.st[(e * N + j) * 8 + 1];
           float d2 = dx * dx + dy * dy;
           if (!(d2 >= min_d_sq)) ok = false;
         }
         unsigned long long f2 = __ballot(ok);
-        int wl = f2 ? (__ffsll((long long)f2) - 1) : (AUTO_RESET_MAX_TRIES - 1);
-        path = __shfl(p2, wl, 64); pt = __shfl(q2, wl, 64); px = __shfl(x2, wl, 64); py = __shfl(y2, wl, 64);
+        const int wl = __builtin_amdgcn_readfirstlane(f2 ? (__ffsll((long long)f2) - 1) : (AUTO_RESET_MAX_TRIES - 1));
+        path = __builtin_amdgcn_readlane(p2, wl); pt = __builtin_amdgcn_readlane(q2, wl);
+        px = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x2), wl)); py = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y2), wl));
       }
-      if (lane == 0) { s.st[sl * 8] = px; s.st[sl * 8 + 1] = py; s.path[sl] = path; s.cp[sl * 3] = pt; }
+      if (lane == i) { my_path = path; my_pt = pt; }
+      if (lane == 0) { s.st[(e * N + i) * 8] = px; s.st[(e * N + i) * 8 + 1] = py; }
       // later agents must keep the minimum distance to this one (world_state_rt_sim.py:296-309)
       float dx = cx - px, dy = cy - py;
       float d2 = dx * dx + dy * dy;
       if (ca > i && !(d2 >= min_d_sq)) cok = false;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     if (lane < N) {  // finalise the accepted starts, one lane per agent (world_state_rt_sim.py:189-213)
       const int i = lane, sl = e * N + i;
       float u = (float)(rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, 1000u) >> 8) * (1.0f / 16777216.0f);
-      place_from_start_table(m, g, s, t, sl, s.path[sl], s.cp[sl * 3], u * c.max_speed, path_first, true);
+      place_from_start_table(m, g, s, t, sl, my_path, my_pt, u * c.max_speed, path_first, true);
     }
   }
   __threadfence_block();
@@ -1278,6 +1279,7 @@ struct sigmaenv {
   int G = 1;      // environments per workgroup (G * N <= 64 agent slots) of the block kernels (reset / observe)
   int wave_G = 1, wave_wpb = 1, wave_grid = 1;  // step kernel: environments per wavefront tile, wavefronts per workgroup, workgroups
   size_t wave_tile_lds = 0;
+  sigmaenv_config_t* d_cfg = nullptr;  // device copy of cfg (the step kernel reads it through scalar loads)
   int grid = 1;
   void* bufs[SIGMAENV_BUF_COUNT] = {nullptr};
   size_t buf_bytes[SIGMAENV_BUF_COUNT] = {0};
@@ -1600,6 +1602,10 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
     if (cfg->envs_per_group >= 1 && cfg->envs_per_group * N <= 64) wg = cfg->envs_per_group;
     if (const char* e = getenv("SIGMAENV_WAVE_G")) { int v = atoi(e); if (v >= 1 && v * N <= 64) wg = v; }
     h->wave_G = wg;
+    if (dev_alloc(h, (void**)&h->d_cfg, sizeof(sigmaenv_config_t)) != SIGMAENV_OK || hipMemcpyAsync(h->d_cfg, &h->cfg, sizeof(sigmaenv_config_t), hipMemcpyHostToDevice, h->stream) != hipSuccess) {
+      sigmaenv_destroy(h);
+      return SIGMAENV_EHIP;
+    }
     { const unsigned d = (unsigned)(wg * N); h->buf.mSG = d <= 1u ? 0u : (uint32_t)(((1ull << 32) + d - 1ull) / d); }
     h->wave_wpb = 1;
     if (const char* e = getenv("SIGMAENV_WPB")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) h->wave_wpb = v; }
@@ -1689,7 +1695,7 @@ static int launch_step(sigmaenv* h, const float* actions, uint64_t seed, uint64_
     const bool par = 2 * h->wave_G * h->N <= 64;
     auto kern = h->map.fast_div ? (par ? sigmaenv_step_wave_kernel<true, true> : sigmaenv_step_wave_kernel<true, false>)
                                 : (par ? sigmaenv_step_wave_kernel<false, true> : sigmaenv_step_wave_kernel<false, false>);
-    hipLaunchKernelGGL(kern, dim3(h->wave_grid), dim3(64 * h->wave_wpb), h->wave_tile_lds * h->wave_wpb, h->stream, h->cfg, h->map, h->buf, actions,
+    hipLaunchKernelGGL(kern, dim3(h->wave_grid), dim3(64 * h->wave_wpb), h->wave_tile_lds * h->wave_wpb, h->stream, h->d_cfg, h->map, h->buf, actions,
                        h->wave_G, (int)h->wave_tile_lds, seed, counter, path_first, path_count, h->buf.slab);
   }
   HIPCHK(h, hipGetLastError());
