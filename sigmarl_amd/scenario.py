@@ -354,11 +354,14 @@ class ScenarioRoadTraffic(BaseScenario):
                     for e in range(env.B):
                         self.reset_world_at(e)
                     return
-                # vectorised initial reset: the device-side sampler (same rule, counter-based RNG instead of torch's generator)
-                env.buffer(capi.BUF_DONE).fill_(1)
-                env.auto_reset(seed=int(getattr(p, "random_seed", 0)))
-                self._obs_dirty = False
-                return
+                if self.device_side_resets:
+                    # vectorised initial reset by the device-side sampler (same rule, counter-based RNG instead of torch's generator)
+                    env.buffer(capi.BUF_DONE).fill_(1)
+                    env.auto_reset(seed=int(getattr(p, "random_seed", 0)))
+                    self._obs_dirty = False
+                    return
+                # default: the reference's own loop over the envs (road_traffic.py:832-834) drawing from torch's global generator in the
+                # reference's order, so a caller that seeds torch gets the reference's initial states
             envs = range(env.B)
         else:
             envs = [int(env_index)]

@@ -667,6 +667,34 @@ TRAJS = {
                             is_use_mtv_distance=False, rew_method="cbf", is_using_cbf_training=True, is_solve_qp=False, nom_controller_type="clf"),
 }
 
+def gen_initial_reset():
+    """The reference's INITIAL reset from a seeded torch generator: `torch.manual_seed(s)` right before `env_reset_world_at(None)` (every import
+    and make_world done -- importing road_traffic itself consumes draws), so that a caller of the mirrored surface who seeds at the same point
+    must get the same start states (road_traffic.py:832-834, world_state_rt_sim.py:215-311)."""
+    out = {}
+    cases = [("cpm16", dict(n_agents=16, scenario_type="cpm_entire"), 6, 5), ("intersection4", dict(n_agents=4, scenario_type="intersection_1"), 8, 6),
+             ("cpm8_testing", dict(n_agents=8, scenario_type="cpm_entire", is_testing_mode=True), 4, 7)]
+    for nme, kw, B, seed in cases:
+        p = Parameters(is_obs_noise=False, is_apply_mask=False, max_steps=128, num_vmas_envs=B, is_challenging_initial_state_buffer=False, **kw)
+        refshim.install()
+        from sigmarl.scenarios.road_traffic import ScenarioRoadTraffic
+
+        sc = ScenarioRoadTraffic()
+        sc.parameters = p
+        world = sc.env_make_world(B, torch.device("cpu"))
+        torch.manual_seed(seed)
+        sc.env_reset_world_at(None)
+        rp = sc.world_state.ref_paths_agent_related
+        out[nme + "_path_id"] = np_(rp.path_id).astype(np.int32)
+        out[nme + "_point_id"] = np_(rp.point_id).astype(np.int32) if hasattr(rp, "point_id") else np.zeros((B, len(world.agents)), np.int32)
+        out[nme + "_pos"] = np.stack([np_(a.state.pos) for a in world.agents], axis=1).astype(np.float32)
+        out[nme + "_rot"] = np.stack([np_(a.state.rot)[:, 0] for a in world.agents], axis=1).astype(np.float32)
+        out[nme + "_speed"] = np.stack([np_(a.state.speed)[:, 0] for a in world.agents], axis=1).astype(np.float32)
+        out[nme + "_meta"] = np.asarray([B, len(world.agents), seed], np.int32)
+    np.savez_compressed(os.path.join(OUT, "initial_reset.npz"), **out)
+    print("initial_reset:", {k: v.shape for k, v in out.items() if k.endswith("_pos")})
+
+
 def content_hash(path):
     """sha256 over the fixture's CONTENT (sorted keys, dtype, shape, raw bytes): independent of the zip container's timestamps."""
     import hashlib
@@ -686,6 +714,8 @@ def generate_one(nme):
         gen_cbf_functions()
     elif nme == "adversarial":
         gen_adversarial()
+    elif nme == "initial_reset":
+        gen_initial_reset()
     else:
         run_traj(nme, **TRAJS[nme])
 
@@ -699,7 +729,7 @@ if __name__ == "__main__":
     if len(sys.argv) >= 3 and sys.argv[1] == "--one":
         generate_one(sys.argv[2])
         sys.exit(0)
-    names = sys.argv[1:] or (["functions", "cbf_functions", "adversarial"] + list(TRAJS))
+    names = sys.argv[1:] or (["functions", "cbf_functions", "adversarial", "initial_reset"] + list(TRAJS))
     envv = dict(os.environ, PYTHONHASHSEED="0")
     for nme in names:
         subprocess.check_call([sys.executable, os.path.abspath(__file__), "--one", nme], env=envv)

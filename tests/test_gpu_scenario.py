@@ -257,3 +257,34 @@ def test_device_side_resets_through_the_surface():
         assert torch.isfinite(new_obs).all()
     assert total_done > 0
     sc.env.close()
+
+
+@pytest.mark.parametrize("name,kw", [("cpm16", dict(n_agents=16, scenario_type="cpm_entire")), ("intersection4", dict(n_agents=4, scenario_type="intersection_1")),
+                                     ("cpm8_testing", dict(n_agents=8, scenario_type="cpm_entire", is_testing_mode=True))])
+def test_seeded_initial_reset_reproduces_the_reference(name, kw):
+    """`torch.manual_seed(s)` right before `env_reset_world_at(None)` gives the reference's initial states through the mirrored surface
+    (road_traffic.py:832-834 loops the envs; world_state_rt_sim.py:215-311 draws path / point / speed from torch's global generator in this
+    order): fixture tests/golden/initial_reset.npz was recorded from the reference exactly that way.  Only `device_side_resets=True`
+    switches the initial reset to the device sampler."""
+    import os
+
+    import torch
+    from sigmarl_amd.scenario import make_scenario
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "initial_reset.npz"))
+    B, N, seed = [int(v) for v in z[name + "_meta"]]
+    p = Parameters(is_apply_mask=False, is_obs_noise=False, num_vmas_envs=B, max_steps=128, **kw)
+    sc = make_scenario(p)
+    sc.env_make_world(B, "cuda:0", n_agents=N)
+    torch.manual_seed(seed)
+    sc.env_reset_world_at(None)
+    env = sc.env
+    env.sync()
+    path = env.buffer(capi.BUF_PATH).cpu().numpy()
+    assert np.array_equal(path[:, :, 2], z[name + "_path_id"])
+    assert np.array_equal(path[:, :, 3], z[name + "_point_id"])
+    st = env.state.cpu().numpy()
+    assert np.abs(st[:, :, 0:2] - z[name + "_pos"]).max() <= 1e-6
+    assert np.abs(st[:, :, 2] - z[name + "_rot"]).max() <= 1e-6
+    assert np.abs(st[:, :, 3] - z[name + "_speed"]).max() <= 1e-6
+    env.close()
