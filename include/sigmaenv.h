@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define SIGMAENV_ABI_VERSION 1
+#define SIGMAENV_ABI_VERSION 2
 
 /* error codes */
 #define SIGMAENV_OK 0
@@ -102,6 +102,8 @@ typedef struct sigmaenv_config {
                                  * one in ego view: the reference computes the agents' lanelets (for the mask by lanelet relation) in its
                                  * bird-view branch only (:537-588), so that mask stays empty (map_manager.py:21,102-118). */
   float distance_mask_agents;   /* thresholds.distance_mask_agents = 5 * length (road_traffic.py:663) */
+  float reset_agent_fixed_duration; /* Parameters.reset_agent_fixed_duration [s], 0 = off: every env is also done when t = step * dt (fp32) is a
+                                     * non-zero multiple of it (t % duration == 0, road_traffic.py:1388-1397, :1431, :1454) */
 } sigmaenv_config_t;
 
 /* Unpadded reference-path table (output of the map parser, sigmarl/map_manager.py:13-40).  The library builds the padded

@@ -513,9 +513,14 @@ static void env_done(oracle_t* o, int b) {
   for (int k = 0; k < N * N; ++k) col_a |= o->col_agents[(size_t)b * N * N + k];
   for (int i = 0; i < N; ++i) col_l |= o->col_flags[((size_t)b * N + i) * 4];
   int max_reached = o->timer[b * 4] == (c->max_steps - 1);      /* :1413 */
+  int fixed = 0;                                                 /* :1388-1397: t = timer.step * dt is an fp32 tensor */
+  if (c->reset_agent_fixed_duration > 0.0f) {
+    float tt = (float)o->timer[b * 4] * c->dt;
+    fixed = (remainder_pos(tt, c->reset_agent_fixed_duration) == 0.0f) && (tt != 0.0f);
+  }
   int done;
-  if (c->is_testing_mode) done = max_reached;                    /* :1429-1433 */
-  else done = max_reached | col_a | col_l;                       /* :1450-1455 */
+  if (c->is_testing_mode) done = max_reached | fixed;            /* :1429-1433 */
+  else done = max_reached | col_a | col_l | fixed;               /* :1450-1455 */
   o->done[b] = (uint8_t)done;
   for (int i = 0; i < N; ++i) {
     size_t bi = (size_t)b * N + i;

@@ -14,7 +14,7 @@ import ctypes as C
 import math
 import os
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 DIST_C2C, DIST_MTV = 0, 1
 REW_DISTANCE, REW_TTC, REW_EXACT_SPARSE, REW_HAS_SPARSE, REW_CBF, REW_CBF_QP = 1, 2, 4, 8, 16, 32
 CBF_MAX_CIRCLES = 4
@@ -49,7 +49,7 @@ class Config(C.Structure):
         ("threshold_near_other_agents_low", C.c_float), ("threshold_near_other_agents_high", C.c_float),
         ("ttc_low", C.c_float), ("ttc_high", C.c_float),
         ("penalty_deviate_from_cbf_vel", C.c_float), ("penalty_deviate_from_cbf_steer", C.c_float),
-        ("is_apply_mask", C.c_int32), ("distance_mask_agents", C.c_float),
+        ("is_apply_mask", C.c_int32), ("distance_mask_agents", C.c_float), ("reset_agent_fixed_duration", C.c_float),
     ]
 
 

@@ -104,8 +104,6 @@ def check_supported(p: Parameters) -> None:
         bad.append("is_observe_ref_path_other_agents=True")
     if p.n_points_short_term != capi.N_SHORT_TERM:
         bad.append(f"n_points_short_term={p.n_points_short_term} (only {capi.N_SHORT_TERM})")
-    if p.reset_agent_fixed_duration:
-        bad.append("reset_agent_fixed_duration>0")
     if p.is_challenging_initial_state_buffer:
         bad.append("is_challenging_initial_state_buffer=True")
     # flags that change the observation layout or the distance definition elsewhere in the reference (opponent modelling pads the observation
@@ -179,6 +177,7 @@ def make_config(p: Parameters, map_table, n_envs: int, make_world_scenario_type:
         c.threshold_near_other_agents_high = p.threshold_near_other_agents_c2c_high if p.threshold_near_other_agents_c2c_high is not None else 0.3
     c.is_apply_mask = int(bool(p.is_apply_mask))
     c.distance_mask_agents = A["length"] * 5  # road_traffic.py:663
+    c.reset_agent_fixed_duration = float(p.reset_agent_fixed_duration or 0.0)  # road_traffic.py:1388-1397
     c.penalty_deviate_from_cbf_vel = c.penalty_deviate_from_cbf_steer = -5 / r_p_normalizer  # road_traffic.py:238-243
     c.ttc_low = p.ttc_low if p.ttc_low is not None else 0
     c.ttc_high = p.ttc_high if p.ttc_high is not None else 3.75

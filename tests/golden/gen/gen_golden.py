@@ -657,6 +657,11 @@ TRAJS = {
                                is_use_mtv_distance=False, rew_method="distance", is_apply_mask=True),
     "roundabout6_mask": dict(T=40, B=2, seed=26, mode_pattern=[1, 0], n_agents=6, scenario_type="roundabout_2", dt=0.1,
                              is_use_mtv_distance=True, rew_method="ttc", is_apply_mask=True),
+    # Parameters.reset_agent_fixed_duration: every env is done whenever t = step * dt hits a multiple of it (road_traffic.py:1388-1397)
+    "cpm8_fixed_reset": dict(T=32, B=4, seed=27, mode_pattern=[1, 1, 0, 1], n_agents=8, scenario_type="cpm_entire", dt=0.05,
+                             is_use_mtv_distance=False, rew_method="distance", reset_agent_fixed_duration=0.5),
+    "intersection4_fixed_testing": dict(T=48, B=3, seed=28, mode_pattern=[1, 0, 1], n_agents=4, scenario_type="intersection_1", dt=0.1,
+                                        is_use_mtv_distance=False, rew_method="distance", is_testing_mode=True, reset_agent_fixed_duration=1.5),
     # BASELINE config 4: 32 agents on the on-ramp map.  The reference's rejection sampler cannot place them, so the
     # start is injected (Parameters.predefined_ref_path_idx / init_state); vehicles overlap from the first step on, every env is "done" at
     # every step and none is reset: non-reset steps only, as the survey prescribes for this configuration

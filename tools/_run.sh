@@ -1,2 +1,2 @@
 cd /root/repo
-timeout 600 python -m pytest tests/test_gpu_scenario.py -x -q 2>&1 | tail -15
+timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -6
