@@ -286,7 +286,15 @@ typedef struct sigmaenv_cbf_config {
   double qp_w_lambda;            /* lambda_weight (1e3) when Parameters.adaptive_lambda, else 0 (:924-927) */
   double lam_clf;                /* lam_clf (2) */
   int32_t is_apply_cbf_action;   /* Parameters.is_apply_cbf_action: which action SIGMAENV_BUF_CBF_NOMINAL receives (below) */
-  int32_t reserved3;
+  /* grouped CBF-QPs (Parameters.is_grouping_agents, cbf_qp.py:1562-2281): sigmaenv_cbf_qp then solves, per env, the ceil(N / max_group_size)
+   * group problems of build_grouped_cbf_qps instead of the centralized one (below) */
+  int32_t is_grouping;           /* Parameters.is_grouping_agents */
+  int32_t max_group_size;        /* Parameters.max_group_size (m): capacity of a group */
+  int32_t reserved4;
+  double observation_range;      /* Parameters.observation_range: cross-group rows only against external vehicles within this distance (:2094-2109) */
+  double rs;                     /* Parameters.rs: share of a cross-group row's h a vehicle takes on (rs * h * lambda, :1751-1757) */
+  double qp_w_cross;             /* cross_slack_weight (1e9, :428-430) */
+  double qp_w_lambda_cross;      /* lambda_weight (1e3): the cross-group lambdas are always penalised (:1789-1791) */
 } sigmaenv_cbf_config_t;
 
 /* seg_left / seg_right: HOST pointers f32 [n_paths, seg_stride, 5] = per boundary segment (cos, sin, m_b, m_t, length): the
@@ -319,6 +327,20 @@ int sigmaenv_cbf_rewards(sigmaenv_t* h, const float* actions, double* margins);
  * SIGMAENV_REW_CBF_QP the next step penalises the distance between the two (road_traffic.py:1117-1135).  n_agents <= 32 (SIGMAENV_EINVAL
  * beyond: the 2N x 2N Hessian is kept in LDS).  Repeated launches on the same state return the same bits. */
 int sigmaenv_cbf_qp(sigmaenv_t* h, const float* actions, float* actions_safe, double* u_opt, int32_t* info);
+
+/* Grouped mode (cfg.is_grouping): per env the vehicles are partitioned ONCE into K = ceil(N / m) groups by group_agents_k_nearest
+ * (cbf_qp.py:193-310: farthest-point seeds, then every vehicle joins the nearest group with room; members sorted, groups ordered by their
+ * first member) from the positions at the first sigmaenv_cbf_qp call, and kept for the rest of the run (use_fixed_groups, :1897-1909).  Each
+ * group problem (:1562-1856) has the lane rows of its members, the pair rows of its member pairs, and per member i and external vehicle j
+ * within observation_range the ONE-SIDED rows  A_i u_i + b0 / 2 + rs h lambda >= -s  (ttcbf_pair_affine_coeffs_cross :2491-2532; slack
+ * weight qp_w_cross, lambda always penalised).  The group problems share no variable, so sigmaenv_cbf_qp solves them as one block-separable
+ * problem in the 2N controls: the same minimisers.  As in the reference the safe action always replaces the action
+ * (actions_safe) and SIGMAENV_BUF_CBF_NOMINAL receives the clamped policy action ("rl", :2254-2260) or U_nom ("clf", :2262-2268).
+ * Requires is_solve_qp semantics (the reference's grouped update raises otherwise: its coefficient builders receive lam = None).
+ * sigmaenv_cbf_regroup: forget the groups (the next sigmaenv_cbf_qp call forms them again: what constructing new CBFQP objects does).
+ * sigmaenv_cbf_get_groups: HOST i32 [B,N] group index of every vehicle (SIGMAENV_EINVAL before the first grouped call). */
+int sigmaenv_cbf_regroup(sigmaenv_t* h);
+int sigmaenv_cbf_get_groups(sigmaenv_t* h, int32_t* groups_host);
 
 #ifdef __cplusplus
 }

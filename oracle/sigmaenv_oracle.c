@@ -48,6 +48,8 @@ typedef struct sigmaenv_oracle {
   int32_t *path, *closest, *nearing, *timer;
   uint8_t *col_agents, *col_flags, *done;
   sigmaenv_cbf_config_t cbf;    /* sigmaenv_oracle_cbf_attach */
+  int32_t* cbf_groups;          /* [B,N] group index of every vehicle (grouped CBF-QPs), formed at the first sigmaenv_oracle_cbf_qp call */
+  int cbf_groups_valid;
   float *seg_left, *seg_right;  /* [n_paths][seg_stride][5] */
   int seg_stride;
   char err[256];
@@ -750,7 +752,7 @@ void sigmaenv_oracle_destroy(oracle_t* o) {
   void* ptrs[] = {o->center, o->left, o->right, o->yaw, o->n_center, o->n_left, o->n_right, o->is_loop, o->state, o->prev_pos,
                   o->vertices, o->short_term, o->dist_ref, o->dist_left, o->dist_right, o->dist_bound, o->dist_agents, o->reward,
                   o->reward_info, o->obs, o->action, o->path, o->closest, o->nearing, o->timer, o->col_agents, o->col_flags, o->done,
-                  o->seg_left, o->seg_right, o->cbf_nominal};
+                  o->seg_left, o->seg_right, o->cbf_nominal, o->cbf_groups};
   for (size_t k = 0; k < sizeof(ptrs) / sizeof(ptrs[0]); ++k) free(ptrs[k]);
   free(o);
 }

@@ -71,7 +71,9 @@ class CbfConfig(C.Structure):
         ("l_r", C.c_double), ("l_wb", C.c_double), ("min_speed", C.c_float), ("min_steering", C.c_float),
         ("steering_rate_max", C.c_double), ("k_clf_speed", C.c_double), ("k_clf_heading", C.c_double), ("ref_speed", C.c_double),
         ("qp_w_acc", C.c_double), ("qp_w_steer", C.c_double), ("qp_w_lane", C.c_double), ("qp_w_pair", C.c_double), ("qp_w_clf", C.c_double),
-        ("qp_w_lambda", C.c_double), ("lam_clf", C.c_double), ("is_apply_cbf_action", C.c_int32), ("reserved3", C.c_int32),
+        ("qp_w_lambda", C.c_double), ("lam_clf", C.c_double), ("is_apply_cbf_action", C.c_int32), ("is_grouping", C.c_int32),
+        ("max_group_size", C.c_int32), ("reserved4", C.c_int32), ("observation_range", C.c_double), ("rs", C.c_double),
+        ("qp_w_cross", C.c_double), ("qp_w_lambda_cross", C.c_double),
     ]
 
 
@@ -122,6 +124,8 @@ _SIGS = {
     "cbf_attach": (C.c_int, [C.c_void_p, C.POINTER(CbfConfig), C.c_void_p, C.c_void_p, C.c_int32]),
     "cbf_rewards": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cbf_qp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cbf_regroup": (C.c_int, [C.c_void_p]),
+    "cbf_get_groups": (C.c_int, [C.c_void_p, C.c_void_p]),
 }
 _PRODUCT_ONLY = {
     "step_time_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),

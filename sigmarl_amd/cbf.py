@@ -113,6 +113,13 @@ def make_cbf_config(p, n_circles: int | None = None):
     c.qp_w_lambda = 1e3 if bool(getattr(p, "adaptive_lambda", False)) else 0.0
     c.lam_clf = float(getattr(p, "lam_clf", 2.0))
     c.is_apply_cbf_action = int(bool(getattr(p, "is_apply_cbf_action", False)))
+    # grouped CBF-QPs (cbf_qp.py:1562-2281)
+    c.is_grouping = int(bool(getattr(p, "is_grouping_agents", False)))
+    c.max_group_size = int(getattr(p, "max_group_size", 2))
+    c.observation_range = float(getattr(p, "observation_range", 0.5))
+    c.rs = float(getattr(p, "rs", 0.5))
+    c.qp_w_cross = 1e9    # cross_slack_weight, :428-430
+    c.qp_w_lambda_cross = 1e3  # lambda_weight, :431 (always applied to the cross-group lambdas, :1789-1791)
     return c
 
 

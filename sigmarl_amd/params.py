@@ -113,9 +113,15 @@ def check_supported(p: Parameters) -> None:
         if getattr(p, flag, False):
             bad.append(f"{flag}=True")
     if p.is_using_cbf_training or p.is_using_cbf_testing or "cbf" in p.rew_method:
-        # built: the centralized QP (is_solve_qp=True) and the QP-free margin reward (sigmarl/cbf_qp.py:2534-2560); not the grouped QPs
-        if p.is_grouping_agents:
-            bad.append("is_grouping_agents=True")
+        # built: the centralized QP (is_solve_qp=True), the grouped QPs (is_grouping_agents) and the QP-free margin reward
+        # (sigmarl/cbf_qp.py:2534-2560).  The reference's grouped update only runs with is_solve_qp=True (its coefficient builders receive
+        # lam=None and raise otherwise, :1993-1998 with :2371-2398) and without a cap on the cross-group neighbours.
+        if p.is_grouping_agents and not p.is_solve_qp:
+            bad.append("is_grouping_agents=True with is_solve_qp=False (raises in the reference as well)")
+        if p.is_grouping_agents and getattr(p, "max_cross_neighbors", None) is not None:
+            bad.append("max_cross_neighbors")
+        if p.is_grouping_agents and int(p.max_group_size) < 1:
+            bad.append("max_group_size < 1")
         if p.nom_controller_type not in ("rl", "clf"):
             bad.append(f"nom_controller_type={p.nom_controller_type!r}")
         if not 1 <= int(p.n_circles_approximate_vehicle) <= capi.CBF_MAX_CIRCLES:

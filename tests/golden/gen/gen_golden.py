@@ -721,6 +721,10 @@ def generate_one(nme):
         gen_adversarial()
     elif nme == "initial_reset":
         gen_initial_reset()
+    elif nme == "cbf_grouped":  # needs its own cvxpy stand-in installed before the reference is imported: own script
+        import subprocess
+
+        subprocess.check_call([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "gen_cbf_grouped.py")])
     else:
         run_traj(nme, **TRAJS[nme])
 
@@ -734,7 +738,7 @@ if __name__ == "__main__":
     if len(sys.argv) >= 3 and sys.argv[1] == "--one":
         generate_one(sys.argv[2])
         sys.exit(0)
-    names = sys.argv[1:] or (["functions", "cbf_functions", "adversarial", "initial_reset"] + list(TRAJS))
+    names = sys.argv[1:] or (["functions", "cbf_functions", "adversarial", "initial_reset", "cbf_grouped"] + list(TRAJS))
     envv = dict(os.environ, PYTHONHASHSEED="0")
     for nme in names:
         subprocess.check_call([sys.executable, os.path.abspath(__file__), "--one", nme], env=envv)

@@ -156,7 +156,7 @@ class OracleEnv:
         """(actions_safe f32 [B,N,2], u_opt f64 [B,N,2], info i32 [B,2]) and, with_data, the constraint rows [B,n_con,8] and u_nom."""
         a = np.ascontiguousarray(actions, np.float32).reshape(self.B, self.N, 2)
         Cc = int(self.cbf_cfg.n_circles)
-        ncon = self.N * Cc * 2 + self.N * (self.N - 1) // 2 * Cc * Cc
+        ncon = self.N * Cc * 2 + (2 if int(self.cbf_cfg.is_grouping) else 1) * (self.N * (self.N - 1) // 2 * Cc * Cc)  # (rows beyond an env's count: i = -1)
         safe = np.zeros((self.B, self.N, 2), np.float32)
         u = np.zeros((self.B, self.N, 2), np.float64)
         info = np.zeros((self.B, 2), np.int32)
@@ -166,6 +166,17 @@ class OracleEnv:
         if rc != 0:
             raise RuntimeError(f"oracle cbf_qp failed: {rc}")
         return (safe, u, info, con, unom) if with_data else (safe, u, info)
+
+    def cbf_groups(self):
+        """[B,N] group index of every vehicle (grouped CBF-QPs; formed at the first cbf_qp call)."""
+        g = np.zeros((self.B, self.N), np.int32)
+        rc = self.lib.cbf_get_groups(self.h, ptr(g))
+        if rc != 0:
+            raise RuntimeError(f"oracle cbf_get_groups failed: {rc}")
+        return g
+
+    def cbf_regroup(self):
+        self.lib.cbf_regroup(self.h)
 
     def auto_reset(self, seed, counter, path_first, path_count):
         rc = self.lib.auto_reset(self.h, int(seed), int(counter), int(path_first), int(path_count))

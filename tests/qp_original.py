@@ -20,12 +20,14 @@ import scipy.sparse as sp
 import scipy.sparse.linalg as spla
 
 
-def build_original_qp(con, unom, lo, hi, w, ws_lane, ws_pair, wl, n_lane, clf_e, clf_v, wc=1.0):
-    """(P, q, A, l, u, n_u) of the original problem for one env.  Variable order: u [n], s [m], lambda [m], s_clf [n]."""
+def build_original_qp(con, unom, lo, hi, w, ws_lane, ws_pair, wl, n_lane, clf_e, clf_v, wc=1.0, ws_rows=None, wl_rows=None):
+    """(P, q, A, l, u, n_u) of the original problem for one env.  Variable order: u [n], s [m], lambda [m], s_clf [n].
+    ws_rows / wl_rows: per-row slack / lambda weights (the grouped problems: cross-group rows carry their own)."""
     n, m = len(unom), len(con)
     nv = 2 * n + 2 * m
-    ws = np.where(np.arange(m) < n_lane, ws_lane, ws_pair).astype(np.float64)
-    pd = np.concatenate([2.0 * w ** 2, 2.0 * ws, np.full(m, 2.0 * wl), np.full(n, 2.0 * wc)])
+    ws = np.where(np.arange(m) < n_lane, ws_lane, ws_pair).astype(np.float64) if ws_rows is None else np.asarray(ws_rows, np.float64)
+    wlv = np.full(m, float(wl)) if wl_rows is None else np.asarray(wl_rows, np.float64)
+    pd = np.concatenate([2.0 * w ** 2, 2.0 * ws, 2.0 * wlv, np.full(n, 2.0 * wc)])
     P = sp.diags(pd).tocsc()
     q = np.zeros(nv)
     q[:n] = -2.0 * (w ** 2) * unom
