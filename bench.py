@@ -48,6 +48,8 @@ def make_params_kw(args, n_envs):
               is_apply_mask=False, is_obs_noise=False, max_steps=128, num_vmas_envs=n_envs)
     if args.cbf_qp:
         kw.update(rew_method="cbf", is_solve_qp=True, is_using_cbf_training=True)
+        if args.cbf_group_size > 0:  # the grouped CBF-QPs (Parameters.is_grouping_agents, cbf_qp.py:1562-2281) instead of the centralized one
+            kw.update(is_grouping_agents=True, max_group_size=args.cbf_group_size, adaptive_lambda=True)
     elif args.cbf:
         kw.update(rew_method="cbf", is_solve_qp=False, is_using_cbf_training=True)
     return kw
@@ -345,6 +347,7 @@ def main():
                     "inference variant")
     ap.add_argument("--cbf", action="store_true", help="widening (SURVEY 8f-4): rew_method='cbf' with the QP-free CBF margin reward "
                     "(sigmaenv_cbf_rewards before every step); reported in config.cbf")
+    ap.add_argument("--cbf-group-size", type=int, default=0, help="--cbf-qp: solve the grouped CBF-QPs with this max_group_size instead of the centralized QP")
     ap.add_argument("--cbf-qp", action="store_true", help="BASELINE config 5: rew_method='cbf' with the centralized CBF-QP safety filter solved for "
                     "every env before every step (sigmaenv_cbf_qp); reported in config.cbf")
     ap.add_argument("--exchange", choices=["alltoall", "gather"], default="alltoall",
@@ -442,7 +445,8 @@ def main():
             "policy": (f"actor MLP 32-256-256-256-4 ({args.policy_precision}) on device before every step" if args.policy
                        else "none in the timed region (precomputed actions resident in HBM)"),
             **({"cbf": ("centralized CBF-QP safety filter of every env (sigmaenv_cbf_qp: 2 N controls, lane + pair constraints, projected "
-                        "Newton in float64) solved before every step; the step penalises the deviation from the safe action" if args.cbf_qp else
+                        "Newton in float64) solved before every step; the step penalises the deviation from the safe action"
+                        + (f"; grouped QPs, max_group_size {args.cbf_group_size}" if args.cbf_group_size > 0 else "") if args.cbf_qp else
                         "QP-free CBF margin reward (sigmaenv_cbf_rewards: 3 circles per vehicle, 9-point fp16 pseudo-distance stencils to both "
                         "boundaries, float64 margins) launched before every step")} if (args.cbf or args.cbf_qp) else {}),
             "resets_per_step_per_gpu": dones / max(1, args.steps),

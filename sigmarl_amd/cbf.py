@@ -130,7 +130,8 @@ def split_cbf_margins(flat: np.ndarray, B: int, N: int, Cc: int):
 
 
 class CBFQP:
-    """Mirror of ``sigmarl.cbf_qp.CBFQP`` for the QP-free margin reward (reference ``cbf_qp.py:325-364, 2534-2560``).
+    """Mirror of ``sigmarl.cbf_qp.CBFQP`` (reference ``cbf_qp.py:325-364, 2534-2560``): the QP-free margin reward, the centralized CBF-QP and the
+    grouped CBF-QPs, dispatched as ``update_qp`` does there.
 
     The reference builds one controller per env (``mappo_cavs.py:583``) and loops over them every step
     (``helper_training.py:1620-1627``); here ONE launch serves the whole batch.  ``CBFQP(env=env)`` is the batched controller;
@@ -148,8 +149,9 @@ class CBFQP:
         self.env_idx = env_idx
         self.agent_idx = agent_idx
         self.parameters = sc.parameters
-        if self.parameters.is_grouping_agents:
-            raise NotImplementedError("sigmarl_amd.cbf.CBFQP: the grouped QPs are not built (centralized QP and QP-free margin reward are)")
+        if self.parameters.is_grouping_agents and not self.parameters.is_solve_qp:
+            # the reference's grouped update hands lam=None to its coefficient builders, whose non-adaptive branch then raises (cbf_qp.py:1993-1998)
+            raise NotImplementedError("sigmarl_amd.cbf.CBFQP: is_grouping_agents needs is_solve_qp=True (as in the reference)")
         self.time_pseudo_dis = 0
         self.cbf_solving_t = []
         if getattr(sc.env, "cbf_cfg", None) is None:
@@ -162,6 +164,13 @@ class CBFQP:
             return
         act = tensordict[("agents", "action")] if not hasattr(tensordict, "is_cuda") else tensordict
         env = self.scenario.env
+        if self.parameters.is_grouping_agents:
+            # update_grouped_cbf_qps (cbf_qp.py:1858-2281): the group problems of every env; the safe action always replaces the action
+            # (:2211-2222) and world_state.nominal_action_* receives the clamped policy action / U_nom (:2254-2268)
+            safe = env.cbf_qp(act.contiguous())
+            act.copy_(safe)
+            self.scenario.inter_groups = None  # (formed on the device: scenario.env.cbf_groups())
+            return
         if not self.parameters.is_solve_qp:
             env.cbf_rewards(act.contiguous())
             return

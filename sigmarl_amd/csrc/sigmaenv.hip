@@ -1297,6 +1297,8 @@ struct sigmaenv {
   sigmaenv_cbf_config_t cbf_cfg{};
   void *cbf_seg4 = nullptr, *cbf_segl = nullptr, *cbf_cxy = nullptr, *cbf_u = nullptr, *cbf_kin = nullptr, *cbf_clf = nullptr, *cbf_safe = nullptr;
   int cbf_seg_stride = 0;
+  int32_t* cbf_groups = nullptr;  // [B,N] group index of every vehicle (grouped CBF-QPs), formed by the first sigmaenv_cbf_qp call
+  bool cbf_groups_valid = false;
   std::string err;
 };
 

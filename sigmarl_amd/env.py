@@ -241,6 +241,17 @@ class SigmaEnv:
                                   C.c_void_p(info.data_ptr()) if info is not None else None), "cbf_qp")
         return actions_safe
 
+    def cbf_groups(self) -> np.ndarray:
+        """[B, N] int32: the group of every vehicle (grouped CBF-QPs, ``Parameters.is_grouping_agents``), formed by the first ``cbf_qp`` call
+        and kept (``use_fixed_groups``, ``sigmarl/cbf_qp.py:1897-1909``)."""
+        g = np.zeros((self.B, self.N), np.int32)
+        self._chk(self.lib.cbf_get_groups(self.h, g.ctypes.data_as(C.c_void_p)), "cbf_get_groups")
+        return g
+
+    def cbf_regroup(self):
+        """Forget the groups: the next ``cbf_qp`` call forms them again (what constructing new ``CBFQP`` objects does in the reference)."""
+        self._chk(self.lib.cbf_regroup(self.h), "cbf_regroup")
+
     def step_autoreset(self, actions: torch.Tensor, seed: int = 0, counter: int | None = None, path_first: int | None = None,
                        path_count: int | None = None):
         """``step`` + ``auto_reset`` in one launch (same end state); the terminal observation goes to the slab only."""
@@ -375,6 +386,12 @@ class NumpyAdapter:
         safe = self.env.cbf_qp(a, None, u, info)
         self.env.sync()
         return safe.cpu().numpy(), u.cpu().numpy(), info.cpu().numpy()
+
+    def cbf_groups(self):
+        return self.env.cbf_groups()
+
+    def cbf_regroup(self):
+        self.env.cbf_regroup()
 
     def auto_reset(self, seed, counter, path_first, path_count):
         self.env.auto_reset(seed, counter, path_first, path_count)

@@ -233,10 +233,10 @@ def test_cbf_full_scan_fallback_matches(monkeypatch):
     ora.close()
 
 
-def test_cbf_requires_attach_and_rejects_grouping():
+def test_cbf_requires_attach_and_rejects_grouping_without_qp():
     mp = load_map("cpm_entire")
-    with pytest.raises(NotImplementedError):
-        make_config(Parameters(n_agents=4, rew_method="cbf", is_solve_qp=True, is_using_cbf_training=True, is_grouping_agents=True, is_apply_mask=False,
+    with pytest.raises(NotImplementedError):  # the reference's grouped update raises without is_solve_qp (lam=None in its coefficient builders)
+        make_config(Parameters(n_agents=4, rew_method="cbf", is_solve_qp=False, is_using_cbf_training=True, is_grouping_agents=True, is_apply_mask=False,
                                is_obs_noise=False), mp, 2)
     p = Parameters(n_agents=4, rew_method="cbf", is_solve_qp=False, is_using_cbf_training=True, is_apply_mask=False, is_obs_noise=False)
     dev = _hip_env(make_config(p, mp, 2), mp)
@@ -453,4 +453,110 @@ def test_cbf_qp_full_size_4096_envs():
         n_changed += int((np.abs(u_d - unom).max(axis=(1, 2)) > 1e-6).sum())
         ora.close()
     assert n_changed >= 10
+    env.close()
+
+
+# ---- grouped CBF-QPs (Parameters.is_grouping_agents; sigmarl/cbf_qp.py:193-310, 1562-2281) ---------------------------------------------
+@pytest.mark.parametrize("case", [(2, 0.5, "rl"), (3, 0.5, "rl"), (4, 1.0, "rl"), (2, 1.0, "clf"), (5, 0.5, "clf")])
+def test_grouped_qp_matches_oracle_and_reference_groups(case):
+    """HIP == oracle for the grouped problems: identical groups (the reference's, tests/golden/cbf_grouped.npz), minimiser within 1e-7,
+    safe actions and the nominal-action record within 1e-6."""
+    import test_cbf_grouped as tg
+
+    m, rng, nominal = case
+    z, _ = tg.grouped_fixture()
+    k0 = [c[0] for c in tg.fixture_cases() if c[1:] == (m, rng, nominal)][0]
+    outs = []
+    for make in (ob.OracleEnv, _hip_env):
+        env, act, ref = tg.grouped_case(make, m, rng, nominal)
+        st = env.get(capi.BUF_SHORT_TERM, copy=False) if make is ob.OracleEnv else None
+        if st is not None:
+            st[:, :, 2, :] = ref
+        else:
+            env.env.buffer(capi.BUF_SHORT_TERM)[:, :, 2, :] = __import__("torch").as_tensor(ref).to(env.env.device)
+        safe, u, info = env.cbf_qp(act)[:3]
+        outs.append((safe, u, info, env.cbf_groups(), env.get(capi.BUF_CBF_NOMINAL).copy()))
+        env.close()
+    (s0, u0, i0, g0, n0), (s1, u1, i1, g1, n1) = outs
+    assert np.array_equal(g0, g1) and np.array_equal(g1, z["grp"][k0:k0 + len(g1)])
+    assert i1[:, 1].all()
+    assert np.abs(u0 - u1).max() <= 1e-7
+    assert np.abs(s0 - s1).max() <= 1e-6 and np.abs(n0 - n1).max() <= 1e-6
+
+
+def test_grouped_qp_against_the_original_problems_and_regroup():
+    """The HIP minimiser of the grouped problems == the interior-point solution of the original problems (every slack / lambda of every group
+    problem explicit; tests/qp_original.py) within 1e-5, with the row data taken from the oracle (pinned on the reference's); the groups are kept
+    across calls and re-formed after sigmaenv_cbf_regroup; repeated launches return the same bits."""
+    import test_cbf_grouped as tg
+
+    m, rng, nominal = 3, 1.0, "rl"
+    envo, act, ref = tg.grouped_case(ob.OracleEnv, m, rng, nominal)
+    _, _, _, con, unom = envo.cbf_qp(act, with_data=True)
+    env, _, _ = tg.grouped_case(_hip_env, m, rng, nominal)
+    safe, u, info = env.cbf_qp(act)
+    assert info[:, 1].all()
+    worst = 0.0
+    for b in range(env.B):
+        x = tg.solve_grouped_original(envo, con[b], unom[b], nominal, b)
+        worst = max(worst, float(np.abs(x - u[b].reshape(-1)).max()))
+    assert worst <= 1e-5, worst
+    safe2, u2, _ = env.cbf_qp(act)
+    assert np.array_equal(u.view(np.uint64), u2.view(np.uint64))
+    g0 = env.cbf_groups()
+    import torch
+    st = env.env.buffer(capi.BUF_STATE)
+    st[:, :, 0:2] = torch.flip(st[:, :, 0:2], dims=[1])
+    env.cbf_qp(act)
+    assert np.array_equal(env.cbf_groups(), g0)
+    env.cbf_regroup()
+    env.cbf_qp(act)
+    assert not np.array_equal(env.cbf_groups(), g0)
+    envo.close(); env.close()
+
+
+def test_grouped_qp_full_size_4096_envs():
+    """16 agents x 4096 envs, groups of 4, observation range 0.75 m: every env converges; groups (formed on the device) and minimisers of the
+    first and last 96 envs equal the oracle's on the same states; a few steps with the safe actions applied keep the groups."""
+    import torch
+    from sigmarl_amd.env import SigmaEnv
+
+    B, N, S = 4096, 16, 96
+    p = Parameters(n_agents=N, scenario_type="cpm_entire", rew_method="cbf", dt=0.05, is_solve_qp=True, is_using_cbf_training=True, is_apply_mask=False,
+                   is_obs_noise=False, is_use_mtv_distance=False, adaptive_lambda=True, is_grouping_agents=True, max_group_size=4, observation_range=0.75)
+    env = SigmaEnv(p, n_envs=B, device="cuda:0")
+    env.reset_random(seed=13)
+    env.cbf_attach()
+    g = torch.Generator(device="cuda").manual_seed(6)
+    safe = torch.empty((B, N, 2), device="cuda")
+    u = torch.empty((B, N, 2), dtype=torch.float64, device="cuda")
+    info = torch.empty((B, 2), dtype=torch.int32, device="cuda")
+    st0 = env.buffer(capi.BUF_STATE)[:, :, 0:2].cpu().numpy().copy()
+    for t in range(3):
+        act = torch.stack([torch.rand(B, N, generator=g, device="cuda") * 1.4 - 0.2, torch.rand(B, N, generator=g, device="cuda") * 1.0 - 0.5], -1).contiguous()
+        env.cbf_qp(act, safe, u, info)
+        if t < 2:
+            env.step(safe)  # (no resets: the groups belong to the vehicles of the run)
+    env.sync()
+    assert bool(info[:, 1].all()), int((info[:, 1] == 0).sum())
+    assert bool(torch.isfinite(u).all()) and bool(torch.isfinite(safe).all())
+    groups = env.cbf_groups()
+    assert all(np.bincount(groups[b], minlength=4).tolist() == [4, 4, 4, 4] for b in range(0, B, 97))
+    mp = env.map
+    seg_l, seg_r = cbf.load_segment_tables(mp)
+    for lo in (0, B - S):
+        ora = ob.OracleEnv(make_config(p, mp, S), mp)
+        ora.cbf_attach(cbf.make_cbf_config(p), seg_l, seg_r)
+        pa = env.buffer(capi.BUF_PATH)[lo:lo + S].cpu().numpy()
+        st = env.buffer(capi.BUF_STATE)[lo:lo + S].cpu().numpy()
+        first = st.copy()
+        first[:, :, 0:2] = st0[lo:lo + S]  # the oracle forms its groups on the states of the first call, as the device did
+        ora.reset(np.repeat(np.arange(S), N), np.tile(np.arange(N), S), pa.reshape(-1, 4), first.reshape(-1, 8), 1)
+        ora.cbf_qp(act[lo:lo + S].cpu().numpy())
+        assert np.array_equal(ora.cbf_groups(), groups[lo:lo + S])
+        ora.reset(np.repeat(np.arange(S), N), np.tile(np.arange(N), S), pa.reshape(-1, 4), st.reshape(-1, 8), 1)
+        safe_o, u_o, info_o = ora.cbf_qp(act[lo:lo + S].cpu().numpy())
+        assert np.abs(u[lo:lo + S].cpu().numpy() - u_o).max() <= 1e-7
+        assert np.abs(safe[lo:lo + S].cpu().numpy() - safe_o).max() <= 1e-6
+        ora.close()
     env.close()

@@ -42,7 +42,7 @@ def test_rew_flags_follow_the_reference_string_tests():
 def test_unsupported_configurations_fail_loudly():
     ok = Parameters(is_apply_mask=False)
     check_supported(ok)
-    for kw in (dict(is_apply_mask=True, is_ego_view=False), dict(is_apply_mask=False, is_ego_view=False), dict(is_apply_mask=False, is_using_cbf_training=True, is_grouping_agents=True),
+    for kw in (dict(is_apply_mask=True, is_ego_view=False), dict(is_apply_mask=False, is_ego_view=False), dict(is_apply_mask=False, is_using_cbf_training=True, is_grouping_agents=True, is_solve_qp=False),
                dict(is_apply_mask=False, n_points_short_term=5)):
         with pytest.raises(NotImplementedError):
             check_supported(Parameters(**kw))
