@@ -1279,6 +1279,7 @@ struct sigmaenv {
   int G = 1;      // environments per workgroup (G * N <= 64 agent slots) of the block kernels (reset / observe)
   int wave_G = 1, wave_wpb = 1, wave_grid = 1;  // step kernel: environments per wavefront tile, wavefronts per workgroup, workgroups
   size_t wave_tile_lds = 0;
+  int wave_spec = 0;  // agents * 256 + envs per wavefront of a fixed-shape instantiation of the step kernel (2 observed neighbours), else 0
   sigmaenv_config_t* d_cfg = nullptr;  // device copy of cfg (the step kernel reads it through scalar loads)
   int grid = 1;
   void* bufs[SIGMAENV_BUF_COUNT] = {nullptr};
@@ -1609,6 +1610,8 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
       return SIGMAENV_EHIP;
     }
     { const unsigned d = (unsigned)(wg * N); h->buf.mSG = d <= 1u ? 0u : (uint32_t)(((1ull << 32) + d - 1ull) / d); }
+    h->wave_spec = (K == 2 && ((N == 16 && wg == 1) || (N == 32 && wg == 1) || (N == 8 && wg == 2) || (N == 4 && wg == 4))) ? N * 256 + wg : 0;
+    if (const char* e = getenv("SIGMAENV_WAVE_SPEC")) { if (atoi(e) == 0) h->wave_spec = 0; }  // A/B: the generic instantiation
     h->wave_wpb = 1;
     if (const char* e = getenv("SIGMAENV_WPB")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) h->wave_wpb = v; }
     h->wave_tile_lds = (((Smem::bytes(wg * N, N, K, h->D, true) + 15) & ~(size_t)15) + 16 * (size_t)wg + 16 + 15) & ~(size_t)15;
@@ -1620,6 +1623,10 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_wave_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_wave_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_wave_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_wave_kernel<true, true, 16, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_wave_kernel<true, true, 32, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_wave_kernel<true, true, 8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_wave_kernel<true, true, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     }
   }
   if (hipStreamSynchronize(h->stream) != hipSuccess) { sigmaenv_destroy(h); return SIGMAENV_EHIP; }
@@ -1697,6 +1704,15 @@ static int launch_step(sigmaenv* h, const float* actions, uint64_t seed, uint64_
     const bool par = 2 * h->wave_G * h->N <= 64;
     auto kern = h->map.fast_div ? (par ? sigmaenv_step_wave_kernel<true, true> : sigmaenv_step_wave_kernel<true, false>)
                                 : (par ? sigmaenv_step_wave_kernel<false, true> : sigmaenv_step_wave_kernel<false, false>);
+    if (h->map.fast_div) {  // fixed-shape instantiations (the plain-division variant of a map with degenerate segments stays generic)
+      switch (h->wave_spec) {
+        case 16 * 256 + 1: kern = sigmaenv_step_wave_kernel<true, true, 16, 1>; break;
+        case 32 * 256 + 1: kern = sigmaenv_step_wave_kernel<true, true, 32, 1>; break;
+        case 8 * 256 + 2: kern = sigmaenv_step_wave_kernel<true, true, 8, 2>; break;
+        case 4 * 256 + 4: kern = sigmaenv_step_wave_kernel<true, true, 4, 4>; break;
+        default: break;
+      }
+    }
     hipLaunchKernelGGL(kern, dim3(h->wave_grid), dim3(64 * h->wave_wpb), h->wave_tile_lds * h->wave_wpb, h->stream, h->d_cfg, h->map, h->buf, actions,
                        h->wave_G, (int)h->wave_tile_lds, seed, counter, path_first, path_count, h->buf.slab);
   }

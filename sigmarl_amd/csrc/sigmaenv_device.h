@@ -80,6 +80,7 @@ struct __attribute__((packed, aligned(8))) Seg4 { float ax, ay, bx, by; };
 __device__ __forceinline__ Seg4 load_segment(const float2* p, int k) { return *reinterpret_cast<const Seg4*>(p + k); }
 
 // x / d for x * d < 2^32 with m = ceil(2^32 / d) (d = 1: m wraps to 0): two instructions instead of the ~20 of a runtime division
+__host__ __device__ constexpr uint32_t magic_u32(unsigned d) { return d <= 1u ? 0u : (uint32_t)(((1ull << 32) + d - 1ull) / d); }
 __device__ __forceinline__ int fdiv(int x, uint32_t m) { return m ? (int)__umulhi((uint32_t)x, m) : x; }
 
 // four consecutive floats stored with ONE 16-byte store at 4-byte alignment (global memory accepts it): rows of the rollout record
