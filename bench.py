@@ -11,10 +11,12 @@ step_and_maybe_reset keeps both the terminal and the post-reset observation) int
 finished; for N > 1 additionally one asynchronous RCCL exchange of the rollout chunk per --chunk-steps steps (--exchange alltoall: by
 time slices to every rank, the default; --exchange gather: everything to rank 0).  Inputs (actions) are resident in HBM before the timed
 region starts.  Weak scaling: every GPU steps BASELINE config 2 (CPM map, 16 agents x 4096 envs); N = 8 is config 3 (32768 envs).
+Up to 8192 envs per GPU are stepped as two env shards on two HIP streams (--streams); `config.one_stream` carries the same workload timed
+with a single launch per step right after the headline region (--no-one-stream skips it).
 
 Other workloads of BASELINE.json through the same code path:
   --scenario on_ramp_1 --agents 32 --envs-per-gpu 8192      config 4 (injected start, see sigmarl_amd.maps.injected_start)
-  --cbf-qp                                                  config 5 (centralized CBF-QP before every step)
+  --cbf-qp                                                  config 5 (centralized CBF-QP before every step; --cbf-group-size M: the grouped QPs)
   --sweep                                                   the metric's batch sweep 16 agents x {256 .. 32768} envs in `sweep`
 
 roofline (SURVEY.md section 8d / BASELINE.md section 3): `achieved` = algorithmic bytes per agent-env-step (44 + 251 + 5 N) x agent-env-steps
@@ -336,6 +338,7 @@ def main():
                     "report it in `sweep`; the headline stays --envs-per-gpu")
     ap.add_argument("--sweep-envs", default="256,512,1024,2048,4096,8192,16384,32768")
     ap.add_argument("--sweep-steps", type=int, default=64)
+    ap.add_argument("--no-one-stream", action="store_true", help="skip the additional one-stream measurement reported in config.one_stream")
     ap.add_argument("--no-reset", action="store_true", help="diagnostic: leave finished envs un-reset")
     ap.add_argument("--separate-reset", action="store_true", help="two launches per step (sigmaenv_step; sigmaenv_auto_reset) instead of the fused one")
     ap.add_argument("--no-gather", action="store_true", help="diagnostic: no rollout record (and no exchange for N > 1)")
@@ -467,6 +470,20 @@ def main():
         },
     }
     run.close()
+    if S > 1 and not args.no_one_stream:
+        # the same workload with ONE launch per step (no env shards): what the kernel does without the host-side overlap of two launches
+        import copy
+
+        a1 = copy.copy(args)
+        a1.streams = 1
+        r1 = GpuRun(a1, device, B, world, rank)
+        for t in range(min(args.warmup, 32)):
+            r1.one_step(t)
+        r1.finish_chunk()
+        el1 = timed(r1, args.steps, args.warmup, use_dist, dist, torch, device)
+        out["config"]["one_stream"] = {"ms_per_step": el1 / args.steps * 1e3, "value": total_agent_steps / el1,
+                                       "note": "same steps, one handle and one launch per step on one stream (timed after the headline region)"}
+        r1.close()
     if args.sweep:
         sweep = []
         for Bx in [int(x) for x in args.sweep_envs.split(",") if x]:

@@ -1,8 +1,5 @@
 cd /root/repo
-bash tools/profile_round.sh r02_d > /dev/null 2>&1
-cat gpurun_out/r02_d/r02_d_kernel_stats.csv | head -5
-python tools/make_traffic_json.py gpurun_out/r02_d/pmc > gpurun_out/r02_d/traffic_latest.json 2>/dev/null; cat gpurun_out/r02_d/traffic_latest.json | head -20
-python tools/make_valu_json.py gpurun_out/r02_d/pmc > gpurun_out/r02_d/valu_latest.json 2>/dev/null; cat gpurun_out/r02_d/valu_latest.json
-timeout 300 python tools/phase_timestamps.py > gpurun_out/r02_d/r02_d_phase_cycles.txt 2>&1; tail -10 gpurun_out/r02_d/r02_d_phase_cycles.txt
-bash tools/pmc_ablation.sh gpurun_out/r02_d/ablation > gpurun_out/r02_d/r02_d_pmc_phase_ablation.txt 2>&1
-grep -E "skip=|SQ_INSTS_VALU " gpurun_out/r02_d/r02_d_pmc_phase_ablation.txt | head -40
+mkdir -p gpurun_out/r02_e
+timeout 600 python bench.py --sweep > gpurun_out/r02_e/bench_default_sweep.json 2> gpurun_out/r02_e/bench.err; tail -c 3000 gpurun_out/r02_e/bench_default_sweep.json
+timeout 120 python bench.py --steps 20 --warmup 5 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('driver-like', d['value'], d['ms_per_step'], d['config'].get('one_stream'), d['roofline']['kernel_launches'])"
+for v in "--policy" "--policy --policy-precision bf16" "--cbf" "--cbf-qp" "--distance mtv" "--scenario on_ramp_1 --agents 32 --envs-per-gpu 8192"; do timeout 300 python bench.py --steps 128 --warmup 16 --cpu-seconds 0 --no-one-stream $v 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', d['value'], d['ms_per_step'])"; done
