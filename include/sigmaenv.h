@@ -221,7 +221,8 @@ int sigmaenv_trig_selftest(sigmaenv_t* h, int32_t kind, int32_t n, const float* 
 typedef struct sigmaenv_actor sigmaenv_actor_t;
 
 /* w_l / b_l: HOST pointers, torch.nn.Linear layout (w_l row-major [out, in], fp32); low / high: action bounds, 2 floats each
- * (VMAS: -/+ u_range = max_speed, max_steering, helper_common.py:382-430). */
+ * (VMAS: -/+ u_range = max_speed, max_steering, helper_common.py:382-430).  obs_dim must be 8, 16, 24 or 32 (whole MFMA k-blocks; the
+ * reference's default observation is 32 = sigmaenv_obs_dim(2)); other widths: SIGMAENV_EINVAL -- use sigmaenv_mlp32_* (any width). */
 int sigmaenv_actor_create(int32_t obs_dim, const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
                           const float* w4, const float* b4, const float* low, const float* high, sigmaenv_actor_t** out);
 void sigmaenv_actor_destroy(sigmaenv_actor_t* a);

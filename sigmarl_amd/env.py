@@ -221,6 +221,7 @@ class SigmaEnv:
             if not (margins.is_cuda and margins.dtype == torch.float64 and margins.is_contiguous() and margins.numel() == self.cbf_margin_count()):
                 raise TypeError("margins must be a contiguous float64 CUDA tensor with cbf_margin_count() elements")
             mp = C.c_void_p(margins.data_ptr())
+        self._warn_cbf_noise()
         self._chk(self.lib.cbf_rewards(self.h, C.c_void_p(actions.data_ptr()), mp), "cbf_rewards")
 
     def cbf_qp(self, actions: torch.Tensor, actions_safe: torch.Tensor | None = None, u_opt: torch.Tensor | None = None, info: torch.Tensor | None = None):
@@ -236,6 +237,7 @@ class SigmaEnv:
         for t, dt in ((actions_safe, torch.float32), (u_opt, torch.float64), (info, torch.int32)):
             if t is not None and not (t.is_cuda and t.dtype == dt and t.is_contiguous()):
                 raise TypeError("cbf_qp outputs must be contiguous CUDA tensors (float32 / float64 / int32)")
+        self._warn_cbf_noise()
         self._chk(self.lib.cbf_qp(self.h, C.c_void_p(actions.data_ptr()), C.c_void_p(actions_safe.data_ptr()),
                                   C.c_void_p(u_opt.data_ptr()) if u_opt is not None else None,
                                   C.c_void_p(info.data_ptr()) if info is not None else None), "cbf_qp")
@@ -284,6 +286,16 @@ class SigmaEnv:
             self._noise_warned = True
             warnings.warn(f"sigmarl_amd: is_obs_noise=True, but {what} reads the observation buffer on the device, where no noise is added "
                           "(the noise is applied in ScenarioRoadTraffic.observation() only); pass is_obs_noise=False to make this explicit", stacklevel=3)
+
+    def _warn_cbf_noise(self):
+        """With ``is_obs_noise`` the reference perturbs the policy's action before it enters the "rl" nominal controller of the CBF module
+        (``rl_i + rand_like(rl_i) * obs_noise_level``, cbf_qp.py:1060-1061, :2608-2609); the device path takes the action as given."""
+        if getattr(self.parameters, "is_obs_noise", False) and not getattr(self, "_cbf_noise_warned", False):
+            import warnings
+
+            self._cbf_noise_warned = True
+            warnings.warn("sigmarl_amd: is_obs_noise=True, but the CBF module on the device uses the policy's action without the reference's "
+                          "action noise (cbf_qp.py:2608-2609); add it to the action tensor before the call to reproduce it", stacklevel=3)
 
     def set_slab(self, slab: torch.Tensor | None):
         """Route the per-step rollout record ([B, N*(D+1)+1] fp32: obs | reward | done) into ``slab`` (None disables it)."""
