@@ -1,15 +1,19 @@
 // sigmaenv.hip -- fused vectorized multi-agent CAV environment step for MI355X (gfx950) + its C-ABI (include/sigmaenv.h).
 //
-// One workgroup = one WAVEFRONT'S WORTH OF AGENTS: G = floor(64 / N) environments (G*N <= 64 "slots").  That way the
-// per-agent phases fill a whole 64-lane wavefront instead of N lanes.  Phases of the fused step kernel (one launch per step):
-//   A  lane per agent : action clamp + kinematic bicycle Euler step, new rectangle vertices             (K1, K2)
-//   B1 lane per pair  : mutual distances (c2c / mtv) and rectangle-rectangle collision masks            (K4, K5)
-//   B2 wave per agent : 11 point->polyline queries and 2 rectangle->boundary collision scans: lanes across the polyline
-//                       segments that survive bounding-box pruning, wavefront shuffles for (min, first argmin)  (K3, K5)
-//   C  lane per agent : reward terms, short-term reference path; per-env done / counters by wavefront ballots   (K7, K6, K9)
-//   D  lane per item  : top-k nearest agents, ego-view transforms (uniform passes), observation rows staged in LDS  (K8)
+// The step kernel (sigmaenv_step_wave.inc) gives every WAVEFRONT its own tile of G envs x N agents (G * N <= 64 "slots", one env per
+// wavefront at 16 agents) and never synchronises wavefronts with each other; one launch per step:
+//   A  two lanes per agent : action clamp + kinematic bicycle Euler step, new rectangle vertices                  (K1, K2)
+//   S  lane per work item  : the 11 point->polyline queries per agent as a balanced list of (agent, polyline, chunk of 4 segments)
+//                            items -- only chunks that survive bounding-box pruning -- merged by LDS atomics        (K3)
+//   E  lane per (agent, near segment, edge) : rectangle->boundary collision tests                                 (K5)
+//   B1 lane per pair       : mutual distances (c2c / mtv) and rectangle-rectangle collision masks                  (K4, K5)
+//   C  lane per agent      : reward terms, short-term reference path; per-env done / counters by wavefront ballots (K7, K6, K9)
+//   D  lane per item       : top-k nearest agents, ego-view transforms, observation rows staged in LDS, rollout record row (K8)
+//   R  the tile's wavefront: device-side reset of finished envs / re-placement of agents with a pending request
 // Per-env agent poses / vertices / distance rows live in LDS between the phases; HBM sees each state word once in, once out.
-// MFMA is unused on purpose: there is no dense contraction in this path.
+// This file holds the shared device code (full-scan fallback, candidate masks, observation, resets), the workgroup kernels of the
+// stand-alone entry points (reset, observe, auto-reset, start table) and the C-ABI.
+// MFMA is unused on purpose in the step: there is no dense contraction in this path.
 //
 // Reference citations are relative to /root/reference/sigmarl; see sigmaenv_device.h for the arithmetic contract.
 #include <hip/hip_runtime.h>
@@ -737,8 +741,8 @@ __device__ inline void observe_tile(const sigmaenv_config_t& c, const Smem& s, c
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// the fused step kernel: grid = ceil(n_envs / G), block = 64 * waves
-// VMAS >= 1.4 call order restated per env: world.step(); reward(a) for all a; observation(a) for all a; done()
+// device-side resets (used by the step kernel's phase R and by sigmaenv_auto_reset)
+// VMAS >= 1.4 call order restated per env by the step: world.step(); reward(a) for all a; observation(a) for all a; done()
 // ---------------------------------------------------------------------------------------------------------------------
 // candidate (path, point) of try `tr` for agent `i` of env `b` -- the draw layout shared with the oracle
 struct ResetDraw {
