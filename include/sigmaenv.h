@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define SIGMAENV_ABI_VERSION 2
+#define SIGMAENV_ABI_VERSION 3
 
 /* error codes */
 #define SIGMAENV_OK 0
@@ -102,6 +102,7 @@ typedef struct sigmaenv_config {
                                  * one in ego view: the reference computes the agents' lanelets (for the mask by lanelet relation) in its
                                  * bird-view branch only (:537-588), so that mask stays empty (map_manager.py:21,102-118). */
   float distance_mask_agents;   /* thresholds.distance_mask_agents = 5 * length (road_traffic.py:663) */
+  int32_t obs_flags;            /* SIGMAENV_OBS_*: non-default observation layout (below); 0 = the reference's config.json defaults */
   float reset_agent_fixed_duration; /* Parameters.reset_agent_fixed_duration [s], 0 = off: every env is also done when t = step * dt (fp32) is a
                                      * non-zero multiple of it (t % duration == 0, road_traffic.py:1388-1397, :1431, :1454) */
 } sigmaenv_config_t;
@@ -152,6 +153,20 @@ typedef struct sigmaenv sigmaenv_t;
 
 /* obs_dim for the default observation flags (config.json:36-45): 1 + 2*3 + 3 + K*(8+2+1) */
 int sigmaenv_obs_dim(int32_t n_nearing);
+
+/* Non-default observation flags of Parameters (ego view, partial observation; observation_provider_rt.py:594-925).  Row layout:
+ *   [own]     speed | steering (STEERING) | short-term path 2*3 | distance to the centre line (unless NO_DIST_CENTER) | left | right boundary
+ *   [other k] vertices 8  (NO_VERTICES: position 2, relative rotation 1, length 1, width 1) | velocity 2 | steering (STEERING) |
+ *             distance (unless NO_DIST_AGENTS) | its short-term path 2*3 in the ego frame (REF_OTHERS)
+ * normalised as update_state does (:345-536: positions by 10 lengths, rotations / steering by 2 pi, lengths / widths by 10 lengths).
+ * With obs_flags != 0 SIGMAENV_BUF_OBS has sigmaenv_obs_dim_ex columns and is written by a separate kernel after every step / reset /
+ * observe (the fused step keeps computing the default row for its own use); sigmaenv_set_slab and sigmaenv_rollout return SIGMAENV_EINVAL. */
+#define SIGMAENV_OBS_STEERING 1        /* Parameters.is_obs_steering */
+#define SIGMAENV_OBS_REF_OTHERS 2      /* Parameters.is_observe_ref_path_other_agents */
+#define SIGMAENV_OBS_NO_VERTICES 4     /* Parameters.is_observe_vertices == False */
+#define SIGMAENV_OBS_NO_DIST_AGENTS 8  /* Parameters.is_observe_distance_to_agents == False */
+#define SIGMAENV_OBS_NO_DIST_CENTER 16 /* Parameters.is_observe_distance_to_center_line == False */
+int sigmaenv_obs_dim_ex(int32_t n_nearing, int32_t obs_flags);
 
 /* device_id: HIP device ordinal.  hip_stream: hipStream_t to enqueue on (NULL = the device's default stream). */
 int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_t* map, int device_id, void* hip_stream,

@@ -439,16 +439,20 @@ static inline void ego_transform(float pix, float piy, float rot_i, float pjx, f
   *oy = cr_sin(rr) * ab;
 }
 
-/* observation of one agent, default flags: observation_provider_rt.py:345-588 (latest slot only), :594-925 */
+/* observation of one agent (ego view, partial observation): observation_provider_rt.py:345-588 (latest slot only), :594-925.  obs_flags = 0 is
+ * the default layout; the SIGMAENV_OBS_* switches add / drop / replace columns exactly where _observe_self / _observe_other_agents do. */
 static void agent_observation(oracle_t* o, int b, int i) {
   int N = o->N, K = o->K, D = o->D;
   const sigmaenv_config_t* c = &o->cfg;
+  const int F = c->obs_flags;
   size_t bi = (size_t)b * N + i;
   const float* si = o->state + bi * 8;
   float* ob = o->obs + bi * D;
   float n_pos = (float)((double)c->length * 10.0);               /* normalizers.pos, road_traffic.py:588-592 */
   float n_v = c->max_speed;                                      /* :596 */
   float n_dl = (float)((double)c->lane_width * 3.0);             /* :599-601 */
+  float n_rot = (float)(2.0 * 3.141592653589793);                /* normalizers.rot = 2 * torch.pi, :597 */
+  float n_da = (float)((double)c->length * 10.0);                /* normalizers.distance_agent, :605-607 */
   const float* Drow = o->dist_agents + (size_t)b * N * N + (size_t)i * N;
   /* top-k smallest, ascending, lowest index on ties: observation_provider_rt.py:629-636 */
   int32_t* near = o->nearing + bi * K;
@@ -469,6 +473,7 @@ static void agent_observation(oracle_t* o, int b, int i) {
     float rr = angle_eliminate_two_pi(si[2] - si[2]);
     ob[p++] = (norm2(si[5], si[6]) * cr_cos(rr)) / n_v;
   }
+  if (F & SIGMAENV_OBS_STEERING) ob[p++] = angle_eliminate_two_pi(si[4]) / n_rot;   /* [own] steering, :356-360, :392, :888-892 */
   /* [own] short-term reference path in the ego frame (:451-460, :893-897) */
   for (int k = 0; k < NS; ++k) {
     float ox, oy;
@@ -477,32 +482,49 @@ static void agent_observation(oracle_t* o, int b, int i) {
     ob[p++] = oy / n_pos;
   }
   /* [own] distances, all normalised by distance_lanelet (:373-389, :898-922) */
-  ob[p++] = o->dist_ref[bi] / n_dl;
+  if (!(F & SIGMAENV_OBS_NO_DIST_CENTER)) ob[p++] = o->dist_ref[bi] / n_dl;
   float ml = INFINITY, mr = INFINITY;
   for (int q = 0; q < 5; ++q) { ml = fminf(ml, o->dist_left[bi * 5 + q]); mr = fminf(mr, o->dist_right[bi * 5 + q]); }
   ob[p++] = ml / n_dl;
   ob[p++] = mr / n_dl;
-  /* [others] vertices (8), velocity (2), distance (1) per observed neighbour (:819-853) */
+  /* [others] per observed neighbour (:803-853): vertices (8) -- or position (2), relative rotation, length, width --, velocity (2), steering,
+   * distance, its short-term reference path; masked by distance (:638-749): positions / vertices / reference path / distance := 1,
+   * rotation / steering / velocity := 0 (lengths and widths are not masked) */
   for (int k = 0; k < K; ++k) {
     int j = near[k];
     size_t bj = (size_t)b * N + j;
     const float* sj = o->state + bj * 8;
     const float* vj = o->vertices + bj * 10;
-    for (int q = 0; q < 4; ++q) {
+    const int masked = c->is_apply_mask && Drow[j] >= c->distance_mask_agents;
+    if (!(F & SIGMAENV_OBS_NO_VERTICES)) {
+      for (int q = 0; q < 4; ++q) {
+        float ox, oy;
+        ego_transform(si[0], si[1], si[2], vj[2 * q], vj[2 * q + 1], &ox, &oy);
+        ob[p++] = masked ? 1.0f : ox / n_pos;                    /* :734-737 */
+        ob[p++] = masked ? 1.0f : oy / n_pos;
+      }
+    } else {
       float ox, oy;
-      ego_transform(si[0], si[1], si[2], vj[2 * q], vj[2 * q + 1], &ox, &oy);
-      ob[p++] = ox / n_pos;
-      ob[p++] = oy / n_pos;
+      ego_transform(si[0], si[1], si[2], sj[0], sj[1], &ox, &oy);          /* :429-434 */
+      ob[p++] = masked ? 1.0f : ox / n_pos;                      /* :672-680 */
+      ob[p++] = masked ? 1.0f : oy / n_pos;
+      ob[p++] = masked ? 0.0f : angle_eliminate_two_pi(sj[2] - si[2]) / n_rot;   /* :437, :683-688 */
+      ob[p++] = c->length / n_da;                                /* :387-389, :691-694 */
+      ob[p++] = c->width / n_da;                                 /* :390-391, :695-698 */
     }
     float rr = angle_eliminate_two_pi(sj[2] - si[2]);           /* :439 */
     float va = norm2(sj[5], sj[6]);                              /* :444 */
-    ob[p++] = (va * cr_cos(rr)) / n_v;
-    ob[p++] = (va * cr_sin(rr)) / n_v;
-    ob[p++] = Drow[j] / n_dl;                                    /* :373-375 */
-    if (c->is_apply_mask && Drow[j] >= c->distance_mask_agents) {  /* masked by distance, :638-665: vertices / distance := 1, velocity := 0 */
-      for (int q = 0; q < 8; ++q) ob[p - 11 + q] = 1.0f;         /* :734-737 */
-      ob[p - 3] = 0.0f; ob[p - 2] = 0.0f;                        /* :717-719 */
-      ob[p - 1] = 1.0f;                                          /* :747-749 */
+    ob[p++] = masked ? 0.0f : (va * cr_cos(rr)) / n_v;           /* :717-719 */
+    ob[p++] = masked ? 0.0f : (va * cr_sin(rr)) / n_v;
+    if (F & SIGMAENV_OBS_STEERING) ob[p++] = masked ? 0.0f : angle_eliminate_two_pi(sj[4]) / n_rot;   /* :699-706 */
+    if (!(F & SIGMAENV_OBS_NO_DIST_AGENTS)) ob[p++] = masked ? 1.0f : Drow[j] / n_dl;   /* :373-375, :747-749 */
+    if (F & SIGMAENV_OBS_REF_OTHERS) {                           /* :451-460, :721-729 */
+      for (int q = 0; q < NS; ++q) {
+        float ox, oy;
+        ego_transform(si[0], si[1], si[2], o->short_term[bj * NS * 2 + 2 * q], o->short_term[bj * NS * 2 + 2 * q + 1], &ox, &oy);
+        ob[p++] = masked ? 1.0f : ox / n_pos;
+        ob[p++] = masked ? 1.0f : oy / n_pos;
+      }
     }
   }
 }
@@ -680,6 +702,12 @@ static void auto_reset_env(oracle_t* o, int b, uint64_t seed, uint64_t counter, 
 
 /* ---- C-ABI twin --------------------------------------------------------------------------------------------------- */
 int sigmaenv_oracle_obs_dim(int32_t n_nearing) { return 1 + 2 * NS + 3 + n_nearing * 11; }
+int sigmaenv_oracle_obs_dim_ex(int32_t n_nearing, int32_t f) {   /* observation_provider_rt.py:803-925 */
+  int s = (f & SIGMAENV_OBS_STEERING) ? 1 : 0, r = (f & SIGMAENV_OBS_REF_OTHERS) ? 1 : 0;
+  int own = 1 + s + 2 * NS + ((f & SIGMAENV_OBS_NO_DIST_CENTER) ? 0 : 1) + 2;
+  int other = ((f & SIGMAENV_OBS_NO_VERTICES) ? 5 : 8) + 2 + s + ((f & SIGMAENV_OBS_NO_DIST_AGENTS) ? 0 : 1) + r * 2 * NS;
+  return own + n_nearing * other;
+}
 
 static void* xcalloc(size_t n, size_t sz) { return calloc(n ? n : 1, sz); }
 
@@ -694,7 +722,7 @@ int sigmaenv_oracle_create(const sigmaenv_config_t* cfg, const sigmaenv_map_t* m
   if (!o) return SIGMAENV_ENOMEM;
   o->cfg = *cfg;
   int B = o->B = cfg->n_envs, N = o->N = cfg->n_agents, K = o->K = cfg->n_nearing;
-  o->D = sigmaenv_oracle_obs_dim(K);
+  o->D = sigmaenv_oracle_obs_dim_ex(K, cfg->obs_flags);
   int np = o->n_paths = map->n_paths, S = map->stride_points;
   int maxc = 0;
   for (int p = 0; p < np; ++p) {

@@ -14,7 +14,7 @@ import ctypes as C
 import math
 import os
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 DIST_C2C, DIST_MTV = 0, 1
 REW_DISTANCE, REW_TTC, REW_EXACT_SPARSE, REW_HAS_SPARSE, REW_CBF, REW_CBF_QP = 1, 2, 4, 8, 16, 32
 CBF_MAX_CIRCLES = 4
@@ -49,7 +49,7 @@ class Config(C.Structure):
         ("threshold_near_other_agents_low", C.c_float), ("threshold_near_other_agents_high", C.c_float),
         ("ttc_low", C.c_float), ("ttc_high", C.c_float),
         ("penalty_deviate_from_cbf_vel", C.c_float), ("penalty_deviate_from_cbf_steer", C.c_float),
-        ("is_apply_mask", C.c_int32), ("distance_mask_agents", C.c_float), ("reset_agent_fixed_duration", C.c_float),
+        ("is_apply_mask", C.c_int32), ("distance_mask_agents", C.c_float), ("obs_flags", C.c_int32), ("reset_agent_fixed_duration", C.c_float),
     ]
 
 
@@ -103,8 +103,16 @@ def rew_flags_from_method(rew_method: str, is_solve_qp: bool = True) -> int:
     return f
 
 
-def obs_dim(n_nearing: int) -> int:
-    return 1 + 2 * N_SHORT_TERM + 3 + n_nearing * 11
+OBS_STEERING, OBS_REF_OTHERS, OBS_NO_VERTICES, OBS_NO_DIST_AGENTS, OBS_NO_DIST_CENTER = 1, 2, 4, 8, 16
+
+
+def obs_dim(n_nearing: int, obs_flags: int = 0) -> int:
+    """``sigmaenv_obs_dim_ex``: [own] speed, (steering), short-term path, (centre-line distance), two boundary distances; per observed
+    neighbour vertices (or position / rotation / length / width), velocity, (steering), (distance), (its short-term path)."""
+    s, r = int(bool(obs_flags & OBS_STEERING)), int(bool(obs_flags & OBS_REF_OTHERS))
+    own = 1 + s + 2 * N_SHORT_TERM + (0 if obs_flags & OBS_NO_DIST_CENTER else 1) + 2
+    other = (5 if obs_flags & OBS_NO_VERTICES else 8) + 2 + s + (0 if obs_flags & OBS_NO_DIST_AGENTS else 1) + r * 2 * N_SHORT_TERM
+    return own + n_nearing * other
 
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
@@ -112,6 +120,7 @@ DEFAULT_LIB = os.path.join(_PKG_DIR, "csrc", "libsigmaenv.so")
 
 _SIGS = {
     "obs_dim": (C.c_int, [C.c_int32]),
+    "obs_dim_ex": (C.c_int, [C.c_int32, C.c_int32]),
     "create": (C.c_int, [C.POINTER(Config), C.POINTER(Map), C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "destroy": (None, [C.c_void_p]),
     "last_error": (C.c_char_p, [C.c_void_p]),

@@ -1302,6 +1302,8 @@ struct sigmaenv {
   sigmaenv_cbf_config_t cbf_cfg{};
   void *cbf_seg4 = nullptr, *cbf_segl = nullptr, *cbf_cxy = nullptr, *cbf_u = nullptr, *cbf_kin = nullptr, *cbf_clf = nullptr, *cbf_safe = nullptr;
   int cbf_seg_stride = 0;
+  float* obs_var = nullptr;       // [B,N,D_pub]: the public observation buffer when cfg.obs_flags != 0 (sigmaenv_obs_variant.inc)
+  int D_pub = 0;                  // its row width (= D for the default flags)
   int32_t* cbf_groups = nullptr;  // [B,N] group index of every vehicle (grouped CBF-QPs), formed by the first sigmaenv_cbf_qp call
   bool cbf_groups_valid = false;
   std::string err;
@@ -1334,6 +1336,12 @@ static void dev_free(sigmaenv* h, void* p) {
 }
 
 extern "C" int sigmaenv_obs_dim(int32_t n_nearing) { return 1 + 2 * NS + 3 + n_nearing * 11; }
+extern "C" int sigmaenv_obs_dim_ex(int32_t n_nearing, int32_t f) {  // observation_provider_rt.py:803-925
+  const int s = (f & SIGMAENV_OBS_STEERING) ? 1 : 0, r = (f & SIGMAENV_OBS_REF_OTHERS) ? 1 : 0;
+  const int own = 1 + s + 2 * NS + ((f & SIGMAENV_OBS_NO_DIST_CENTER) ? 0 : 1) + 2;
+  const int other = ((f & SIGMAENV_OBS_NO_VERTICES) ? 5 : 8) + 2 + s + ((f & SIGMAENV_OBS_NO_DIST_AGENTS) ? 0 : 1) + r * 2 * NS;
+  return own + n_nearing * other;
+}
 
 extern "C" const char* sigmaenv_last_error(const sigmaenv_t* h) { return h ? h->err.c_str() : "null handle"; }
 
@@ -1372,7 +1380,8 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
   h->device = device_id;
   h->stream = reinterpret_cast<hipStream_t>(hip_stream);
   const int B = h->B = cfg->n_envs, N = h->N = cfg->n_agents, K = h->K = cfg->n_nearing;
-  h->D = sigmaenv_obs_dim(K);
+  h->D = sigmaenv_obs_dim(K);  // the fused kernels' own (default) row
+  h->D_pub = sigmaenv_obs_dim_ex(K, cfg->obs_flags);
   const int np = h->n_paths = map->n_paths, S = map->stride_points;
   for (int p = 0; p < np; ++p) {
     if (map->n_center[p] < 2 || map->n_left[p] < 2 || map->n_right[p] < 2 || map->n_center[p] > S || map->n_left[p] > S || map->n_right[p] > S) {
@@ -1548,6 +1557,11 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
     h->bufs[sp.id] = *sp.p;
     h->buf_bytes[sp.id] = sp.bytes;
   }
+  if (cfg->obs_flags != 0) {  // non-default observation switches: the public buffer is written by the variant kernel
+    ALLOC(h->obs_var, BN * h->D_pub * 4);
+    h->bufs[SIGMAENV_BUF_OBS] = h->obs_var;
+    h->buf_bytes[SIGMAENV_BUF_OBS] = BN * h->D_pub * 4;
+  }
   ALLOC(g.reset_mask, (size_t)B * 8);
   ALLOC(g.reset_full, (size_t)B);
   g.slab = nullptr;
@@ -1638,11 +1652,21 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
   return SIGMAENV_OK;
 }
 
+#include "sigmaenv_obs_variant.inc"
+// after every launch that refreshed the observations: the public row of the non-default observation switches
+static int launch_obs_variant(sigmaenv* h) {
+  if (!h->obs_var) return SIGMAENV_OK;
+  const size_t BN = (size_t)h->B * h->N;
+  hipLaunchKernelGGL(obsvar::sigmaenv_observe_variant_kernel, dim3((unsigned)((BN + 255) / 256)), dim3(256), 0, h->stream, h->cfg, h->buf, h->obs_var, h->D_pub);
+  HIPCHK(h, hipGetLastError());
+  return SIGMAENV_OK;
+}
+
 static int launch_derive(sigmaenv* h, int with_obs) {
   // resets touch few envs: one env per workgroup (G = 1) keeps the untouched ones out of the way
   hipLaunchKernelGGL(sigmaenv_reset_derive_kernel, dim3(h->B), dim3(h->reset_block), h->smem_bytes, h->stream, h->cfg, h->map, h->buf, with_obs, 1);
   HIPCHK(h, hipGetLastError());
-  return SIGMAENV_OK;
+  return with_obs ? launch_obs_variant(h) : SIGMAENV_OK;
 }
 
 extern "C" int sigmaenv_reset(sigmaenv_t* h, int32_t n, const int32_t* env_idx, const int32_t* agent_idx, const int32_t* path_ids,
@@ -1722,7 +1746,7 @@ static int launch_step(sigmaenv* h, const float* actions, uint64_t seed, uint64_
   }
   HIPCHK(h, hipGetLastError());
   if (slot >= 0) HIPCHK(h, hipEventRecord(h->ev_pool[slot].second, h->stream));
-  return SIGMAENV_OK;
+  return launch_obs_variant(h);
 }
 
 extern "C" int sigmaenv_step(sigmaenv_t* h, const float* actions) { return launch_step(h, actions, 0, 0, 0, 0); }
@@ -1752,7 +1776,7 @@ extern "C" int sigmaenv_observe(sigmaenv_t* h) {
   HIPCHK(h, hipSetDevice(h->device));
   hipLaunchKernelGGL(sigmaenv_observe_kernel, dim3(h->grid), dim3(h->block), h->smem_bytes, h->stream, h->cfg, h->buf, h->G);
   HIPCHK(h, hipGetLastError());
-  return SIGMAENV_OK;
+  return launch_obs_variant(h);
 }
 
 extern "C" int sigmaenv_auto_reset(sigmaenv_t* h, uint64_t seed, uint64_t counter, int32_t path_first, int32_t path_count) {
@@ -1761,7 +1785,7 @@ extern "C" int sigmaenv_auto_reset(sigmaenv_t* h, uint64_t seed, uint64_t counte
   hipLaunchKernelGGL(sigmaenv_auto_reset_kernel, dim3(h->B), dim3(h->reset_block), h->smem_bytes, h->stream, h->cfg, h->map, h->buf, seed, counter,
                      (int)path_first, (int)path_count, 1);
   HIPCHK(h, hipGetLastError());
-  return SIGMAENV_OK;
+  return launch_obs_variant(h);
 }
 
 extern "C" int sigmaenv_get(sigmaenv_t* h, sigmaenv_buf_t which, void** dev_ptr, size_t* bytes) {
@@ -1782,6 +1806,7 @@ extern "C" int sigmaenv_sync(sigmaenv_t* h) {
 // to dev_ptr ([B, N*(D+1)+1]); the caller rotates the pointer through its rollout buffer.  NULL disables it.
 extern "C" int sigmaenv_set_slab(sigmaenv_t* h, void* dev_ptr) {
   if (!h) return SIGMAENV_EINVAL;
+  if (dev_ptr && h->obs_var) { h->err = "set_slab: the rollout record holds the default observation row; not available with obs_flags != 0"; return SIGMAENV_EINVAL; }
   h->buf.slab = reinterpret_cast<float*>(dev_ptr);
   return SIGMAENV_OK;
 }

@@ -80,6 +80,22 @@ class Parameters:
             return cls(**json.load(f))
 
 
+def obs_flags(p: Parameters) -> int:
+    """``sigmaenv_config_t.obs_flags`` of the observation switches (observation_provider_rt.py:803-925)."""
+    f = 0
+    if p.is_obs_steering:
+        f |= capi.OBS_STEERING
+    if p.is_observe_ref_path_other_agents:
+        f |= capi.OBS_REF_OTHERS
+    if not p.is_observe_vertices:
+        f |= capi.OBS_NO_VERTICES
+    if not p.is_observe_distance_to_agents:
+        f |= capi.OBS_NO_DIST_AGENTS
+    if not p.is_observe_distance_to_center_line:
+        f |= capi.OBS_NO_DIST_CENTER
+    return f
+
+
 def check_supported(p: Parameters) -> None:
     """Raise for observation/feature flags the fused step does not implement (fail loudly, never silently differ)."""
     bad = []
@@ -87,21 +103,13 @@ def check_supported(p: Parameters) -> None:
         bad.append("is_ego_view=False (bird view)")
     if not p.is_partial_observation:
         bad.append("is_partial_observation=False")
-    if not p.is_observe_vertices:
-        bad.append("is_observe_vertices=False")
-    if not p.is_observe_distance_to_agents:
-        bad.append("is_observe_distance_to_agents=False")
     if not p.is_observe_distance_to_boundaries:
         bad.append("is_observe_distance_to_boundaries=False")
-    if not p.is_observe_distance_to_center_line:
-        bad.append("is_observe_distance_to_center_line=False")
     # is_apply_mask: in ego view (the only view built) only the DISTANCE criterion is live in the reference -- the lanelet of every agent
     # (MapManager.determine_current_lanelet) is only computed in the bird-view branch of update_state (observation_provider_rt.py:537-588),
     # so current_lanelet_idx stays empty and determine_masked_agents_by_lanelets masks nobody (map_manager.py:21,102-118) on every map
-    if p.is_obs_steering:
-        bad.append("is_obs_steering=True")
-    if p.is_observe_ref_path_other_agents:
-        bad.append("is_observe_ref_path_other_agents=True")
+    # built through the separate observation kernel (capi.OBS_*): is_obs_steering, is_observe_ref_path_other_agents, is_observe_vertices=False,
+    # is_observe_distance_to_agents=False, is_observe_distance_to_center_line=False
     if p.n_points_short_term != capi.N_SHORT_TERM:
         bad.append(f"n_points_short_term={p.n_points_short_term} (only {capi.N_SHORT_TERM})")
     if p.is_challenging_initial_state_buffer:
@@ -184,6 +192,7 @@ def make_config(p: Parameters, map_table, n_envs: int, make_world_scenario_type:
     c.is_apply_mask = int(bool(p.is_apply_mask))
     c.distance_mask_agents = A["length"] * 5  # road_traffic.py:663
     c.reset_agent_fixed_duration = float(p.reset_agent_fixed_duration or 0.0)  # road_traffic.py:1388-1397
+    c.obs_flags = obs_flags(p)
     c.penalty_deviate_from_cbf_vel = c.penalty_deviate_from_cbf_steer = -5 / r_p_normalizer  # road_traffic.py:238-243
     c.ttc_low = p.ttc_low if p.ttc_low is not None else 0
     c.ttc_high = p.ttc_high if p.ttc_high is not None else 3.75

@@ -662,6 +662,13 @@ TRAJS = {
                              is_use_mtv_distance=False, rew_method="distance", reset_agent_fixed_duration=0.5),
     "intersection4_fixed_testing": dict(T=48, B=3, seed=28, mode_pattern=[1, 0, 1], n_agents=4, scenario_type="intersection_1", dt=0.1,
                                         is_use_mtv_distance=False, rew_method="distance", is_testing_mode=True, reset_agent_fixed_duration=1.5),
+    # non-default observation switches (observation_provider_rt.py:803-925): steering + the neighbours' reference paths (with the distance
+    # mask on); position / rotation / length / width instead of vertices, without the distance columns
+    "cpm8_obs_steer_ref": dict(T=24, B=3, seed=29, mode_pattern=[1, 0, 1], n_agents=8, scenario_type="cpm_entire", dt=0.05, is_use_mtv_distance=False,
+                               rew_method="distance", is_apply_mask=True, is_obs_steering=True, is_observe_ref_path_other_agents=True),
+    "intersection4_obs_novert": dict(T=32, B=3, seed=30, mode_pattern=[1, 1, 0], n_agents=4, scenario_type="intersection_1", dt=0.1,
+                                     is_use_mtv_distance=True, rew_method="ttc", is_observe_vertices=False, is_observe_distance_to_agents=False,
+                                     is_observe_distance_to_center_line=False, is_obs_steering=True),
     # BASELINE config 4: 32 agents on the on-ramp map.  The reference's rejection sampler cannot place them, so the
     # start is injected (Parameters.predefined_ref_path_idx / init_state); vehicles overlap from the first step on, every env is "done" at
     # every step and none is reset: non-reset steps only, as the survey prescribes for this configuration

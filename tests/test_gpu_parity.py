@@ -664,3 +664,56 @@ def test_single_agent_and_odd_observation_width(scen, N):
     assert dev.env.D == 4 + 6 + 11 * min(2, N - 1)
     dev.close()
     ora.close()
+
+
+OBS_VARIANTS = [
+    dict(is_obs_steering=True),
+    dict(is_observe_ref_path_other_agents=True, is_apply_mask=True),
+    dict(is_observe_vertices=False),
+    dict(is_observe_distance_to_agents=False, is_observe_distance_to_center_line=False),
+    dict(is_obs_steering=True, is_observe_ref_path_other_agents=True, is_observe_vertices=False, is_observe_distance_to_agents=False,
+         is_observe_distance_to_center_line=False, is_apply_mask=True),
+]
+
+
+@pytest.mark.parametrize("kw", OBS_VARIANTS)
+def test_observation_variants_hip_vs_oracle(kw):
+    """Non-default observation switches (capi.OBS_*, observation_provider_rt.py:803-925): the public observation buffer has
+    sigmaenv_obs_dim_ex columns and equals the oracle's row (pinned on two reference trajectories, tests/golden) through steps, device-side
+    resets and sigmaenv_observe; every other buffer is unaffected; the rollout record is refused."""
+    import torch
+
+    N, B = 8, 40
+    base = dict(n_agents=N, scenario_type="cpm_entire", is_use_mtv_distance=False, rew_method="distance", dt=0.05, is_apply_mask=False, is_obs_noise=False,
+                max_steps=9)
+    base.update(kw)
+    p = Parameters(**base)
+    mp = load_map("cpm_entire")
+    cfg = make_config(p, mp, B)
+    assert cfg.obs_flags != 0
+    dev, ora = _hip_env(cfg, mp), ob.OracleEnv(cfg, mp)
+    D = capi.obs_dim(2, cfg.obs_flags)
+    assert dev.D == D == ora.D and dev.env.lib.obs_dim_ex(2, cfg.obs_flags) == D and D != 32
+    dev.env.buffer(capi.BUF_DONE).fill_(1)
+    ora.get(capi.BUF_DONE, copy=False)[:] = 1
+    pf, pc = mp.list_first[0], mp.list_count[0]
+    dev.auto_reset(7, 0, pf, pc)
+    ora.auto_reset(7, 0, pf, pc)
+    _compare_all(dev, ora, "after initial reset")
+    rng = np.random.default_rng(77)
+    for t in range(8):
+        act = np.stack([rng.uniform(-0.2, 1.3, (B, N)), rng.uniform(-0.7, 0.7, (B, N))], axis=-1).astype(np.float32)
+        dev.step(act)
+        ora.step(act)
+        _compare_all(dev, ora, f"step {t}")
+        assert dev.get(capi.BUF_OBS).shape == (B, N, D)
+        dev.auto_reset(7, t + 1, pf, pc)
+        ora.auto_reset(7, t + 1, pf, pc)
+        _compare_all(dev, ora, f"reset after step {t}")
+    dev.env.observe()
+    ora.observe() if hasattr(ora, "observe") else None
+    _compare_all(dev, ora, "observe")
+    with pytest.raises(RuntimeError):
+        dev.env.set_slab(torch.zeros((B, N * (D + 1) + 1), device="cuda"))
+    dev.close()
+    ora.close()
