@@ -1,3 +1,5 @@
 cd /root/repo
-timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | tail -4
-for i in 1 2; do timeout 300 python bench.py --steps 512 --warmup 64 --cpu-seconds 0 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['config']['one_stream']['ms_per_step'])"; done
+rm -rf gpurun_out/r02_g/trace gpurun_out/r02_g/pmc
+bash tools/profile_round.sh r02_g > /dev/null 2>&1
+cat gpurun_out/r02_g/r02_g_kernel_stats.csv | head -3
+timeout 300 python tools/phase_timestamps.py > gpurun_out/r02_g/r02_g_phase_cycles.txt 2>&1; tail -9 gpurun_out/r02_g/r02_g_phase_cycles.txt
