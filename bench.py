@@ -470,7 +470,7 @@ def main():
         },
     }
     run.close()
-    if S > 1 and not args.no_one_stream:
+    if S > 1 and not args.no_one_stream and world == 1 and not use_dist:
         # the same workload with ONE launch per step (no env shards): what the kernel does without the host-side overlap of two launches
         import copy
 
