@@ -20,7 +20,8 @@ TRAJ_NAMES = ["cpm16_c2c", "cpm16_mtv", "intersection4_c2c", "onramp6_mtv", "cpm
               "cpm16_cbf", "intersection4_cbf", "onramp4_cbf_clf", "cpm16_mask", "intersection4_mask", "roundabout6_mask", "onramp32_c2c",
               "cpm8_fixed_reset", "intersection4_fixed_testing", "cpm8_obs_steer_ref", "intersection4_obs_novert"]
 # The reference rounds the pseudo distance to fp16 and differentiates it numerically (pseudo_distance.py:118, cbf_qp.py:624-644): a
-# one-ulp difference in a float32 circle centre (torch's SLEEF cos/sin vs the correctly rounded ones of oracle and HIP path) can flip
+# one-ulp difference in a float32 circle centre (torch's cos / sin -- a closed vector math library, within 1 ulp of the correctly rounded
+# value the oracle and the HIP path compute and NOT restatable, see include/sigma_trig_f32.h -- ) can flip
 # an fp16 rounding and move a margin by up to ~5e-3.  Against the reference goldens the CBF quantities are therefore checked as:
 # all but a fraction CBF_OUTLIER_FRAC within CBF_TOL (scaled by max(1, |value|)), every entry within CBF_OUTLIER_TOL.
 CBF_TOL = 2e-6
