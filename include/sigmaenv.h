@@ -166,6 +166,9 @@ int sigmaenv_obs_dim(int32_t n_nearing);
 #define SIGMAENV_OBS_NO_VERTICES 4     /* Parameters.is_observe_vertices == False */
 #define SIGMAENV_OBS_NO_DIST_AGENTS 8  /* Parameters.is_observe_distance_to_agents == False */
 #define SIGMAENV_OBS_NO_DIST_CENTER 16 /* Parameters.is_observe_distance_to_center_line == False */
+#define SIGMAENV_OBS_BIRD_VIEW 32      /* Parameters.is_ego_view == False (:537-575, :855-884): world-frame positions / vertices / reference points divided by
+                                        * (world_x_dim, world_y_dim), velocities as (vx, vy) / max_speed, rotations wrapped / 2 pi; [own] gains position 2 and
+                                        * rotation 1 in front, its velocity has both components */
 int sigmaenv_obs_dim_ex(int32_t n_nearing, int32_t obs_flags);
 
 /* device_id: HIP device ordinal.  hip_stream: hipStream_t to enqueue on (NULL = the device's default stream). */

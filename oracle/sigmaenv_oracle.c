@@ -468,8 +468,15 @@ static void agent_observation(oracle_t* o, int b, int i) {
     near[k] = bj;
   }
   int p = 0;
-  /* [own] longitudinal speed: past_vel[b,i,i,0] = ||v_i|| * cos(wrap(psi_i - psi_i)) / v  (:441-449, :885-887) */
-  {
+  const int bird = (F & SIGMAENV_OBS_BIRD_VIEW) != 0;            /* is_ego_view == False: world frame, normalizers.pos_world (:537-575) */
+  const float nwx = c->world_x_dim, nwy = c->world_y_dim;
+#define OBS_POINT(tx, ty, ox, oy) do { if (bird) { ox = (tx) / nwx; oy = (ty) / nwy; } else { float ex_, ey_; ego_transform(si[0], si[1], si[2], (tx), (ty), &ex_, &ey_); ox = ex_ / n_pos; oy = ey_ / n_pos; } } while (0)
+  if (bird) {                                                    /* [own] position and rotation (:862-877) */
+    ob[p++] = si[0] / nwx; ob[p++] = si[1] / nwy;
+    ob[p++] = angle_eliminate_two_pi(si[2]) / n_rot;
+    ob[p++] = si[5] / n_v; ob[p++] = si[6] / n_v;                /* [own] velocity, both components (:547-549, :878-880) */
+  } else {
+    /* [own] longitudinal speed: past_vel[b,i,i,0] = ||v_i|| * cos(wrap(psi_i - psi_i)) / v  (:441-449, :885-887) */
     float rr = angle_eliminate_two_pi(si[2] - si[2]);
     ob[p++] = (norm2(si[5], si[6]) * cr_cos(rr)) / n_v;
   }
@@ -477,9 +484,9 @@ static void agent_observation(oracle_t* o, int b, int i) {
   /* [own] short-term reference path in the ego frame (:451-460, :893-897) */
   for (int k = 0; k < NS; ++k) {
     float ox, oy;
-    ego_transform(si[0], si[1], si[2], o->short_term[bi * NS * 2 + 2 * k], o->short_term[bi * NS * 2 + 2 * k + 1], &ox, &oy);
-    ob[p++] = ox / n_pos;
-    ob[p++] = oy / n_pos;
+    OBS_POINT(o->short_term[bi * NS * 2 + 2 * k], o->short_term[bi * NS * 2 + 2 * k + 1], ox, oy);
+    ob[p++] = ox;
+    ob[p++] = oy;
   }
   /* [own] distances, all normalised by distance_lanelet (:373-389, :898-922) */
   if (!(F & SIGMAENV_OBS_NO_DIST_CENTER)) ob[p++] = o->dist_ref[bi] / n_dl;
@@ -499,34 +506,40 @@ static void agent_observation(oracle_t* o, int b, int i) {
     if (!(F & SIGMAENV_OBS_NO_VERTICES)) {
       for (int q = 0; q < 4; ++q) {
         float ox, oy;
-        ego_transform(si[0], si[1], si[2], vj[2 * q], vj[2 * q + 1], &ox, &oy);
-        ob[p++] = masked ? 1.0f : ox / n_pos;                    /* :734-737 */
-        ob[p++] = masked ? 1.0f : oy / n_pos;
+        OBS_POINT(vj[2 * q], vj[2 * q + 1], ox, oy);
+        ob[p++] = masked ? 1.0f : ox;                            /* :734-737 */
+        ob[p++] = masked ? 1.0f : oy;
       }
     } else {
       float ox, oy;
-      ego_transform(si[0], si[1], si[2], sj[0], sj[1], &ox, &oy);          /* :429-434 */
-      ob[p++] = masked ? 1.0f : ox / n_pos;                      /* :672-680 */
-      ob[p++] = masked ? 1.0f : oy / n_pos;
-      ob[p++] = masked ? 0.0f : angle_eliminate_two_pi(sj[2] - si[2]) / n_rot;   /* :437, :683-688 */
+      OBS_POINT(sj[0], sj[1], ox, oy);                           /* :429-434 */
+      ob[p++] = masked ? 1.0f : ox;                              /* :672-680 */
+      ob[p++] = masked ? 1.0f : oy;
+      ob[p++] = masked ? 0.0f : (bird ? angle_eliminate_two_pi(sj[2]) : angle_eliminate_two_pi(sj[2] - si[2])) / n_rot;   /* :437, :551-553, :683-688 */
       ob[p++] = c->length / n_da;                                /* :387-389, :691-694 */
       ob[p++] = c->width / n_da;                                 /* :390-391, :695-698 */
     }
-    float rr = angle_eliminate_two_pi(sj[2] - si[2]);           /* :439 */
-    float va = norm2(sj[5], sj[6]);                              /* :444 */
-    ob[p++] = masked ? 0.0f : (va * cr_cos(rr)) / n_v;           /* :717-719 */
-    ob[p++] = masked ? 0.0f : (va * cr_sin(rr)) / n_v;
+    if (bird) {
+      ob[p++] = masked ? 0.0f : sj[5] / n_v;                     /* :547-549 */
+      ob[p++] = masked ? 0.0f : sj[6] / n_v;
+    } else {
+      float rr = angle_eliminate_two_pi(sj[2] - si[2]);         /* :439 */
+      float va = norm2(sj[5], sj[6]);                            /* :444 */
+      ob[p++] = masked ? 0.0f : (va * cr_cos(rr)) / n_v;         /* :717-719 */
+      ob[p++] = masked ? 0.0f : (va * cr_sin(rr)) / n_v;
+    }
     if (F & SIGMAENV_OBS_STEERING) ob[p++] = masked ? 0.0f : angle_eliminate_two_pi(sj[4]) / n_rot;   /* :699-706 */
     if (!(F & SIGMAENV_OBS_NO_DIST_AGENTS)) ob[p++] = masked ? 1.0f : Drow[j] / n_dl;   /* :373-375, :747-749 */
     if (F & SIGMAENV_OBS_REF_OTHERS) {                           /* :451-460, :721-729 */
       for (int q = 0; q < NS; ++q) {
         float ox, oy;
-        ego_transform(si[0], si[1], si[2], o->short_term[bj * NS * 2 + 2 * q], o->short_term[bj * NS * 2 + 2 * q + 1], &ox, &oy);
-        ob[p++] = masked ? 1.0f : ox / n_pos;
-        ob[p++] = masked ? 1.0f : oy / n_pos;
+        OBS_POINT(o->short_term[bj * NS * 2 + 2 * q], o->short_term[bj * NS * 2 + 2 * q + 1], ox, oy);
+        ob[p++] = masked ? 1.0f : ox;
+        ob[p++] = masked ? 1.0f : oy;
       }
     }
   }
+#undef OBS_POINT
 }
 
 /* done(), road_traffic.py:1368-1487 (flags only; the resets it triggers are requests to the host) */
@@ -704,7 +717,7 @@ static void auto_reset_env(oracle_t* o, int b, uint64_t seed, uint64_t counter, 
 int sigmaenv_oracle_obs_dim(int32_t n_nearing) { return 1 + 2 * NS + 3 + n_nearing * 11; }
 int sigmaenv_oracle_obs_dim_ex(int32_t n_nearing, int32_t f) {   /* observation_provider_rt.py:803-925 */
   int s = (f & SIGMAENV_OBS_STEERING) ? 1 : 0, r = (f & SIGMAENV_OBS_REF_OTHERS) ? 1 : 0;
-  int own = 1 + s + 2 * NS + ((f & SIGMAENV_OBS_NO_DIST_CENTER) ? 0 : 1) + 2;
+  int own = 1 + s + 2 * NS + ((f & SIGMAENV_OBS_NO_DIST_CENTER) ? 0 : 1) + 2 + ((f & SIGMAENV_OBS_BIRD_VIEW) ? 4 : 0);
   int other = ((f & SIGMAENV_OBS_NO_VERTICES) ? 5 : 8) + 2 + s + ((f & SIGMAENV_OBS_NO_DIST_AGENTS) ? 0 : 1) + r * 2 * NS;
   return own + n_nearing * other;
 }

@@ -1338,7 +1338,7 @@ static void dev_free(sigmaenv* h, void* p) {
 extern "C" int sigmaenv_obs_dim(int32_t n_nearing) { return 1 + 2 * NS + 3 + n_nearing * 11; }
 extern "C" int sigmaenv_obs_dim_ex(int32_t n_nearing, int32_t f) {  // observation_provider_rt.py:803-925
   const int s = (f & SIGMAENV_OBS_STEERING) ? 1 : 0, r = (f & SIGMAENV_OBS_REF_OTHERS) ? 1 : 0;
-  const int own = 1 + s + 2 * NS + ((f & SIGMAENV_OBS_NO_DIST_CENTER) ? 0 : 1) + 2;
+  const int own = 1 + s + 2 * NS + ((f & SIGMAENV_OBS_NO_DIST_CENTER) ? 0 : 1) + 2 + ((f & SIGMAENV_OBS_BIRD_VIEW) ? 4 : 0);
   const int other = ((f & SIGMAENV_OBS_NO_VERTICES) ? 5 : 8) + 2 + s + ((f & SIGMAENV_OBS_NO_DIST_AGENTS) ? 0 : 1) + r * 2 * NS;
   return own + n_nearing * other;
 }

@@ -93,14 +93,18 @@ def obs_flags(p: Parameters) -> int:
         f |= capi.OBS_NO_DIST_AGENTS
     if not p.is_observe_distance_to_center_line:
         f |= capi.OBS_NO_DIST_CENTER
+    if not p.is_ego_view:
+        f |= capi.OBS_BIRD_VIEW
     return f
 
 
 def check_supported(p: Parameters) -> None:
     """Raise for observation/feature flags the fused step does not implement (fail loudly, never silently differ)."""
     bad = []
-    if not p.is_ego_view:
-        bad.append("is_ego_view=False (bird view)")
+    if not p.is_ego_view and p.is_apply_mask:
+        # bird view itself is built (capi.OBS_BIRD_VIEW); with is_apply_mask the reference then also masks by lanelet relation, which needs the
+        # parsers' neighbouring-lanelet tables (observation_provider_rt.py:577-588, map_manager.py:41-118): not built
+        bad.append("is_ego_view=False together with is_apply_mask=True (lanelet-relation mask)")
     if not p.is_partial_observation:
         bad.append("is_partial_observation=False")
     if not p.is_observe_distance_to_boundaries:

@@ -669,6 +669,12 @@ TRAJS = {
     "intersection4_obs_novert": dict(T=32, B=3, seed=30, mode_pattern=[1, 1, 0], n_agents=4, scenario_type="intersection_1", dt=0.1,
                                      is_use_mtv_distance=True, rew_method="ttc", is_observe_vertices=False, is_observe_distance_to_agents=False,
                                      is_observe_distance_to_center_line=False, is_obs_steering=True),
+    # bird view (is_ego_view=False): world-frame observation normalised by the world size, own position / rotation in front
+    "cpm8_birdview": dict(T=24, B=3, seed=31, mode_pattern=[1, 0, 1], n_agents=8, scenario_type="cpm_entire", dt=0.05, is_use_mtv_distance=False,
+                          rew_method="distance", is_ego_view=False, is_apply_mask=False, is_observe_ref_path_other_agents=True),
+    "intersection4_birdview_novert": dict(T=24, B=3, seed=32, mode_pattern=[1, 1, 0], n_agents=4, scenario_type="intersection_1", dt=0.1,
+                                          is_use_mtv_distance=True, rew_method="ttc", is_ego_view=False, is_apply_mask=False, is_observe_vertices=False,
+                                          is_obs_steering=True),
     # BASELINE config 4: 32 agents on the on-ramp map.  The reference's rejection sampler cannot place them, so the
     # start is injected (Parameters.predefined_ref_path_idx / init_state); vehicles overlap from the first step on, every env is "done" at
     # every step and none is reset: non-reset steps only, as the survey prescribes for this configuration
