@@ -42,10 +42,12 @@ def test_rew_flags_follow_the_reference_string_tests():
 def test_unsupported_configurations_fail_loudly():
     ok = Parameters(is_apply_mask=False)
     check_supported(ok)
-    for kw in (dict(is_apply_mask=True, is_ego_view=False), dict(is_apply_mask=False, is_ego_view=False), dict(is_apply_mask=False, is_using_cbf_training=True, is_grouping_agents=True, is_solve_qp=False),
+    for kw in (dict(is_apply_mask=True, is_ego_view=False), dict(is_apply_mask=False, is_partial_observation=False), dict(is_apply_mask=False, is_using_cbf_training=True, is_grouping_agents=True, is_solve_qp=False),
                dict(is_apply_mask=False, n_points_short_term=5)):
         with pytest.raises(NotImplementedError):
             check_supported(Parameters(**kw))
+    check_supported(Parameters(is_apply_mask=False, is_ego_view=False))  # bird view without the lanelet-relation mask
+    check_supported(Parameters(is_apply_mask=False, is_obs_steering=True, is_observe_vertices=False))  # observation switches
     check_supported(Parameters(is_apply_mask=True, scenario_type="cpm_entire"))  # the reference's default (distance mask)
     check_supported(Parameters(is_apply_mask=True, scenario_type="intersection_1"))
     check_supported(Parameters(is_apply_mask=False, is_using_cbf_testing=True))  # CBF-QP safety filter at test time
