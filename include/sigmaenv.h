@@ -169,6 +169,9 @@ int sigmaenv_obs_dim(int32_t n_nearing);
 #define SIGMAENV_OBS_BIRD_VIEW 32      /* Parameters.is_ego_view == False (:537-575, :855-884): world-frame positions / vertices / reference points divided by
                                         * (world_x_dim, world_y_dim), velocities as (vx, vy) / max_speed, rotations wrapped / 2 pi; [own] gains position 2 and
                                         * rotation 1 in front, its velocity has both components */
+#define SIGMAENV_OBS_BOUNDARY_POINTS 64 /* Parameters.is_observe_distance_to_boundaries == False: instead of the two boundary distances, [own] carries the 5 points
+                                        * of each boundary around its closest point (world_state_rt.py:686-724: indices closest - 2 ... closest + 2 with the loop
+                                        * rule of get_short_term_reference_path; a negative index addresses the padded polyline from its end, as torch does) */
 int sigmaenv_obs_dim_ex(int32_t n_nearing, int32_t obs_flags);
 
 /* device_id: HIP device ordinal.  hip_stream: hipStream_t to enqueue on (NULL = the device's default stream). */

@@ -48,6 +48,8 @@ typedef struct sigmaenv_oracle {
   int32_t *path, *closest, *nearing, *timer;
   uint8_t *col_agents, *col_flags, *done;
   sigmaenv_cbf_config_t cbf;    /* sigmaenv_oracle_cbf_attach */
+  uint8_t* fresh;               /* [B,N] 1: the agent was (re)placed and has not been stepped since (the boundary points of the observation
+                                 * are taken with another index shift then, world_state_rt.py:531-576 vs :686-724) */
   int32_t* cbf_groups;          /* [B,N] group index of every vehicle (grouped CBF-QPs), formed at the first sigmaenv_oracle_cbf_qp call */
   int cbf_groups_valid;
   float *seg_left, *seg_right;  /* [n_paths][seg_stride][5] */
@@ -490,10 +492,32 @@ static void agent_observation(oracle_t* o, int b, int i) {
   }
   /* [own] distances, all normalised by distance_lanelet (:373-389, :898-922) */
   if (!(F & SIGMAENV_OBS_NO_DIST_CENTER)) ob[p++] = o->dist_ref[bi] / n_dl;
-  float ml = INFINITY, mr = INFINITY;
-  for (int q = 0; q < 5; ++q) { ml = fminf(ml, o->dist_left[bi * 5 + q]); mr = fminf(mr, o->dist_right[bi * 5 + q]); }
-  ob[p++] = ml / n_dl;
-  ob[p++] = mr / n_dl;
+  if (F & SIGMAENV_OBS_BOUNDARY_POINTS) {
+    /* [own] the 5 points of each boundary around its closest point instead of the distances (:905-922; world_state_rt.py:686-724:
+     * get_short_term_reference_path with sample_interval 1, n_points_shift -2 on the PADDED boundary polyline, the loop rule with the
+     * centre line's point count; a negative index counts from the end of the padded tensor) */
+    int path = o->path[bi * 4];
+    int n = o->n_center[path], loop = o->is_loop[path] != 0;
+    for (int side = 0; side < 2; ++side) {
+      const float* poly = (side ? o->right : o->left) + (size_t)path * o->P * 2;
+      int cp = o->closest[bi * 3 + 1 + side];
+      const int shift = o->fresh[bi] ? 1 : -2;                   /* n_points_shift: 1 at a reset (:531-576), -2 in update_distances (:686-724) */
+      for (int k = 0; k < 5; ++k) {
+        int id = k + cp + shift;
+        if (loop && id >= n - 1) id = (id + 1) % n;
+        if (id < 0) id += o->P;
+        float ox, oy;
+        OBS_POINT(poly[2 * id], poly[2 * id + 1], ox, oy);
+        ob[p++] = ox;
+        ob[p++] = oy;
+      }
+    }
+  } else {
+    float ml = INFINITY, mr = INFINITY;
+    for (int q = 0; q < 5; ++q) { ml = fminf(ml, o->dist_left[bi * 5 + q]); mr = fminf(mr, o->dist_right[bi * 5 + q]); }
+    ob[p++] = ml / n_dl;
+    ob[p++] = mr / n_dl;
+  }
   /* [others] per observed neighbour (:803-853): vertices (8) -- or position (2), relative rotation, length, width --, velocity (2), steering,
    * distance, its short-term reference path; masked by distance (:638-749): positions / vertices / reference path / distance := 1,
    * rotation / steering / velocity := 0 (lengths and widths are not masked) */
@@ -578,6 +602,7 @@ static void step_env(oracle_t* o, int b, const float* actions) {
   int N = o->N;
   for (int i = 0; i < N; ++i) {
     size_t bi = (size_t)b * N + i;
+    o->fresh[bi] = 0;
     bicycle_step(&o->cfg, o->state + bi * 8, actions + bi * 2, o->action + bi * 2);
   }
   float* RI = o->reward_info;
@@ -625,6 +650,7 @@ static void step_env(oracle_t* o, int b, const float* actions) {
 /* reset_init_distances_and_short_term_ref_path for one agent, world_state_rt.py:422-529: vertices first, then corners */
 static void reset_agent_derived(oracle_t* o, int b, int i) {
   size_t bi = (size_t)b * o->N + i;
+  o->fresh[bi] = 1;
   const float* s = o->state + bi * 8;
   rect_vertices(&o->cfg, s[0], s[1], s[2], o->vertices + bi * 10);
   agent_distances(o, b, i);
@@ -717,7 +743,7 @@ static void auto_reset_env(oracle_t* o, int b, uint64_t seed, uint64_t counter, 
 int sigmaenv_oracle_obs_dim(int32_t n_nearing) { return 1 + 2 * NS + 3 + n_nearing * 11; }
 int sigmaenv_oracle_obs_dim_ex(int32_t n_nearing, int32_t f) {   /* observation_provider_rt.py:803-925 */
   int s = (f & SIGMAENV_OBS_STEERING) ? 1 : 0, r = (f & SIGMAENV_OBS_REF_OTHERS) ? 1 : 0;
-  int own = 1 + s + 2 * NS + ((f & SIGMAENV_OBS_NO_DIST_CENTER) ? 0 : 1) + 2 + ((f & SIGMAENV_OBS_BIRD_VIEW) ? 4 : 0);
+  int own = 1 + s + 2 * NS + ((f & SIGMAENV_OBS_NO_DIST_CENTER) ? 0 : 1) + ((f & SIGMAENV_OBS_BOUNDARY_POINTS) ? 20 : 2) + ((f & SIGMAENV_OBS_BIRD_VIEW) ? 4 : 0);
   int other = ((f & SIGMAENV_OBS_NO_VERTICES) ? 5 : 8) + 2 + s + ((f & SIGMAENV_OBS_NO_DIST_AGENTS) ? 0 : 1) + r * 2 * NS;
   return own + n_nearing * other;
 }
@@ -781,7 +807,7 @@ int sigmaenv_oracle_create(const sigmaenv_config_t* cfg, const sigmaenv_map_t* m
   o->short_term = xcalloc(BN * NS * 2, 4); o->dist_ref = xcalloc(BN, 4); o->dist_left = xcalloc(BN * 5, 4);
   o->dist_right = xcalloc(BN * 5, 4); o->dist_bound = xcalloc(BN, 4); o->dist_agents = xcalloc(BN * N, 4);
   o->reward = xcalloc(BN, 4); o->reward_info = xcalloc(BN * SIGMAENV_N_REWARD_INFO, 4); o->obs = xcalloc(BN * o->D, 4);
-  o->action = xcalloc(BN * 2, 4); o->cbf_nominal = xcalloc(BN * 2, 4); o->path = xcalloc(BN * 4, 4); o->closest = xcalloc(BN * 3, 4);
+  o->action = xcalloc(BN * 2, 4); o->fresh = xcalloc(BN, 1); o->cbf_nominal = xcalloc(BN * 2, 4); o->path = xcalloc(BN * 4, 4); o->closest = xcalloc(BN * 3, 4);
   o->nearing = xcalloc(BN * (K ? K : 1), 4); o->timer = xcalloc((size_t)B * 4, 4);
   o->col_agents = xcalloc(BN * N, 1); o->col_flags = xcalloc(BN * 4, 1); o->done = xcalloc(B, 1);
   *out = o;
@@ -793,7 +819,7 @@ void sigmaenv_oracle_destroy(oracle_t* o) {
   void* ptrs[] = {o->center, o->left, o->right, o->yaw, o->n_center, o->n_left, o->n_right, o->is_loop, o->state, o->prev_pos,
                   o->vertices, o->short_term, o->dist_ref, o->dist_left, o->dist_right, o->dist_bound, o->dist_agents, o->reward,
                   o->reward_info, o->obs, o->action, o->path, o->closest, o->nearing, o->timer, o->col_agents, o->col_flags, o->done,
-                  o->seg_left, o->seg_right, o->cbf_nominal, o->cbf_groups};
+                  o->seg_left, o->seg_right, o->cbf_nominal, o->cbf_groups, o->fresh};
   for (size_t k = 0; k < sizeof(ptrs) / sizeof(ptrs[0]); ++k) free(ptrs[k]);
   free(o);
 }

@@ -103,14 +103,14 @@ def rew_flags_from_method(rew_method: str, is_solve_qp: bool = True) -> int:
     return f
 
 
-OBS_STEERING, OBS_REF_OTHERS, OBS_NO_VERTICES, OBS_NO_DIST_AGENTS, OBS_NO_DIST_CENTER, OBS_BIRD_VIEW = 1, 2, 4, 8, 16, 32
+OBS_STEERING, OBS_REF_OTHERS, OBS_NO_VERTICES, OBS_NO_DIST_AGENTS, OBS_NO_DIST_CENTER, OBS_BIRD_VIEW, OBS_BOUNDARY_POINTS = 1, 2, 4, 8, 16, 32, 64
 
 
 def obs_dim(n_nearing: int, obs_flags: int = 0) -> int:
     """``sigmaenv_obs_dim_ex``: [own] speed, (steering), short-term path, (centre-line distance), two boundary distances; per observed
     neighbour vertices (or position / rotation / length / width), velocity, (steering), (distance), (its short-term path)."""
     s, r = int(bool(obs_flags & OBS_STEERING)), int(bool(obs_flags & OBS_REF_OTHERS))
-    own = 1 + s + 2 * N_SHORT_TERM + (0 if obs_flags & OBS_NO_DIST_CENTER else 1) + 2 + (4 if obs_flags & OBS_BIRD_VIEW else 0)
+    own = 1 + s + 2 * N_SHORT_TERM + (0 if obs_flags & OBS_NO_DIST_CENTER else 1) + (20 if obs_flags & OBS_BOUNDARY_POINTS else 2) + (4 if obs_flags & OBS_BIRD_VIEW else 0)
     other = (5 if obs_flags & OBS_NO_VERTICES else 8) + 2 + s + (0 if obs_flags & OBS_NO_DIST_AGENTS else 1) + r * 2 * N_SHORT_TERM
     return own + n_nearing * other
 

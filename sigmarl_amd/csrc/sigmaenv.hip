@@ -821,6 +821,7 @@ __global__ void sigmaenv_reset_scatter_kernel(DevBufs g, int N, int n, const int
   size_t bi = (size_t)b * N + i;
   for (int q = 0; q < 8; ++q) g.state[bi * 8 + q] = state8[(size_t)k * 8 + q];
   for (int q = 0; q < 4; ++q) g.path[bi * 4 + q] = path_ids[(size_t)k * 4 + q];
+  if (g.fresh) g.fresh[bi] = 1;
   atomicOr(&g.reset_mask[b], 1ull << i);
   if (full_env) g.reset_full[b] = 1;
 }
@@ -1114,6 +1115,7 @@ __device__ __forceinline__ void place_from_start_table(const DevMap& m, const De
 #pragma unroll
   for (int k = 0; k < 3; ++k) { const int cpk = __float_as_int(r[START_CP + k]); s.cp[sl * 3 + k] = cpk; g.closest[gi * 3 + k] = cpk; }
   s.path[sl] = path;
+  if (g.fresh) g.fresh[gi] = 1;
   g.path[gi * 4 + 0] = path;
   if (full_env) g.path[gi * 4 + 1] = 0;  // scenario_id is kept by a per-agent reset
   g.path[gi * 4 + 2] = path - path_first;
@@ -1338,7 +1340,7 @@ static void dev_free(sigmaenv* h, void* p) {
 extern "C" int sigmaenv_obs_dim(int32_t n_nearing) { return 1 + 2 * NS + 3 + n_nearing * 11; }
 extern "C" int sigmaenv_obs_dim_ex(int32_t n_nearing, int32_t f) {  // observation_provider_rt.py:803-925
   const int s = (f & SIGMAENV_OBS_STEERING) ? 1 : 0, r = (f & SIGMAENV_OBS_REF_OTHERS) ? 1 : 0;
-  const int own = 1 + s + 2 * NS + ((f & SIGMAENV_OBS_NO_DIST_CENTER) ? 0 : 1) + 2 + ((f & SIGMAENV_OBS_BIRD_VIEW) ? 4 : 0);
+  const int own = 1 + s + 2 * NS + ((f & SIGMAENV_OBS_NO_DIST_CENTER) ? 0 : 1) + ((f & SIGMAENV_OBS_BOUNDARY_POINTS) ? 20 : 2) + ((f & SIGMAENV_OBS_BIRD_VIEW) ? 4 : 0);
   const int other = ((f & SIGMAENV_OBS_NO_VERTICES) ? 5 : 8) + 2 + s + ((f & SIGMAENV_OBS_NO_DIST_AGENTS) ? 0 : 1) + r * 2 * NS;
   return own + n_nearing * other;
 }
@@ -1565,6 +1567,11 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
   ALLOC(g.reset_mask, (size_t)B * 8);
   ALLOC(g.reset_full, (size_t)B);
   g.slab = nullptr;
+  g.fresh = nullptr;
+  if (cfg->obs_flags & SIGMAENV_OBS_BOUNDARY_POINTS) {
+    ALLOC(g.fresh, BN);
+    if (hipMemsetAsync(g.fresh, 0, BN, h->stream) != hipSuccess) { sigmaenv_destroy(h); return SIGMAENV_EHIP; }
+  }
   {
     auto magic = [](unsigned d) { return d <= 1u ? 0u : (uint32_t)(((1ull << 32) + d - 1ull) / d); };
     g.mN = magic((unsigned)N);
@@ -1657,7 +1664,7 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
 static int launch_obs_variant(sigmaenv* h) {
   if (!h->obs_var) return SIGMAENV_OK;
   const size_t BN = (size_t)h->B * h->N;
-  hipLaunchKernelGGL(obsvar::sigmaenv_observe_variant_kernel, dim3((unsigned)((BN + 255) / 256)), dim3(256), 0, h->stream, h->cfg, h->buf, h->obs_var, h->D_pub);
+  hipLaunchKernelGGL(obsvar::sigmaenv_observe_variant_kernel, dim3((unsigned)((BN + 255) / 256)), dim3(256), 0, h->stream, h->cfg, h->map, h->buf, h->obs_var, h->D_pub);
   HIPCHK(h, hipGetLastError());
   return SIGMAENV_OK;
 }

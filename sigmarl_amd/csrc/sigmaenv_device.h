@@ -65,6 +65,8 @@ struct DevBufs {
   uint8_t *col_agents, *col_flags, *done;
   unsigned long long* reset_mask;  // [B] bit i: agent i needs its derived state rebuilt
   uint8_t* reset_full;             // [B] full-env reset pending
+  uint8_t* fresh;                  // optional [B,N] (SIGMAENV_OBS_BOUNDARY_POINTS only): 1 = (re)placed and not stepped since -- the observation's boundary
+                                   // points use another index shift then (world_state_rt.py:531-576 vs :686-724); nullptr otherwise
   float* slab;                     // optional rollout record of this step: [B][N*D obs | N reward | 1 done] fp32 (sigmaenv_set_slab)
   // magic multipliers ceil(2^32 / d) for the divisors the kernels' index arithmetic divides by (fdiv below): agents per env, items per
   // agent of the two observation passes, unordered pairs per env, floats per rollout record row

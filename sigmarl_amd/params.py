@@ -95,6 +95,8 @@ def obs_flags(p: Parameters) -> int:
         f |= capi.OBS_NO_DIST_CENTER
     if not p.is_ego_view:
         f |= capi.OBS_BIRD_VIEW
+    if not p.is_observe_distance_to_boundaries:
+        f |= capi.OBS_BOUNDARY_POINTS
     return f
 
 
@@ -107,8 +109,6 @@ def check_supported(p: Parameters) -> None:
         bad.append("is_ego_view=False together with is_apply_mask=True (lanelet-relation mask)")
     if not p.is_partial_observation:
         bad.append("is_partial_observation=False")
-    if not p.is_observe_distance_to_boundaries:
-        bad.append("is_observe_distance_to_boundaries=False")
     # is_apply_mask: in ego view (the only view built) only the DISTANCE criterion is live in the reference -- the lanelet of every agent
     # (MapManager.determine_current_lanelet) is only computed in the bird-view branch of update_state (observation_provider_rt.py:537-588),
     # so current_lanelet_idx stays empty and determine_masked_agents_by_lanelets masks nobody (map_manager.py:21,102-118) on every map

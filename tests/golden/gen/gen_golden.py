@@ -675,6 +675,11 @@ TRAJS = {
     "intersection4_birdview_novert": dict(T=24, B=3, seed=32, mode_pattern=[1, 1, 0], n_agents=4, scenario_type="intersection_1", dt=0.1,
                                           is_use_mtv_distance=True, rew_method="ttc", is_ego_view=False, is_apply_mask=False, is_observe_vertices=False,
                                           is_obs_steering=True),
+    # boundary points instead of boundary distances (is_observe_distance_to_boundaries=False), ego view and bird view
+    "cpm8_boundary_points": dict(T=24, B=3, seed=33, mode_pattern=[1, 0, 1], n_agents=8, scenario_type="cpm_entire", dt=0.05, is_use_mtv_distance=False,
+                                 rew_method="distance", is_observe_distance_to_boundaries=False),
+    "onramp4_boundary_points_bird": dict(T=32, B=3, seed=34, mode_pattern=[1, 1, 0], n_agents=4, scenario_type="on_ramp_1", dt=0.1, is_use_mtv_distance=False,
+                                         rew_method="distance", is_observe_distance_to_boundaries=False, is_ego_view=False, is_apply_mask=False),
     # BASELINE config 4: 32 agents on the on-ramp map.  The reference's rejection sampler cannot place them, so the
     # start is injected (Parameters.predefined_ref_path_idx / init_state); vehicles overlap from the first step on, every env is "done" at
     # every step and none is reset: non-reset steps only, as the survey prescribes for this configuration

@@ -674,6 +674,8 @@ OBS_VARIANTS = [
     dict(is_obs_steering=True, is_observe_ref_path_other_agents=True, is_observe_vertices=False, is_observe_distance_to_agents=False,
          is_observe_distance_to_center_line=False, is_apply_mask=True),
     dict(is_ego_view=False),
+    dict(is_observe_distance_to_boundaries=False),
+    dict(is_observe_distance_to_boundaries=False, is_ego_view=False, is_obs_steering=True),
     dict(is_ego_view=False, is_obs_steering=True, is_observe_vertices=False, is_observe_ref_path_other_agents=True),
 ]
 
