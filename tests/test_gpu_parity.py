@@ -598,6 +598,49 @@ def test_compiled_custom_map_runs_through_both_paths():
     ora.close()
 
 
+@pytest.mark.parametrize("scen,N,B,T,mtv,rew,testing", [
+    ("intersection_1", 4, 768, 120, False, "distance", False),   # 4 x 4 tiles (fixed-shape instantiation), entry / exit requests
+    ("cpm_entire", 8, 512, 100, True, "ttc", True),              # 8 x 2 tiles, testing mode: colliders re-placed one by one
+    ("cpm_entire", 32, 96, 60, False, "distance_sparse", False),  # 32 x 1 tiles
+    ("on_ramp_1", 6, 300, 100, True, "distance", False),         # generic instantiation, ragged tiles
+])
+def test_soak_other_tile_shapes(scen, N, B, T, mtv, rew, testing):
+    """The one-launch path at the other tile shapes (fixed-shape instantiations 4 x 4, 8 x 2, 32 x 1 and the generic kernel) against the
+    oracle over long mixed-action runs, every buffer after every step."""
+    p = Parameters(n_agents=N, scenario_type=scen, is_use_mtv_distance=mtv, rew_method=rew, dt=0.05, is_apply_mask=False, is_obs_noise=False, max_steps=30,
+                   is_testing_mode=testing)
+    mp = load_map(scen)
+    cfg = make_config(p, mp, B)
+    dev, ora = _hip_env(cfg, mp), ob.OracleEnv(cfg, mp)
+    dev.env.buffer(capi.BUF_DONE).fill_(1)
+    ora.get(capi.BUF_DONE, copy=False)[:] = 1
+    pf, pc = mp.list_first[0], mp.list_count[0]
+    dev.auto_reset(23, 0, pf, pc)
+    ora.auto_reset(23, 0, pf, pc)
+    rng = np.random.default_rng(99)
+    n_diff = n_done = n_req = 0
+    for t in range(T):
+        mode = t % 3
+        if mode == 0:
+            act = np.stack([rng.uniform(0, 1, (B, N)), rng.uniform(-0.25, 0.25, (B, N))], axis=-1)
+        elif mode == 1:
+            act = np.stack([rng.uniform(0.1, 0.4, (B, N)), rng.uniform(-0.03, 0.03, (B, N))], axis=-1)
+        else:
+            act = np.stack([rng.uniform(-0.5, 1.6, (B, N)), rng.uniform(-0.9, 0.9, (B, N))], axis=-1)
+        act = act.astype(np.float32)
+        dev.step_autoreset(act, 23, t + 1, pf, pc)
+        ora.step(act)
+        n_done += int(ora.get(capi.BUF_DONE).sum())
+        n_req += int(ora.get(capi.BUF_COL_FLAGS)[..., 3].sum())
+        ora.auto_reset(23, t + 1, pf, pc)
+        n_diff += _compare_all(dev, ora, f"soak {scen} N={N} step {t}")
+    assert n_done > B // 2
+    print(f"soak {scen} N={N}: {n_done} finished episodes, {n_req} per-agent requests, differing non-observation fp32 words: {n_diff}")
+    assert n_diff <= 64
+    dev.close()
+    ora.close()
+
+
 @pytest.mark.parametrize("mtv,rew", [(False, "distance"), (True, "ttc_sparse")])
 def test_soak_fused_launch_vs_oracle(mtv, rew):
     """2.4 million agent-steps through the ONE-launch path (fused step + record + device resets) against the brute-force oracle, every
