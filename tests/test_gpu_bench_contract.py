@@ -1,0 +1,51 @@
+"""bench.py's output contract on a real GPU: one JSON line on stdout, the fields the round prompt names, and the roofline arithmetic a
+reader can recompute from the line itself (44 + 251 + 5 N bytes per agent-env-step)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*extra):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "24", "--warmup", "4", *extra], capture_output=True, text=True, timeout=600,
+                         cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines  # exactly ONE line on stdout
+    return json.loads(lines[0])
+
+
+def test_default_line_follows_the_contract():
+    d = _run("--cpu-seconds", "1.5")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 24 and d["warmup"] == 4 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic" and d["unit"] == "agent-env-steps/s"
+    c = d["config"]
+    assert "workload" in c and c["n_agents"] == 16 and c["envs_per_gpu"] == 4096 and "model" not in c
+    # value = agents x envs x steps / time
+    assert abs(d["value"] - 16 * 4096 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["algorithmic_bytes_per_agent_env_step"] == 44 + 251 + 5 * 16
+    assert abs(r["achieved"] - 375 * d["value"] / 1e9) <= 1e-6 * r["achieved"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-12
+    assert r["kernel"] == "sigmaenv_step_wave_kernel" and r["kernel_launches"] >= 8 and 0.0 < r["kernel_avg_ms"] < 1.0
+    assert r["achieved_incl_record"] > r["achieved"] and 0.0 < r["frac"] < 1.0
+    assert r["traffic"] is None or "traffic_source" in r
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    assert c["one_stream"]["ms_per_step"] > 0
+
+
+def test_config4_and_qp_lines_name_their_workload():
+    d = _run("--cpu-seconds", "0", "--no-one-stream", "--scenario", "on_ramp_1", "--agents", "32", "--envs-per-gpu", "1024")
+    assert "on_ramp_1" in d["config"]["workload"] and d["config"]["n_agents"] == 32 and "cpu_baseline" not in d
+    assert d["roofline"]["algorithmic_bytes_per_agent_env_step"] == 44 + 251 + 5 * 32
+    d = _run("--cpu-seconds", "0", "--no-one-stream", "--cbf-qp", "--envs-per-gpu", "512")
+    assert "cbf" in d["config"] and d["value"] > 0
