@@ -1,0 +1,93 @@
+#!/usr/bin/env python
+"""Randomised differential run: HIP path vs the CPU oracle over random configurations (map, agents, envs, distance type, reward method,
+testing mode, observation switches, fixed-duration resets), every buffer compared after every fused step / reset launch.
+Diagnostic tool for the GPU box (uses tests/' helpers):   python tools/fuzz_parity.py [--seconds 300] [--seed 0]"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+
+import oracle_binding as ob
+import test_gpu_parity as tp
+from sigmarl_amd import capi
+from sigmarl_amd.maps import load_map
+from sigmarl_amd.params import Parameters, make_config
+
+MAPS = ["cpm_entire", "cpm_entire", "cpm_entire", "intersection_1", "on_ramp_1", "roundabout_1", "interchange_2", "intersection_5", "on_ramp_2_multilane"]
+REW = ["distance", "ttc", "sparse", "distance_sparse", "ttc_sparse"]
+
+
+def one_case(rng, k):
+    scen = MAPS[rng.integers(len(MAPS))]
+    mp = load_map(scen)
+    n_max = 20 if scen.startswith("cpm") else 6
+    N = int(rng.integers(1, n_max + 1))
+    B = int(rng.integers(3, 160))
+    kw = dict(n_agents=N, scenario_type=scen, is_use_mtv_distance=bool(rng.integers(2)), rew_method=REW[rng.integers(len(REW))], dt=float(rng.choice([0.05, 0.1])),
+              is_testing_mode=bool(rng.integers(4) == 0), is_apply_mask=bool(rng.integers(3) == 0), is_obs_noise=False, max_steps=int(rng.integers(6, 40)),
+              reset_agent_fixed_duration=float(rng.choice([0, 0, 0.5])))
+    if rng.integers(3) == 0:  # observation switches
+        kw.update(is_obs_steering=bool(rng.integers(2)), is_observe_ref_path_other_agents=bool(rng.integers(2)), is_observe_vertices=bool(rng.integers(2)),
+                  is_observe_distance_to_agents=bool(rng.integers(2)), is_observe_distance_to_center_line=bool(rng.integers(2)),
+                  is_observe_distance_to_boundaries=bool(rng.integers(2)))
+        if rng.integers(3) == 0:
+            kw.update(is_ego_view=False, is_apply_mask=False)
+    p = Parameters(**kw)
+    cfg = make_config(p, mp, B)
+    dev, ora = tp._hip_env(cfg, mp), ob.OracleEnv(cfg, mp)
+    dev.env.buffer(capi.BUF_DONE).fill_(1)
+    ora.get(capi.BUF_DONE, copy=False)[:] = 1
+    lst = int(rng.integers(len(mp.list_first)))
+    if mp.list_count[lst] < 1:
+        lst = 0
+    pf, pc = int(mp.list_first[lst]), int(mp.list_count[lst])
+    seed = int(rng.integers(1 << 30))
+    dev.auto_reset(seed, 0, pf, pc)
+    ora.auto_reset(seed, 0, pf, pc)
+    tag = f"case {k}: {scen} N={N} B={B} " + " ".join(f"{a}={b}" for a, b in kw.items() if a not in ("n_agents", "scenario_type"))
+    n_diff = tp._compare_all(dev, ora, tag + " | initial reset")
+    T = int(rng.integers(8, 40))
+    for t in range(T):
+        mode = rng.integers(4)
+        lo, hi, s = [(0, 1, 0.25), (0.1, 0.4, 0.03), (-0.5, 1.6, 0.9), (0.0, 0.0, 0.0)][mode]
+        act = np.stack([rng.uniform(lo, hi, (B, N)) if hi > lo else np.zeros((B, N)), rng.uniform(-s, s, (B, N)) if s > 0 else np.zeros((B, N))], axis=-1).astype(np.float32)
+        if rng.integers(2):
+            dev.step_autoreset(act, seed, t + 1, pf, pc)
+        else:
+            dev.step(act)
+            n_diff += 0
+            dev.auto_reset(seed, t + 1, pf, pc)
+        ora.step(act)
+        ora.auto_reset(seed, t + 1, pf, pc)
+        n_diff += tp._compare_all(dev, ora, tag + f" | step {t}")
+    dev.close()
+    ora.close()
+    return tag, T * B * N, n_diff
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=300.0)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    rng = np.random.default_rng(args.seed)
+    t0 = time.time()
+    k = n_steps = n_diff = 0
+    while time.time() - t0 < args.seconds:
+        tag, steps, diff = one_case(rng, k)
+        n_steps += steps
+        n_diff += diff
+        if diff:
+            print("differing non-observation words:", diff, tag)
+        k += 1
+    print(f"fuzz: {k} configurations, {n_steps} agent-steps compared, {n_diff} differing non-observation fp32 words, no mask / index mismatch, all floats within {tp.FTOL}")
+
+
+if __name__ == "__main__":
+    main()
