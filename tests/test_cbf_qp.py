@@ -266,3 +266,40 @@ def test_qp_matches_an_independent_solver_of_the_original_problem(nominal):
     env.close()
     assert worst <= 1e-5, worst
     assert n_changed >= n_env // 4
+
+
+# ---- instances found by tools/fuzz_cbf.py on which earlier versions of the projected Newton iteration failed -----------------------------
+REGRESSIONS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "qp_regressions.npz")
+REGRESSION_TAGS = ["cycle", "crawl0", "crawl1", "crawl2", "crawl3", "crawl4", "noisefloor"]
+
+
+def regression_case(make_env, tag):
+    """One env of a fuzz run on which the solver once (cycle) alternated between two points because a step that raised F by 1e-9 |F| was
+    accepted, (crawl*) halved a variable's distance to its bound per iteration until the step underflowed -- and then called it converged --,
+    (noisefloor) never met the step-size stop although it sat on the minimiser.  Returns (env, actions [1, N, 2], nominal controller)."""
+    z = np.load(REGRESSIONS)
+    kw = eval(str(z[tag + "_kw"]))
+    mp = load_map(kw["scenario_type"])
+    p = Parameters(**kw)
+    N = kw["n_agents"]
+    env = make_env(make_config(p, mp, 1), mp)
+    seg_l, seg_r = cbf.load_segment_tables(mp)
+    env.cbf_attach(cbf.make_cbf_config(p), seg_l, seg_r)
+    env.reset(np.zeros(N, np.int32), np.arange(N, dtype=np.int32), z[tag + "_path"].reshape(-1, 4), z[tag + "_state"].reshape(-1, 8), 1)
+    return env, z[tag + "_act"][None].astype(np.float32), z[tag + "_short"][None], kw
+
+
+@pytest.mark.parametrize("tag", REGRESSION_TAGS)
+def test_solver_regressions_converge_to_the_solution_of_the_original_problem(tag):
+    env, act, short, kw = regression_case(ob.OracleEnv, tag)
+    env.get(4, copy=False)[:] = short
+    safe, u, info, con, unom = env.cbf_qp(act, with_data=True)
+    assert info[0, 1] == 1 and info[0, 0] <= 40, info
+    if kw.get("is_grouping_agents"):
+        import test_cbf_grouped as tg
+        x = tg.solve_grouped_original(env, con[0], unom[0], kw["nom_controller_type"], 0, Cc=int(kw["n_circles_approximate_vehicle"]))
+        assert np.abs(x - u[0].reshape(-1)).max() <= 1e-5
+    elif kw.get("adaptive_lambda"):  # (the interior-point check needs the lambda penalty: without it the original problem is not strictly convex)
+        assert compare_with_original_problem(env, u, con, unom, kw["nom_controller_type"], 1) <= 1e-5
+    check_kkt(env, u, con, unom, kw["nom_controller_type"], tol=1e-8) if not kw.get("is_grouping_agents") else None
+    env.close()

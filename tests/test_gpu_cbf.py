@@ -245,7 +245,8 @@ def test_cbf_requires_attach_and_rejects_grouping_without_qp():
     dev.close()
 
 
-@pytest.mark.parametrize("nominal,adaptive,N", [("rl", False, 16), ("rl", True, 16), ("clf", False, 16), ("clf", True, 8), ("rl", False, 32), ("rl", False, 3), ("rl", True, 1)])
+@pytest.mark.parametrize("nominal,adaptive,N", [("rl", False, 16), ("rl", True, 16), ("clf", False, 16), ("clf", True, 8), ("rl", False, 32), ("rl", False, 3), ("rl", True, 1),
+                                                ("rl", True, 9), ("rl", False, 13), ("clf", True, 5)])  # (2 N not a power of two: the factor's LDS area)
 def test_cbf_qp_vs_oracle_and_kkt(nominal, adaptive, N):
     """The centralized CBF-QP (sigmarl/cbf_qp.py:733-1400): HIP minimiser == the oracle's, and it satisfies the KKT conditions of the
     original problem (checked in numpy on the constraint data; cvxpy / OSQP are absent, see tests/test_cbf_qp.py)."""
@@ -560,3 +561,42 @@ def test_grouped_qp_full_size_4096_envs():
         assert np.abs(safe[lo:lo + S].cpu().numpy() - safe_o).max() <= 1e-6
         ora.close()
     env.close()
+
+
+@pytest.mark.parametrize("tag", ["cycle", "crawl0", "crawl1", "crawl2", "crawl3", "crawl4", "noisefloor"])
+def test_solver_regressions_hip_vs_oracle(tag):
+    """The instances of tests/data/qp_regressions.npz (found by tools/fuzz_cbf.py: a 2-cycle of the noise-tolerant acceptance rule, a
+    variable creeping towards a bound with a collapsing line search, a stop test below the gradient's noise floor): the HIP solver converges
+    and returns the oracle's minimiser, which tests/test_cbf_qp.py holds against the interior-point solution of the original problem."""
+    from test_cbf_qp import regression_case
+
+    outs = []
+    for make in (ob.OracleEnv, _hip_env):
+        env, act, short, kw = regression_case(make, tag)
+        if make is ob.OracleEnv:
+            env.get(capi.BUF_SHORT_TERM, copy=False)[:] = short
+        else:
+            import torch
+            env.env.buffer(capi.BUF_SHORT_TERM)[:] = torch.as_tensor(short).to(env.env.device)
+        safe, u, info = env.cbf_qp(act)[:3]
+        outs.append((safe, u, info))
+        env.close()
+    (s0, u0, i0), (s1, u1, i1) = outs
+    assert i0[0, 1] == 1 and i1[0, 1] == 1, (i0, i1)
+    assert np.abs(u0 - u1).max() <= 1e-7 and np.abs(s0 - s1).max() <= 1e-6
+
+
+def test_grouped_qp_unknown_count_not_a_power_of_two():
+    """9 vehicles in groups of 6 / 3 (18 unknowns): the Cholesky factor of the compacted system needs a 32 x 32 area in LDS although the
+    Hessian is 18 x 18 (the kernel once overran it and hung)."""
+    import test_cbf_grouped as tg
+
+    for m in (6, 3):
+        outs = []
+        for make in (ob.OracleEnv, _hip_env):
+            env, act, ref = tg.grouped_case(make, m, 0.5, "rl", N=9)
+            safe, u, info = env.cbf_qp(act)[:3]
+            outs.append((u, info, env.cbf_groups()))
+            env.close()
+        assert outs[0][1][:, 1].all() and outs[1][1][:, 1].all()
+        assert np.array_equal(outs[0][2], outs[1][2]) and np.abs(outs[0][0] - outs[1][0]).max() <= 1e-7
