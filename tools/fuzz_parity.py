@@ -66,6 +66,24 @@ def one_case(rng, k):
         ora.step(act)
         ora.auto_reset(seed, t + 1, pf, pc)
         n_diff += tp._compare_all(dev, ora, tag + f" | step {t}")
+        if rng.integers(4) == 0:  # host-driven resets (sigmaenv_reset): single agents of some envs, or whole envs, onto random centre-line points
+            full = bool(rng.integers(2))
+            envs = rng.choice(B, size=int(rng.integers(1, min(B, 6) + 1)), replace=False)
+            ei, ai, ids, st8 = [], [], [], []
+            for e in envs:
+                agents = range(N) if full else rng.choice(N, size=int(rng.integers(1, N + 1)), replace=False)
+                for i in agents:
+                    gp = pf + int(rng.integers(pc))
+                    pt = int(rng.integers(1, max(2, int(mp.n_center[gp]) - 2)))
+                    x, y = [float(v) for v in mp.center[gp, pt]]
+                    yaw = float(mp.yaw[gp, min(pt, int(mp.n_yaw[gp]) - 1)])
+                    sp = float(rng.uniform(0, 1))
+                    ei.append(int(e)); ai.append(int(i)); ids.append((gp, lst, gp - pf, pt))
+                    st8.append((x, y, yaw, sp, 0.0, sp * np.cos(np.float32(yaw)), sp * np.sin(np.float32(yaw)), 0.0))
+            for env_ in (dev, ora):
+                env_.reset(np.asarray(ei, np.int32), np.asarray(ai, np.int32), np.asarray(ids, np.int32), np.asarray(st8, np.float32), int(full))
+                env_.observe()
+            n_diff += tp._compare_all(dev, ora, tag + f" | host reset after step {t}")
     dev.close()
     ora.close()
     return tag, T * B * N, n_diff
