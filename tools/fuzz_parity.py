@@ -28,6 +28,8 @@ def one_case(rng, k):
     mp = load_map(scen)
     n_max = 20 if scen.startswith("cpm") else 6
     N = int(rng.integers(1, n_max + 1))
+    if scen.startswith("cpm") and rng.integers(8) == 0:  # now and then a crowded map: up to 64 agents (one env per wavefront, no lane pairing)
+        N = int(rng.integers(21, 65))
     B = int(rng.integers(3, 160))
     kw = dict(n_agents=N, scenario_type=scen, is_use_mtv_distance=bool(rng.integers(2)), rew_method=REW[rng.integers(len(REW))], dt=float(rng.choice([0.05, 0.1])),
               is_testing_mode=bool(rng.integers(4) == 0), is_apply_mask=bool(rng.integers(3) == 0), is_obs_noise=False, max_steps=int(rng.integers(6, 40)),
