@@ -1,0 +1,81 @@
+#!/usr/bin/env python
+"""BUILD CONTAINER ONLY: fresh random rollouts of the imported reference (tests/golden/gen/refshim.py + gen_golden.run_traj) replayed through the
+C oracle -- the check the committed goldens are instances of, on configurations they do not contain.  Every trajectory is generated in its own
+interpreter (the generator's rule) into a scratch directory; nothing is committed.
+Usage: python tools/fuzz_reference.py [--cases 12] [--seed 0] [--keep DIR]"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GEN = os.path.join(ROOT, "tests", "golden", "gen")
+
+WORKER = r'''
+import json, os, sys
+sys.path.insert(0, {gen!r}); sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import gen_golden
+gen_golden.OUT = {out!r}
+kw = json.loads({kw!r})
+gen_golden.run_traj(**kw)
+'''
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=12)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--keep", default=None)
+    args = ap.parse_args()
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_binding as ob
+    import traj_replay as tr
+
+    rng = np.random.default_rng(args.seed)
+    out = args.keep or tempfile.mkdtemp(prefix="fuzz_ref_")
+    os.makedirs(out, exist_ok=True)
+    maps = [("cpm_entire", 12), ("cpm_entire", 12), ("intersection_1", 5), ("on_ramp_1", 5), ("roundabout_1", 5), ("interchange_2", 5), ("cpm_mixed", 4)]
+    rews = ["distance", "ttc", "sparse", "distance_sparse", "ttc_sparse"]
+    worst = {}
+    for k in range(args.cases):
+        scen, nmax = maps[rng.integers(len(maps))]
+        N = int(rng.integers(2, nmax + 1))
+        B = int(rng.integers(2, 4))
+        kw = dict(name=f"fuzz{k}", T=int(rng.integers(12, 28)), B=B, seed=int(rng.integers(1000, 100000)), mode_pattern=[int(v) for v in rng.integers(0, 2, B)],
+                  n_agents=N, scenario_type=scen, dt=float(rng.choice([0.05, 0.1])), is_use_mtv_distance=bool(rng.integers(2)), rew_method=str(rews[rng.integers(len(rews))]),
+                  is_testing_mode=bool(rng.integers(5) == 0), is_apply_mask=bool(rng.integers(3) == 0), max_steps=int(rng.integers(8, 40)))
+        if scen == "cpm_mixed":
+            kw["cpm_scenario_probabilities"] = [1.0, 0.0, 0.0]
+        if rng.integers(3) == 0:
+            kw["reset_agent_fixed_duration"] = 0.5
+        if rng.integers(3) == 0:
+            kw.update(is_obs_steering=bool(rng.integers(2)), is_observe_ref_path_other_agents=bool(rng.integers(2)), is_observe_vertices=bool(rng.integers(2)),
+                      is_observe_distance_to_agents=bool(rng.integers(2)), is_observe_distance_to_center_line=bool(rng.integers(2)),
+                      is_observe_distance_to_boundaries=bool(rng.integers(2)))
+            if rng.integers(3) == 0:
+                kw.update(is_ego_view=False, is_apply_mask=False)
+        code = WORKER.format(gen=GEN, root=ROOT, out=out, kw=json.dumps(kw))
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, PYTHONHASHSEED="0"))
+        if r.returncode != 0:
+            print(f"case {k}: reference run failed ({kw}):\n{r.stderr[-1500:]}")
+            continue
+        tr.GOLDEN_DIR = out
+        z, meta = tr.load_fixture(f"fuzz{k}")
+        cfg, mp = tr.config_from_meta(meta)
+        env = ob.OracleEnv(cfg, mp)
+        rep = tr.replay(env, z, meta, mp)
+        env.close()
+        ok = rep.total_mismatch() == 0 and all(v <= 1e-5 for v in rep.max_abs.values())
+        for key, v in rep.max_abs.items():
+            worst[key] = max(worst.get(key, 0.0), float(v))
+        print(f"case {k}: {scen} N={N} B={B} T={kw['T']} {'mtv' if kw['is_use_mtv_distance'] else 'c2c'} {kw['rew_method']} "
+              f"{'testing ' if kw['is_testing_mode'] else ''}mismatches {rep.total_mismatch()} max err {max(rep.max_abs.values()):.2e} {'ok' if ok else 'FAIL ' + str(rep)}", flush=True)
+    print("worst fp32 error per buffer:", {k: f"{v:.2e}" for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:6]})
+
+
+if __name__ == "__main__":
+    main()
