@@ -671,6 +671,23 @@ static void reset_env_tail(oracle_t* o, int b, int full_env) { /* road_traffic.p
   if (full_env) { o->timer[b * 4] = 0; o->timer[b * 4 + 3] += 1; o->done[b] = 0; }
 }
 
+/* TEST REPLAYS ONLY.  road_traffic.py:889-907: `env_j = slice(None); if env_index: env_j = env_index` -- for env 0 the condition is false, so a
+ * reset of env 0 (whole env or single agent) also recomputes, for EVERY env, the derived state of the reset agent(s) with the reset-time rules
+ * (corner queries on the current vertices, boundary points with the reset shift), the mutual distances, and clears every env's collision flags.
+ * Nothing the learner sees depends on it (the next step recomputes all of it from the states, and observations of untouched envs are not taken
+ * again), so the product does not reproduce it; the replay of reference trajectories calls this after an event in env 0 so that the snapshots the
+ * golden generator takes right after the resets compare exactly.  agent < 0: all agents. */
+int sigmaenv_oracle_env0_reset_side_effect(oracle_t* o, int32_t agent) {
+  if (!o || agent >= o->N) return SIGMAENV_EINVAL;
+  for (int b = 1; b < o->B; ++b) {
+    for (int i = 0; i < o->N; ++i) if (agent < 0 || i == agent) reset_agent_derived(o, b, i);
+    mutual_distances(o, b);
+    memset(o->col_agents + (size_t)b * o->N * o->N, 0, (size_t)o->N * o->N);
+    for (int a = 0; a < o->N; ++a) { uint8_t* f = o->col_flags + ((size_t)b * o->N + a) * 4; f[0] = f[1] = f[2] = f[3] = 0; }
+  }
+  return SIGMAENV_OK;
+}
+
 /* counter-based RNG shared (as a specification) with the HIP kernel: 32-bit multiplicative mix + murmur3 finalisers over (seed, counter, env, agent, draw) */
 static inline uint32_t rng_u32(uint64_t seed, uint64_t counter, uint32_t env, uint32_t agent, uint32_t draw) {
   uint32_t h = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9E3779B9u);

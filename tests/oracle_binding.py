@@ -46,6 +46,7 @@ def load_oracle() -> capi.Library:
             "fn_trig": (None, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
             "fn_pseudo_distance": (None, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
             "cbf_qp_ex": (C.c_int, [C.c_void_p] * 7),
+            "env0_reset_side_effect": (C.c_int, [C.c_void_p, C.c_int32]),
             "path_table": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(_f32p), C.POINTER(_f32p), C.POINTER(_f32p)]),
         }
         _lib = capi.Library(ORACLE_SO, "sigmaenv_oracle_", extra)
@@ -129,6 +130,12 @@ class OracleEnv:
         rc = self.lib.step(self.h, ptr(a))
         if rc != 0:
             raise RuntimeError(f"oracle step failed: {rc}")
+
+    def env0_reset_side_effect(self, agent: int):
+        """The reference's `if env_index:` quirk (road_traffic.py:889-907): see sigmaenv_oracle_env0_reset_side_effect."""
+        rc = self.lib.env0_reset_side_effect(self.h, int(agent))
+        if rc != 0:
+            raise RuntimeError(f"oracle env0_reset_side_effect failed: {rc}")
 
     def observe(self):
         assert self.lib.observe(self.h) == 0

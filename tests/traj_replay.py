@@ -188,6 +188,8 @@ def apply_events(env, z, mp, t):
             st[q] = _state8(z["ev_pos"][k][i], z["ev_rot"][k][i], z["ev_speed"][k][i], z["ev_steering"][k][i],
                             z["ev_vel"][k][i], z["ev_sideslip"][k][i])
         env.reset(np.full(len(agents), e, np.int32), np.asarray(agents, np.int32), ids, st, 1 if kind == 1 else 0)
+        if e == 0 and hasattr(env, "env0_reset_side_effect"):  # (oracle replays: the reference's `if env_index:` quirk, see the oracle)
+            env.env0_reset_side_effect(-1 if kind == 1 else a)
         if e not in touched:
             touched.append(e)
     return touched

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--cases", type=int, default=12)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--keep", default=None)
+    ap.add_argument("--only", type=int, default=-1, help="run only this case of the sequence (the others just consume their random draws)")
     args = ap.parse_args()
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -58,6 +59,8 @@ def main():
                       is_observe_distance_to_boundaries=bool(rng.integers(2)))
             if rng.integers(3) == 0:
                 kw.update(is_ego_view=False, is_apply_mask=False)
+        if args.only >= 0 and k != args.only:
+            continue
         code = WORKER.format(gen=GEN, root=ROOT, out=out, kw=json.dumps(kw))
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, PYTHONHASHSEED="0"))
         if r.returncode != 0:
