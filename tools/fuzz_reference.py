@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--cases", type=int, default=12)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--keep", default=None)
+    ap.add_argument("--cbf", action="store_true", help="mix in rollouts with the CBF margin reward (tens of minutes each)")
     ap.add_argument("--only", type=int, default=-1, help="run only this case of the sequence (the others just consume their random draws)")
     args = ap.parse_args()
     sys.path.insert(0, ROOT)
@@ -59,6 +60,13 @@ def main():
                       is_observe_distance_to_boundaries=bool(rng.integers(2)))
             if rng.integers(3) == 0:
                 kw.update(is_ego_view=False, is_apply_mask=False)
+        if args.cbf and rng.integers(4) == 0:  # the CBF margin reward of the reference in front of every step (cbf_qp.py:2534-2804, one Python object per env: VERY slow)
+            kw.update(hook="cbf", rew_method=str(rng.choice(["cbf", "cbf_sparse"])), is_using_cbf_training=True, is_solve_qp=False,
+                      nom_controller_type=str(rng.choice(["rl", "clf"])), T=int(rng.integers(6, 12)), n_agents=min(N, 4))
+            for key in ("is_obs_steering", "is_observe_ref_path_other_agents", "is_observe_vertices", "is_observe_distance_to_agents", "is_observe_distance_to_center_line",
+                        "is_observe_distance_to_boundaries", "is_ego_view", "reset_agent_fixed_duration"):
+                kw.pop(key, None)
+            kw["is_testing_mode"] = False
         if args.only >= 0 and k != args.only:
             continue
         code = WORKER.format(gen=GEN, root=ROOT, out=out, kw=json.dumps(kw))
@@ -72,11 +80,11 @@ def main():
         env = ob.OracleEnv(cfg, mp)
         rep = tr.replay(env, z, meta, mp)
         env.close()
-        ok = rep.total_mismatch() == 0 and all(v <= 1e-5 for v in rep.max_abs.values())
+        ok = rep.total_mismatch() == 0 and all(v <= 1e-5 for v in rep.max_abs.values()) and rep.cbf_ok()
         for key, v in rep.max_abs.items():
             worst[key] = max(worst.get(key, 0.0), float(v))
         print(f"case {k}: {scen} N={N} B={B} T={kw['T']} {'mtv' if kw['is_use_mtv_distance'] else 'c2c'} {kw['rew_method']} "
-              f"{'testing ' if kw['is_testing_mode'] else ''}mismatches {rep.total_mismatch()} max err {max(rep.max_abs.values()):.2e} {'ok' if ok else 'FAIL ' + str(rep)}", flush=True)
+              f"{'testing ' if kw['is_testing_mode'] else ''}{'cbf-' + kw['nom_controller_type'] + ' ' if kw.get('hook') else ''}mismatches {rep.total_mismatch()} max err {max(rep.max_abs.values()):.2e} {'ok' if ok else 'FAIL ' + str(rep)}", flush=True)
     print("worst fp32 error per buffer:", {k: f"{v:.2e}" for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:6]})
 
 
