@@ -5,14 +5,16 @@ Contract (see the round prompt): ``python bench.py --gpus N --steps K --warmup W
 ``python -m torch.distributed.run`` with one rank per GPU.  W untimed warm-up steps, then exactly K timed steps bracketed by a
 barrier + torch.cuda.synchronize() on both sides, MAX over ranks, rank 0 prints ONE JSON line.
 
-A "step" is one pass of the hot path over one batch of synthetic input: ONE launch per env shard (sigmaenv_step_autoreset) that steps
-agents x envs, writes the rollout record of the step (observation incl. the terminal one, reward, done -- the reference's
-step_and_maybe_reset keeps both the terminal and the post-reset observation) into the rollout chunk buffer and re-places the envs that
-finished; for N > 1 additionally one asynchronous RCCL exchange of the rollout chunk per --chunk-steps steps (--exchange alltoall: by
-time slices to every rank, the default; --exchange gather: everything to rank 0).  Inputs (actions) are resident in HBM before the timed
-region starts.  Weak scaling: every GPU steps BASELINE config 2 (CPM map, 16 agents x 4096 envs); N = 8 is config 3 (32768 envs).
-Up to 8192 envs per GPU are stepped as two env shards on two HIP streams (--streams); `config.one_stream` carries the same workload timed
-with a single launch per step right after the headline region (--no-one-stream skips it).
+A "step" is one pass of the hot path over one batch of synthetic input: agents x envs stepped once by the fused kernel, which also writes
+the rollout record of the step (observation incl. the terminal one, reward, done -- the reference's step_and_maybe_reset keeps both the
+terminal and the post-reset observation) into the rollout chunk buffer and re-places the envs that finished.  The steps are issued as the
+reference's rollout loop issues them (helper_training.py:687-788) -- a chunk of T steps per call: ONE launch of sigmaenv_step_autoreset_n in
+which every wavefront walks its env through the T steps (--chunk T; default: the largest divisor of --steps up to 32; --chunk 1 = one launch
+per step, the round-2 form, timed as well and reported in config.per_step_launch).  For N > 1 additionally one asynchronous RCCL exchange of
+the rollout chunk per launch (--exchange alltoall: by time slices to every rank, the default; --exchange gather: everything to rank 0).
+Inputs (actions) are resident in HBM before the timed region starts.  Weak scaling: every GPU steps BASELINE config 2 (CPM map, 16 agents x
+4096 envs); N = 8 is config 3 (32768 envs; rank r's envs are envs [4096 r, 4096 (r + 1)) of the batch -- `env_index_base` -- and draw what the
+unsharded batch would draw).  --emulate-ranks R: config 3's workload on ONE GPU, rank by rank (config.emulated_ranks).
 
 Other workloads of BASELINE.json through the same code path:
   --scenario on_ramp_1 --agents 32 --envs-per-gpu 8192      config 4 (injected start, see sigmarl_amd.maps.injected_start)
@@ -128,10 +130,16 @@ def shard_streams(torch, device, S):
     return _SHARD_STREAMS[key]
 
 
-class GpuRun:
-    """The envs of ONE GPU: S shards (handles) of B / S envs on S HIP streams, precomputed actions, the rollout record + exchange."""
+def pick_chunk(steps: int, cap: int = 32) -> int:
+    """Steps per launch: the largest divisor of `steps` that is at most `cap` (the timed region is then whole launches)."""
+    return max(d for d in range(1, max(1, min(cap, steps)) + 1) if steps % d == 0) if steps > 0 else 1
 
-    def __init__(self, args, device, B, world, rank, with_exchange=True):
+
+class GpuRun:
+    """The envs of ONE GPU: S shards (handles) of B / S envs on S HIP streams, precomputed actions, the rollout record + exchange.
+    T > 1: one handle, T steps per launch (sigmaenv_step_autoreset_n); T == 1: one launch per step and shard."""
+
+    def __init__(self, args, device, B, world, rank, with_exchange=True, T=1, env_base=None):
         import torch
         from sigmarl_amd.env import SigmaEnv
         from sigmarl_amd.maps import injected_start
@@ -140,35 +148,38 @@ class GpuRun:
 
         self.torch, self.args, self.device, self.B, self.N = torch, args, device, B, args.agents
         N = self.N
+        self.T = T = max(1, int(T))
         # env shards of this GPU (no cross-env dependency anywhere in the path); small batches stay in one piece
-        # Shards pay while the whole batch is about one resident round of wavefronts (one env per wavefront, 16 per CU): the tail of one
-        # shard's launch -- its reset-heavy wavefronts -- then overlaps the other shard's start.  Larger batches run several rounds per launch
-        # and fill the tail by themselves (measured: 2 shards 13 % faster at 4096 envs, 20 % at 8192, slower from 16384 on).
+        # Shards pay (per-step launches only) while the whole batch is about one resident round of wavefronts (one env per wavefront, 16 per CU): the
+        # tail of one shard's launch -- its reset-heavy wavefronts -- then overlaps the other shard's start.  Larger batches run several rounds per launch
+        # and fill the tail by themselves (measured: 2 shards 13 % faster at 4096 envs, 20 % at 8192, slower from 16384 on).  A T-step launch has no
+        # per-step tail to hide: one handle.
         min_tiles, max_envs = int(os.environ.get("BENCH_MIN_TILES", "1024")), int(os.environ.get("BENCH_SHARD_MAX_ENVS", "8192"))
-        S = args.streams if (args.streams >= 1 and B % max(1, args.streams) == 0 and (B // max(1, args.streams)) >= min_tiles and B <= max_envs) else 1
+        S = args.streams if (T == 1 and args.streams >= 1 and B % max(1, args.streams) == 0 and (B // max(1, args.streams)) >= min_tiles and B <= max_envs) else 1
         self.S, self.Bs = S, B // S
         Bs = self.Bs
+        self.env_base = rank * B if env_base is None else int(env_base)  # this GPU's first env in the whole batch (shard.shard_range)
         self.main_stream = torch.cuda.current_stream(device)
         self.streams = [self.main_stream] if S == 1 else shard_streams(torch, device, S)
-        self.seed = 1000 + rank
+        self.seed = 1000  # one seed for the whole batch: the generator is keyed on (seed, counter, env index in the batch, agent, draw)
         self.envs = []
         kw = make_params_kw(args, Bs)
         for k in range(S):
             with torch.cuda.stream(self.streams[k]):
-                e = SigmaEnv(Parameters(**kw), n_envs=Bs, device=device)
+                e = SigmaEnv(Parameters(**kw), n_envs=Bs, device=device, env_index_base=self.env_base + k * Bs)
                 if needs_injected_start(e.map, N):
                     e.reset_injected(*injected_start(e.map, N))
                     self.start = "injected (sigmarl_amd.maps.injected_start: the same state in every env, zero speed)"
                 else:
-                    e.reset_random(seed=self.seed * 64 + k)
+                    e.reset_random(seed=self.seed)
                     self.start = "device-side sampler"
                 if args.cbf or args.cbf_qp:
                     e.cbf_attach()
                 self.envs.append(e)
         self.env = self.envs[0]
         self.D = self.env.D
-        gen = torch.Generator(device=device).manual_seed(self.seed)
-        self.n_act = 16
+        gen = torch.Generator(device=device).manual_seed(self.seed + 7919 * (self.env_base // max(1, B)))
+        self.n_act = T * ((16 + T - 1) // T)  # whole chunks of T consecutive action blocks
         self.acts = torch.empty((self.n_act, B, N, 2), dtype=torch.float32, device=device)
         self.acts[..., 0] = torch.rand((self.n_act, B, N), generator=gen, device=device)                 # v_cmd ~ U[0, 1]
         self.acts[..., 1] = torch.rand((self.n_act, B, N), generator=gen, device=device) * 0.5 - 0.25    # delta_cmd ~ U[-0.25, 0.25] rad
@@ -180,8 +191,8 @@ class GpuRun:
         self.gather_fail = None
         if with_exchange and not args.no_gather:
             try:  # the rollout exchange must never take the benchmark down: fall back to "no gather" and say so in the JSON line
-                ex_mode = args.exchange if args.chunk_steps % max(1, world) == 0 else "gather"
-                self.gather = RolloutExchange(B, N, self.D, args.chunk_steps, device, force_collective=args.force_dist, mode=ex_mode)
+                self.chunk_steps = T if T > 1 else args.chunk_steps
+                self.gather = RolloutExchange(B, N, self.D, self.chunk_steps, device, force_collective=args.force_dist, mode=args.exchange)
                 slot0 = self.gather.slot()
                 for k, e in enumerate(self.envs):
                     e.set_slab(slot0[k * Bs:(k + 1) * Bs])
@@ -192,8 +203,8 @@ class GpuRun:
                 self.gather.wait_all()
                 torch.cuda.synchronize()
                 for k, e in enumerate(self.envs):
-                    e.auto_reset(seed=self.seed * 64 + k, counter=0, path_first=self.pf, path_count=self.pc)
-                self.gather_note = (f"step kernel records (obs, reward, done) into a [{args.chunk_steps}, B, {N * (self.D + 1) + 1}] chunk buffer"
+                    e.auto_reset(seed=self.seed, counter=0, path_first=self.pf, path_count=self.pc)
+                self.gather_note = (f"step kernel records (obs, reward, done) into a [{self.chunk_steps}, B, {N * (self.D + 1) + 1}] chunk buffer"
                                     + (("; one async all-to-all per chunk (rank r receives steps [r T/N, (r+1) T/N) of every rank's chunk), double buffered"
                                         if self.gather.mode == "alltoall" else "; one async gather per chunk to rank 0, double buffered")
                                        if self.gather.collective else " (single GPU: no exchange)"))
@@ -215,7 +226,7 @@ class GpuRun:
         self.safe_bufs = [torch.zeros((Bs, N, 2), dtype=torch.float32, device=device) for _ in range(S)] if args.cbf_qp else []
         self.W = N * (self.D + 1) + 1
         self.act_ptrs = [[self.acts[q].data_ptr() + k * Bs * N * 2 * 4 for k in range(S)] for q in range(self.n_act)]
-        self.shard_seeds = [self.seed * 64 + k for k in range(S)]
+        self.shard_seeds = [self.seed for k in range(S)]
         self.fused = not (args.no_reset or args.separate_reset)
         HArr, PArr, SArr = C.c_void_p * S, C.c_void_p * S, C.c_uint64 * S
         self.h_arr = HArr(*[e.h for e in self.envs])
@@ -223,6 +234,37 @@ class GpuRun:
         self.act_arrs = [PArr(*ap_) for ap_ in self.act_ptrs]
         self.slab_arr = PArr()
         self.many = self.envs[0].lib.step_autoreset_many
+
+    def run_steps(self, t0, n):
+        """n steps starting at step index t0: launches of up to T steps (T > 1), else one launch per step and shard."""
+        if self.T == 1:
+            for t in range(n):
+                self.one_step(t0 + t)
+            return
+        done = 0
+        while done < n:
+            k = min(self.T, n - done)
+            self.run_chunk(t0 + done, k)
+            done += k
+
+    def run_chunk(self, t0, k):
+        """ONE launch: k <= T fused steps of every env, the record rows of the k steps into the chunk buffer, then the chunk's exchange."""
+        e, B, N, W = self.env, self.B, self.N, self.W
+        a0 = ((t0 // self.T) * self.T) % self.n_act  # a whole window of T consecutive action blocks
+        ap = self.acts.data_ptr() + a0 * B * N * 2 * 4
+        gather = self.gather
+        slab = gather.chunk().data_ptr() if gather is not None else 0
+        e.step_autoreset_n_ptr(ap, k, B * N * 2, slab, B * W, self.seed, self.counter, self.pf, self.pc)
+        self.counter += k
+        if gather is not None:
+            try:
+                gather.commit(k)
+            except Exception as exc:  # noqa: BLE001 -- a failing exchange must not take the benchmark down: keep recording, stop exchanging
+                print(f"[bench] rollout exchange failed, continuing without it: {exc}", file=sys.stderr)
+                gather.collective = False
+                gather.pending = [None, None]
+                self.gather_fail = f"exchange failed at run time ({type(exc).__name__}); record kept, exchange disabled"
+                gather.t = 0
 
     def one_step(self, t):
         args, S, Bs, W = self.args, self.S, self.Bs, self.W
@@ -310,8 +352,7 @@ def timed(run, steps, start_t, use_dist, dist, torch, device):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for t in range(steps):
-        run.one_step(start_t + t)
+    run.run_steps(start_t, steps)
     run.finish_chunk()
     torch.cuda.synchronize()
     if use_dist:
@@ -338,7 +379,12 @@ def main():
                     "report it in `sweep`; the headline stays --envs-per-gpu")
     ap.add_argument("--sweep-envs", default="256,512,1024,2048,4096,8192,16384,32768")
     ap.add_argument("--sweep-steps", type=int, default=64)
-    ap.add_argument("--no-one-stream", action="store_true", help="skip the additional one-stream measurement reported in config.one_stream")
+    ap.add_argument("--chunk", type=int, default=0, help="steps per launch (sigmaenv_step_autoreset_n); 0 = the largest divisor of --steps up to 32; 1 = one launch "
+                    "per step (sigmaenv_step_autoreset); modes with a launch between the steps (--policy, --cbf, --cbf-qp, --separate-reset) always use 1")
+    ap.add_argument("--no-one-stream", "--no-compare", dest="no_compare", action="store_true",
+                    help="skip the additional per-step-launch measurement reported in config.per_step_launch")
+    ap.add_argument("--emulate-ranks", type=int, default=0, help="after the headline: BASELINE config 3's workload on this ONE GPU -- R shards of --envs-per-gpu envs "
+                    "(rank r = envs [r B, (r + 1) B) of the batch), each timed like the headline with its own rollout exchange; reported in config.emulated_ranks")
     ap.add_argument("--no-reset", action="store_true", help="diagnostic: leave finished envs un-reset")
     ap.add_argument("--separate-reset", action="store_true", help="two launches per step (sigmaenv_step; sigmaenv_auto_reset) instead of the fused one")
     ap.add_argument("--no-gather", action="store_true", help="diagnostic: no rollout record (and no exchange for N > 1)")
@@ -365,8 +411,10 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
 
-    # HIP-event bracket around a sample of the step launches (each bracket costs a few microseconds): at least 8 samples per shard
-    os.environ.setdefault("SIGMAENV_TIMING_STRIDE", str(max(1, min(32, args.steps // 8))))
+    plain = not (args.policy or args.cbf or args.cbf_qp or args.no_reset or args.separate_reset)
+    T = 1 if not plain else (args.chunk if args.chunk >= 1 else pick_chunk(args.steps))
+    # HIP-event bracket around a sample of the step launches (each bracket costs a few microseconds): at least 8 samples per shard when there are that many
+    os.environ.setdefault("SIGMAENV_TIMING_STRIDE", str(max(1, min(32, (args.steps // T) // 8))))
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the HIP runtime starts: enough hardware queues for the shard + RCCL streams
     import torch
     import torch.distributed as dist
@@ -388,9 +436,8 @@ def main():
     torch.cuda.set_device(device)
 
     B, N = args.envs_per_gpu, args.agents
-    run = GpuRun(args, device, B, world, rank)
-    for t in range(args.warmup):
-        run.one_step(t)
+    run = GpuRun(args, device, B, world, rank, T=T)
+    run.run_steps(0, args.warmup)
     run.finish_chunk()
     torch.cuda.synchronize()
     run.arm_timing()  # arms the HIP-event bracketing of the step launches (on the env's stream)
@@ -411,13 +458,15 @@ def main():
     slab_bytes = 4.0 * (N * (D + 1) + 1) * B if run.gather is not None else 0.0
     step_s = elapsed / args.steps
     achieved_incl = (bytes_per * N * B + reset_bytes + slab_bytes) / step_s / 1e9
-    per_launch_bytes = bytes_per * N * Bs
+    steps_per_launch = args.steps / float(-(-args.steps // T))  # (== T when --steps is whole launches, the default)
+    per_launch_bytes = bytes_per * N * Bs * steps_per_launch
     traffic, traffic_source = None, None
     try:  # HBM bytes per launch from the separate rocprofv3 --pmc passes (tools/pmc_passes.sh), corrected as the MI355X guide says
         with open(os.path.join(ROOT, "profiles", "traffic_latest.json")) as f:
             tr = json.load(f)
         if tr.get("n_agents") == N and tr.get("envs_per_launch") == Bs and tr.get("distance") == args.distance and tr.get("scenario", "cpm_entire") == args.scenario:
-            traffic = tr["hbm_bytes_per_launch"]
+            # the profile's launches may hold another number of steps: scale by the steps of ONE launch of this run
+            traffic = tr["hbm_bytes_per_launch"] / float(tr.get("steps_per_launch", 1)) * steps_per_launch
             traffic_source = "profiles/traffic_latest.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload (not this run), per launch"
     except Exception:  # noqa: BLE001
         pass
@@ -426,11 +475,13 @@ def main():
         with open(os.path.join(ROOT, "profiles", "valu_latest.json")) as f:
             vj = json.load(f)
         if vj.get("n_agents") == N and vj.get("envs_per_launch") == Bs and vj.get("scenario", "cpm_entire") == args.scenario:
-            launches_per_s = S / step_s  # the per-launch counts of the profile at this run's launch rate
+            # the per-launch counts of the profile (per step of its launches) at this run's step rate
+            vs = float(vj.get("steps_per_launch", 1))
+            launches_per_s = S / step_s
             valu = {
-                "valu_issue_frac": vj["valu_busy_cycles_per_launch"] * launches_per_s / (vj["n_simd"] * vj["clock_hz"]),
-                "fp32_flop_frac": vj["fp32_flops_per_launch"] * launches_per_s / (FP32_PEAK_TFLOPS * 1e12),
-                "valu_insts_per_launch": vj["valu_insts_per_launch"], "valu_source": vj.get("source", "profiles/valu_latest.json") + " (not this run)",
+                "valu_issue_frac": vj["valu_busy_cycles_per_launch"] / vs * launches_per_s / (vj["n_simd"] * vj["clock_hz"]),
+                "fp32_flop_frac": vj["fp32_flops_per_launch"] / vs * launches_per_s / (FP32_PEAK_TFLOPS * 1e12),
+                "valu_insts_per_launch": vj["valu_insts_per_launch"] / vs * steps_per_launch, "valu_source": vj.get("source", "profiles/valu_latest.json") + " (not this run)",
             }
     except Exception:  # noqa: BLE001
         pass
@@ -442,9 +493,9 @@ def main():
         "config": {
             "workload": f"{args.scenario} map, {N} agents x {B} envs per GPU ({B * world} envs total), {args.distance} distance, "
                         f"rew_method={make_params_kw(args, B)['rew_method']}, dt=0.05, obs_dim={D}, start: {run.start}, fused step + device-side reset of finished envs "
-                        + ("(one launch)" if run.fused else "(two launches)" if not args.no_reset else "(resets disabled)")
+                        + ((f"({T} steps per launch)" if T > 1 else "(one launch per step)") if run.fused else "(two launches)" if not args.no_reset else "(resets disabled)")
                         + ((" + rollout record" + ((" + " + run.gather.mode) if run.gather.collective else "")) if run.gather else ""),
-            "n_agents": N, "envs_per_gpu": B, "envs_total": B * world, "distance": args.distance, "scenario": args.scenario, "env_shards_per_gpu": S,
+            "n_agents": N, "envs_per_gpu": B, "envs_total": B * world, "distance": args.distance, "scenario": args.scenario, "env_shards_per_gpu": S, "steps_per_launch": T,
             "policy": (f"actor MLP 32-256-256-256-4 ({args.policy_precision}) on device before every step" if args.policy
                        else "none in the timed region (precomputed actions resident in HBM)"),
             **({"cbf": ("centralized CBF-QP safety filter of every env (sigmaenv_cbf_qp: 2 N controls, lane + pair constraints, projected "
@@ -459,7 +510,8 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
             "traffic": traffic, "traffic_source": traffic_source,
-            "kernel": "sigmaenv_step_wave_kernel", "kernel_avg_ms": kernel_ms, "kernel_launches": n_launch, "launches_per_step": S,
+            "kernel": "sigmaenv_step_wave_kernel", "kernel_avg_ms": kernel_ms, "kernel_launches": n_launch, "launches_per_step": S / steps_per_launch, "steps_per_launch": steps_per_launch,
+            "kernel_ms_per_step": kernel_ms / steps_per_launch,
             "algorithmic_bytes_per_agent_env_step": bytes_per, "algorithmic_bytes_per_launch": per_launch_bytes,
             "achieved_per_launch": (per_launch_bytes / (kernel_ms * 1e-3) / 1e9) if kernel_ms > 0 else None,
             "achieved_incl_record": achieved_incl,
@@ -470,30 +522,42 @@ def main():
         },
     }
     run.close()
-    if S > 1 and not args.no_one_stream and world == 1 and not use_dist:
-        # the same workload with ONE launch per step (no env shards): what the kernel does without the host-side overlap of two launches
-        import copy
-
-        a1 = copy.copy(args)
-        a1.streams = 1
-        r1 = GpuRun(a1, device, B, world, rank)
-        for t in range(min(args.warmup, 32)):
-            r1.one_step(t)
+    if T > 1 and not args.no_compare and world == 1 and not use_dist:
+        # the same workload with ONE launch per step (two env shards on two streams, the round-2 form): what the step loop inside the kernel buys
+        r1 = GpuRun(args, device, B, world, rank, T=1)
+        r1.run_steps(0, min(args.warmup, 32))
         r1.finish_chunk()
         el1 = timed(r1, args.steps, args.warmup, use_dist, dist, torch, device)
-        out["config"]["one_stream"] = {"ms_per_step": el1 / args.steps * 1e3, "value": total_agent_steps / el1,
-                                       "note": "same steps, one handle and one launch per step on one stream (timed after the headline region)"}
+        out["config"]["per_step_launch"] = {"ms_per_step": el1 / args.steps * 1e3, "value": total_agent_steps / el1, "env_shards_per_gpu": r1.S,
+                                            "note": "same steps, one launch per step and env shard (sigmaenv_step_autoreset), timed after the headline region"}
         r1.close()
+    if args.emulate_ranks > 1 and world == 1:
+        # BASELINE config 3 (16 agents x 32768 envs over 8 GPUs) on the one GPU of this box: rank r's shard -- envs [r B, (r + 1) B) of the batch, the
+        # same seed, its own rollout exchange (RCCL with world size 1 under --force-dist) -- timed like the headline, one rank after the other
+        shards = []
+        for r in range(args.emulate_ranks):
+            rr = GpuRun(args, device, B, 1, 0, T=T, env_base=r * B)
+            rr.run_steps(0, args.warmup)
+            rr.finish_chunk()
+            el = timed(rr, args.steps, args.warmup, use_dist, dist, torch, device)
+            shards.append(el / args.steps * 1e3)
+            rr.close()
+        out["config"]["emulated_ranks"] = {
+            "ranks": args.emulate_ranks, "envs_total": B * args.emulate_ranks, "ms_per_step_per_rank": shards,
+            "value_if_concurrent": N * B * args.emulate_ranks / (max(shards) * 1e-3),
+            "note": "every rank's shard of the sharded batch stepped on THIS GPU, one after the other (same seed, env_index_base = r B); value_if_concurrent = "
+                    "all ranks' agent-env-steps / the slowest rank's time -- what N GPUs deliver when the exchange hides behind the steps; NOT a measured multi-GPU number",
+        }
     if args.sweep:
         sweep = []
         for Bx in [int(x) for x in args.sweep_envs.split(",") if x]:
-            r = GpuRun(args, device, Bx, world, rank)
-            for t in range(16):
-                r.one_step(t)
+            Tx = 1 if not plain else (args.chunk if args.chunk >= 1 else pick_chunk(args.sweep_steps))
+            r = GpuRun(args, device, Bx, world, rank, T=Tx)
+            r.run_steps(0, 16)
             r.finish_chunk()
             el = timed(r, args.sweep_steps, 16, use_dist, dist, torch, device)
             sweep.append({"envs_per_gpu": Bx, "value": N * Bx * world * args.sweep_steps / el, "ms_per_step": el / args.sweep_steps * 1e3,
-                          "env_shards_per_gpu": r.S, "roofline_frac": bytes_per * (N * Bx * args.sweep_steps / el) / 1e9 / HBM_PEAK_GBPS})
+                          "env_shards_per_gpu": r.S, "steps_per_launch": Tx, "roofline_frac": bytes_per * (N * Bx * args.sweep_steps / el) / 1e9 / HBM_PEAK_GBPS})
             r.close()
         out["sweep"] = sweep
     if rank == 0 and args.cpu_seconds > 0 and world == 1:

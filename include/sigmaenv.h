@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define SIGMAENV_ABI_VERSION 3
+#define SIGMAENV_ABI_VERSION 4
 
 /* error codes */
 #define SIGMAENV_OK 0
@@ -105,6 +105,13 @@ typedef struct sigmaenv_config {
   int32_t obs_flags;            /* SIGMAENV_OBS_*: non-default observation layout (below); 0 = the reference's config.json defaults */
   float reset_agent_fixed_duration; /* Parameters.reset_agent_fixed_duration [s], 0 = off: every env is also done when t = step * dt (fp32) is a
                                      * non-zero multiple of it (t % duration == 0, road_traffic.py:1388-1397, :1431, :1454) */
+  int32_t env_index_base;       /* index of this handle's env 0 in the whole batch (shard_range begin when the batch is sharded over handles / GPUs, else
+                                 * 0): every device-side random draw -- reset sampler, observation noise, action sampling -- is keyed on
+                                 * (seed, counter, env_index_base + local env, agent, draw), so a sharded batch draws exactly what the unsharded
+                                 * batch draws, whatever the number of shards */
+  float obs_noise_level;        /* Parameters.obs_noise_level when Parameters.is_obs_noise, else 0: amplitude of the uniform noise
+                                 * `obs + level * (2 U[0,1) - 1)`... see sigmaenv_set_obs_noise; 0 = no noise on the device */
+  int32_t reserved[6];          /* must be 0 */
 } sigmaenv_config_t;
 
 /* Unpadded reference-path table (output of the map parser, sigmarl/map_manager.py:13-40).  The library builds the padded
@@ -214,6 +221,17 @@ int sigmaenv_step_autoreset(sigmaenv_t* h, const float* actions, uint64_t seed, 
  * slab_ptrs[k] (array may be NULL: record targets unchanged) and steps on actions[k] with seeds[k]. */
 int sigmaenv_step_autoreset_many(sigmaenv_t** hs, int32_t n, const float* const* actions, float* const* slab_ptrs, const uint64_t* seeds,
                                  uint64_t counter, int32_t path_first, int32_t path_count);
+
+/* n_steps fused steps of every env in ONE launch -- the reference's rollout loop over a chunk of steps for actions that are already on the
+ * device (sigmarl/helper_training.py:687-788: `for t in range(max_steps): policy; env.step; step_mdp`, and TorchRL's step_and_maybe_reset
+ * per step).  Step t reads actions + t * action_stride floats ([B, N, 2]; stride 0 repeats one block), draws its resets from
+ * (seed, counter0 + t) and records into slab + t * slab_stride floats ([B, N (D + 1) + 1]; slab may be NULL).  End state, record rows and reset
+ * draws are bit-identical to n_steps calls of sigmaenv_step_autoreset with sigmaenv_set_slab(slab + t * slab_stride) before call t; the
+ * pointer of sigmaenv_set_slab itself is neither used nor changed.  Every wavefront walks its own env tile through the n_steps steps (envs
+ * never read each other), so launch ramp / tail and the host's enqueue are paid once per call.  Not available (EINVAL) with a "cbf" rew_method
+ * when n_steps > 1: those need sigmaenv_cbf_rewards / sigmaenv_cbf_qp between the steps. */
+int sigmaenv_step_autoreset_n(sigmaenv_t* h, const float* actions, int32_t n_steps, int64_t action_stride, float* slab, int64_t slab_stride,
+                              uint64_t seed, uint64_t counter0, int32_t path_first, int32_t path_count);
 
 int sigmaenv_get(sigmaenv_t* h, sigmaenv_buf_t which, void** dev_ptr, size_t* bytes);
 

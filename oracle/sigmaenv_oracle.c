@@ -726,10 +726,10 @@ static void auto_reset_env(oracle_t* o, int b, uint64_t seed, uint64_t counter, 
     float* s = o->state + bi * 8;
     int path = path_first, pt = 3;
     for (int t = 0; t < AUTO_RESET_MAX_TRIES; ++t) {
-      path = path_first + (int)(((uint64_t)rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, 2u * t) * (uint64_t)(uint32_t)path_count) >> 32);
+      path = path_first + (int)(((uint64_t)rng_u32(seed, counter, (uint32_t)(c->env_index_base + b), (uint32_t)i, 2u * t) * (uint64_t)(uint32_t)path_count) >> 32);
       int n = o->n_center[path];
       int end = reset_end_point(c->is_testing_mode, t, n);
-      pt = 3 + (int)(((uint64_t)rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, 2u * t + 1u) * (uint64_t)(uint32_t)(end - 3)) >> 32);
+      pt = 3 + (int)(((uint64_t)rng_u32(seed, counter, (uint32_t)(c->env_index_base + b), (uint32_t)i, 2u * t + 1u) * (uint64_t)(uint32_t)(end - 3)) >> 32);
       float px = o->center[((size_t)path * o->P + pt) * 2], py = o->center[((size_t)path * o->P + pt) * 2 + 1];
       s[0] = px; s[1] = py;
       int ok = 1;
@@ -741,7 +741,7 @@ static void auto_reset_env(oracle_t* o, int b, uint64_t seed, uint64_t counter, 
       }
       if (ok) break;
     }
-    float u = (float)(rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, 1000u) >> 8) * (1.0f / 16777216.0f);
+    float u = (float)(rng_u32(seed, counter, (uint32_t)(c->env_index_base + b), (uint32_t)i, 1000u) >> 8) * (1.0f / 16777216.0f);
     int ny = o->yaw_stride;
     int yi = pt < ny ? pt : ny - 1;
     float rot = o->yaw[(size_t)path * o->yaw_stride + yi];
@@ -902,10 +902,10 @@ static void auto_reset_agents(oracle_t* o, int b, uint64_t seed, uint64_t counte
     int path = path_first, pt = 3;
     float px = 0.f, py = 0.f;
     for (int t = 0; t < AUTO_RESET_MAX_TRIES; ++t) {
-      path = path_first + (int)(((uint64_t)rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, 2000u + 2u * t) * (uint64_t)(uint32_t)path_count) >> 32);
+      path = path_first + (int)(((uint64_t)rng_u32(seed, counter, (uint32_t)(c->env_index_base + b), (uint32_t)i, 2000u + 2u * t) * (uint64_t)(uint32_t)path_count) >> 32);
       int n = o->n_center[path];
       int end = reset_end_point(c->is_testing_mode, t, n);
-      pt = 3 + (int)(((uint64_t)rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, 2001u + 2u * t) * (uint64_t)(uint32_t)(end - 3)) >> 32);
+      pt = 3 + (int)(((uint64_t)rng_u32(seed, counter, (uint32_t)(c->env_index_base + b), (uint32_t)i, 2001u + 2u * t) * (uint64_t)(uint32_t)(end - 3)) >> 32);
       px = o->center[((size_t)path * o->P + pt) * 2]; py = o->center[((size_t)path * o->P + pt) * 2 + 1];
       int ok = 1;
       for (int j = 0; j < N; ++j) {
@@ -917,7 +917,7 @@ static void auto_reset_agents(oracle_t* o, int b, uint64_t seed, uint64_t counte
       }
       if (ok) break;
     }
-    float u = (float)(rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, 3000u) >> 8) * (1.0f / 16777216.0f);
+    float u = (float)(rng_u32(seed, counter, (uint32_t)(c->env_index_base + b), (uint32_t)i, 3000u) >> 8) * (1.0f / 16777216.0f);
     int yi = pt < o->yaw_stride ? pt : o->yaw_stride - 1;
     float rot = o->yaw[(size_t)path * o->yaw_stride + yi];
     float speed = u * c->max_speed;

@@ -100,11 +100,22 @@ class Actor:
             arrs.append(np.ascontiguousarray(m.weight.detach().cpu().numpy(), np.float32))
             arrs.append(np.ascontiguousarray(m.bias.detach().cpu().numpy(), np.float32))
         self._keep = arrs + [np.ascontiguousarray(low, np.float32), np.ascontiguousarray(high, np.float32)]
-        h = C.c_void_p()
-        rc = self.lib.actor_create(self.obs_dim, *[a.ctypes.data_as(C.c_void_p) for a in self._keep], C.byref(h))
-        if rc != 0:
-            raise RuntimeError(f"sigmaenv_actor_create failed with code {rc}")
-        self.h = h
+        # the bf16 kernel handle exists only for the widths its MFMA tiling takes (sigmaenv_actor_create: obs_dim in {8, 16, 24, 32}); other
+        # observation switches (e.g. is_obs_steering: 35) run the exact-fp32 network, which takes any width
+        self.h = None
+        if precision == "bf16":
+            self._bf16_handle()
+
+    def _bf16_handle(self):
+        if self.h is None:
+            if self.obs_dim not in (8, 16, 24, 32):
+                raise ValueError(f"the bf16 actor kernel takes obs_dim 8, 16, 24 or 32, not {self.obs_dim}: use precision='fp32' for this observation layout")
+            h = C.c_void_p()
+            rc = self.lib.actor_create(self.obs_dim, *[a.ctypes.data_as(C.c_void_p) for a in self._keep], C.byref(h))
+            if rc != 0:
+                raise RuntimeError(f"sigmaenv_actor_create failed with code {rc}")
+            self.h = h
+        return self.h
 
     def close(self):
         if getattr(self, "h", None):
@@ -134,7 +145,7 @@ class Actor:
             if rc != 0:
                 raise RuntimeError(f"sigmaenv_actor_forward_f32 failed with code {rc}: {env.lib.last_error(env.h).decode()}")
             return actions
-        rc = self.lib.actor_forward(env.h, self.h, p(obs), p(actions), p(log_prob), p(loc_scale), int(seed), int(counter), int(bool(deterministic)))
+        rc = self.lib.actor_forward(env.h, self._bf16_handle(), p(obs), p(actions), p(log_prob), p(loc_scale), int(seed), int(counter), int(bool(deterministic)))
         if rc != 0:
             raise RuntimeError(f"sigmaenv_actor_forward failed with code {rc}: {env.lib.last_error(env.h).decode()}")
         return actions

@@ -14,7 +14,7 @@ import ctypes as C
 import math
 import os
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 DIST_C2C, DIST_MTV = 0, 1
 REW_DISTANCE, REW_TTC, REW_EXACT_SPARSE, REW_HAS_SPARSE, REW_CBF, REW_CBF_QP = 1, 2, 4, 8, 16, 32
 CBF_MAX_CIRCLES = 4
@@ -50,6 +50,7 @@ class Config(C.Structure):
         ("ttc_low", C.c_float), ("ttc_high", C.c_float),
         ("penalty_deviate_from_cbf_vel", C.c_float), ("penalty_deviate_from_cbf_steer", C.c_float),
         ("is_apply_mask", C.c_int32), ("distance_mask_agents", C.c_float), ("obs_flags", C.c_int32), ("reset_agent_fixed_duration", C.c_float),
+        ("env_index_base", C.c_int32), ("obs_noise_level", C.c_float), ("reserved", C.c_int32 * 6),
     ]
 
 
@@ -141,6 +142,7 @@ _PRODUCT_ONLY = {
     "set_slab": (C.c_int, [C.c_void_p, C.c_void_p]),
     "trig_selftest": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "step_autoreset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32]),
+    "step_autoreset_n": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32]),
     "step_autoreset_many": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32]),
     "actor_create": (C.c_int, [C.c_int32] + [C.c_void_p] * 10 + [C.POINTER(C.c_void_p)]),
     "actor_destroy": (None, [C.c_void_p]),

@@ -51,7 +51,8 @@ __device__ __constant__ uint32_t W_REF_BITS[3] = {0x3F0E38E3u, 0x3EAAAAABu, 0x3D
 #define COL_STRIDE(N) ((N) + 4)    /* byte stride whose word stride ((N+4)/4) is odd for N = 16 */
 #define ESCR_BYTES (8 * 4 * 4 * 16) /* up to 8 wavefronts x 4 lane groups x 4 segments x float4 */
 #define CAND_LIST 16               /* candidate chunks listed per (agent, polyline); longer masks fall back to bit counting */
-#define ITEM_CAP(S) ((S) * 24)       /* candidate chunks of a tile listed for the balanced scan; tasks beyond it walk their chunks themselves */
+#define ITEM_CAP(S) ((S) * 24 > 64 ? (S) * 24 : 64)  /* candidate chunks of a tile listed per round of the balanced scan; never below 64: ONE task can have up to 64 candidate
+                                                        chunks (the masks are 64-bit) and must fit the list alone, else a round could list nothing and the scan would spin */
 #define NEAR_CAP 8                 /* boundary segments within the circumradius listed per (agent, side); more are tested in place */
 struct Smem {
   float *st, *vold, *vnew, *shrt, *dref, *dleft, *dright, *dbound, *dist, *obs, *thr, *cs, *rew;
@@ -128,7 +129,15 @@ __device__ __forceinline__ void wave_sync() {
 }
 template <bool WAVE>
 struct Grp {
-  __device__ static __forceinline__ int tid() { return WAVE ? (int)(threadIdx.x & 63) : (int)threadIdx.x; }
+  // (wavefront groups: the lane index passes through an empty asm, so that inside the step kernel's step loop nothing derived from it is a loop
+  // invariant the compiler would keep in registers across the whole loop body -- see sigmaenv_step_wave_kernel)
+  __device__ static __forceinline__ int tid() {
+    if (!WAVE) return (int)threadIdx.x;
+    int x = (int)(threadIdx.x & 63);
+    asm volatile("" : "+v"(x));
+    __builtin_assume(x >= 0 && x < 64);
+    return x;
+  }
   __device__ static __forceinline__ int size() { return WAVE ? 64 : (int)blockDim.x; }
   __device__ static __forceinline__ void sync() { if (WAVE) wave_sync(); else __syncthreads(); }
 };
@@ -749,6 +758,7 @@ struct ResetDraw {
   uint64_t seed, counter;
   int path_first, path_count;
   int testing;  // is_testing_mode: the candidate range starts at the path's beginning and grows with the tries
+  int env_base; // sigmaenv_config_t.env_index_base: the generator is keyed on the env's index in the WHOLE batch
 };
 // exclusive upper end of the centre-line points try `tr` may draw from (world_state_rt_sim.py:253-263; specification shared with the oracle)
 __device__ __forceinline__ int reset_end_point(int testing, int tr, int n) {
@@ -762,10 +772,10 @@ __device__ __forceinline__ int reset_end_point(int testing, int tr, int n) {
 }
 __device__ __forceinline__ void reset_candidate(const DevMap& m, const ResetDraw& rd, int b, int i, int tr, int& path, int& pt, float& px, float& py,
                                                 uint32_t draw0 = 0u) {
-  path = rd.path_first + (int)__umulhi(rng_u32(rd.seed, rd.counter, (uint32_t)b, (uint32_t)i, draw0 + 2u * tr), (uint32_t)rd.path_count);
+  path = rd.path_first + (int)__umulhi(rng_u32(rd.seed, rd.counter, (uint32_t)(rd.env_base + b), (uint32_t)i, draw0 + 2u * tr), (uint32_t)rd.path_count);
   int n = m.n_center[path];
   const int end = reset_end_point(rd.testing, tr, n);
-  pt = 3 + (int)__umulhi(rng_u32(rd.seed, rd.counter, (uint32_t)b, (uint32_t)i, draw0 + 2u * tr + 1u), (uint32_t)(end - 3));
+  pt = 3 + (int)__umulhi(rng_u32(rd.seed, rd.counter, (uint32_t)(rd.env_base + b), (uint32_t)i, draw0 + 2u * tr + 1u), (uint32_t)(end - 3));
   const float2 xy = reinterpret_cast<const float2*>(m.center)[(size_t)path * m.P + pt];
   px = xy.x;
   py = xy.y;
@@ -1134,7 +1144,7 @@ __device__ inline void auto_reset_tile(const sigmaenv_config_t& c, const DevMap&
                                        int path_count, int obs_mode, const ResetPrefetch& pre, int g_cap) {
   const int N = t.N;
   const int tid = Grp<WAVE>::tid(), lane = tid & 63, wave = tid >> 6, n_waves = Grp<WAVE>::size() >> 6;
-  const ResetDraw rd{seed, counter, path_first, path_count, c.is_testing_mode};
+  const ResetDraw rd{seed, counter, path_first, path_count, c.is_testing_mode, c.env_index_base};
 #define TS2(k) PROF_TS2(g, tid, k)
   TS2(1);
   const float min_d = sqrtf((float)((double)c.length * (double)c.length + (double)c.width * (double)c.width)) * 1.5f;  // road_traffic.py:679-684
@@ -1164,7 +1174,7 @@ __device__ inline void auto_reset_tile(const sigmaenv_config_t& c, const DevMap&
         unsigned long long f2 = __ballot(ok);
         const int wl = f2 ? (__ffsll((long long)f2) - 1) : (AUTO_RESET_MAX_TRIES - 1);
         if (lane == wl) {
-          float u = (float)(rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, 3000u) >> 8) * (1.0f / 16777216.0f);
+          float u = (float)(rng_u32(seed, counter, (uint32_t)(c.env_index_base + b), (uint32_t)i, 3000u) >> 8) * (1.0f / 16777216.0f);
           place_from_start_table(m, g, s, t, sl, p2, q2, u * c.max_speed, path_first, false);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1214,7 +1224,7 @@ __device__ inline void auto_reset_tile(const sigmaenv_config_t& c, const DevMap&
     }
     if (lane < N) {  // finalise the accepted starts, one lane per agent (world_state_rt_sim.py:189-213)
       const int i = lane, sl = e * N + i;
-      float u = (float)(rng_u32(seed, counter, (uint32_t)b, (uint32_t)i, 1000u) >> 8) * (1.0f / 16777216.0f);
+      float u = (float)(rng_u32(seed, counter, (uint32_t)(c.env_index_base + b), (uint32_t)i, 1000u) >> 8) * (1.0f / 16777216.0f);
       place_from_start_table(m, g, s, t, sl, my_path, my_pt, u * c.max_speed, path_first, true);
     }
   }
@@ -1370,6 +1380,8 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
   if (!cfg || !map || !out) return SIGMAENV_EINVAL;
   *out = nullptr;
   if (cfg->abi_version != SIGMAENV_ABI_VERSION) return SIGMAENV_EINVAL;
+  for (int k = 0; k < 6; ++k) if (cfg->reserved[k] != 0) return SIGMAENV_EINVAL;
+  if (cfg->env_index_base < 0 || !(cfg->obs_noise_level >= 0.0f)) return SIGMAENV_EINVAL;
   if (cfg->n_envs < 1 || cfg->n_agents < 1 || cfg->n_agents > SIGMAENV_MAX_AGENTS) return SIGMAENV_EINVAL;
   if (cfg->n_nearing < 0 || cfg->n_nearing > SIGMAENV_MAX_NEARING || cfg->n_nearing > cfg->n_agents - 1) return SIGMAENV_EINVAL;
   if (cfg->distance_type != SIGMAENV_DIST_C2C && cfg->distance_type != SIGMAENV_DIST_MTV) return SIGMAENV_EINVAL;
@@ -1717,8 +1729,12 @@ extern "C" int sigmaenv_reset(sigmaenv_t* h, int32_t n, const int32_t* env_idx, 
   return SIGMAENV_OK;
 }
 
-static int launch_step(sigmaenv* h, const float* actions, uint64_t seed, uint64_t counter, int path_first, int path_count) {
+// n_steps launches' worth of fused steps in ONE launch when n_steps > 1 (sigmaenv_step_autoreset_n): step t reads actions + t * act_stride, draws its
+// resets from counter + t and records into slab + t * slab_stride (floats)
+static int launch_step(sigmaenv* h, const float* actions, uint64_t seed, uint64_t counter, int path_first, int path_count, int n_steps = 1, size_t act_stride = 0,
+                       float* slab = nullptr, size_t slab_stride = 0, bool slab_from_handle = true) {
   if (!h || !actions) return SIGMAENV_EINVAL;
+  if (slab_from_handle) slab = h->buf.slab;
   HIPCHK(h, hipSetDevice(h->device));  // handles on several GPUs may live in one process: every entry point that enqueues work selects its device
   int slot = -1;
   // HIP-event bracketing of a SAMPLE of the launches (every timing_stride-th): every event pair costs a few microseconds of
@@ -1748,8 +1764,8 @@ static int launch_step(sigmaenv* h, const float* actions, uint64_t seed, uint64_
         default: break;
       }
     }
-    hipLaunchKernelGGL(kern, dim3(h->wave_grid), dim3(64 * h->wave_wpb), h->wave_tile_lds * h->wave_wpb, h->stream, h->d_cfg, h->map, h->buf, actions,
-                       h->wave_G, (int)h->wave_tile_lds, seed, counter, path_first, path_count, h->buf.slab);
+    const StepKernArgs ka{h->map, h->buf, actions, slab, act_stride, slab_stride, seed, counter, h->wave_G, (int)h->wave_tile_lds, path_first, path_count, n_steps};
+    hipLaunchKernelGGL(kern, dim3(h->wave_grid), dim3(64 * h->wave_wpb), h->wave_tile_lds * h->wave_wpb, h->stream, (const sigmaenv_config_t*)h->d_cfg, ka);
   }
   HIPCHK(h, hipGetLastError());
   if (slot >= 0) HIPCHK(h, hipEventRecord(h->ev_pool[slot].second, h->stream));
@@ -1761,6 +1777,28 @@ extern "C" int sigmaenv_step(sigmaenv_t* h, const float* actions) { return launc
 extern "C" int sigmaenv_step_autoreset(sigmaenv_t* h, const float* actions, uint64_t seed, uint64_t counter, int32_t path_first, int32_t path_count) {
   if (!h || path_first < 0 || path_count < 1 || path_first + path_count > h->n_paths) return SIGMAENV_EINVAL;
   return launch_step(h, actions, seed, counter, path_first, path_count);
+}
+
+// n_steps fused steps (step + rollout record + device-side resets) of every env in ONE launch: the reference's rollout loop over a chunk of steps
+// (helper_training.py:687-788: policy -> env.step -> step_mdp, T times) for actions that are already on the device.  Same end state, same record
+// rows and same reset draws as n_steps calls of sigmaenv_step_autoreset(h, actions + t * action_stride, seed, counter0 + t, ...) with the slab set to
+// slab + t * slab_stride -- bit for bit (tests/test_gpu_nstep.py); envs are independent, so every wavefront walks its own env through the n_steps steps
+// without waiting for any other.  actions: device f32, step t at actions + t * action_stride floats ([B, N, 2] each; action_stride 0 repeats one
+// action block); slab: device f32 or NULL, row block t ([B, N (D + 1) + 1]) at slab + t * slab_stride floats.
+extern "C" int sigmaenv_step_autoreset_n(sigmaenv_t* h, const float* actions, int32_t n_steps, int64_t action_stride, float* slab, int64_t slab_stride,
+                                         uint64_t seed, uint64_t counter0, int32_t path_first, int32_t path_count) {
+  if (!h) return SIGMAENV_EINVAL;
+  if (!actions || n_steps < 1 || action_stride < 0 || slab_stride < 0 || path_first < 0 || path_count < 1 || path_first + path_count > h->n_paths) {
+    h->err = "step_autoreset_n: bad argument";
+    return SIGMAENV_EINVAL;
+  }
+  if (slab && h->obs_var) { h->err = "step_autoreset_n: the rollout record holds the default observation row; not available with obs_flags != 0"; return SIGMAENV_EINVAL; }
+  if (n_steps > 1 && (h->cfg.rew_flags & (SIGMAENV_REW_CBF | SIGMAENV_REW_CBF_QP))) {
+    // the CBF reward channels / the safe action of step t come from a separate launch between the policy and step t (sigmaenv_cbf_rewards / _qp)
+    h->err = "step_autoreset_n: rew_method with \"cbf\" needs the CBF launch before every step; use sigmaenv_step_autoreset (or sigmaenv_rollout)";
+    return SIGMAENV_EINVAL;
+  }
+  return launch_step(h, actions, seed, counter0, path_first, path_count, n_steps, (size_t)action_stride, slab, (size_t)slab_stride, false);
 }
 
 // One call for several handles (env shards of one GPU on their own streams): slab_ptrs[k] (may be NULL) becomes handle k's record

@@ -102,7 +102,7 @@ class SigmaEnv:
 
     def __init__(self, parameters: Parameters | None = None, n_envs: int | None = None, device=None, *, cfg: capi.Config | None = None,
                  map_table: MapTable | None = None, make_world_scenario_type: str = "cpm_entire", lib_path: str | None = None,
-                 envs_per_group: int = 0):
+                 envs_per_group: int = 0, env_index_base: int | None = None):
         if not torch.cuda.is_available():
             raise RuntimeError("sigmarl_amd.SigmaEnv needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
         self.lib = capi.load_library(lib_path)
@@ -111,6 +111,8 @@ class SigmaEnv:
                 raise ValueError("pass `parameters` (+ n_envs) or a ready `cfg` + `map_table`")
             map_table = map_table or load_map(parameters.scenario_type)
             cfg = make_config(parameters, map_table, int(n_envs if n_envs is not None else parameters.num_vmas_envs), make_world_scenario_type)
+        if env_index_base is not None:  # this shard's first env in the whole batch (shard.shard_range): the random draws of env e do not depend on the sharding
+            cfg.env_index_base = int(env_index_base)
         if envs_per_group:  # full tiles even for a small shard (several handles stepped concurrently on different streams)
             cfg.envs_per_group = int(envs_per_group)
         self.parameters = parameters
@@ -268,6 +270,34 @@ class SigmaEnv:
             path_first, path_count = self.map.list_first[0], self.map.list_count[0]
         self._chk(self.lib.step_autoreset(self.h, C.c_void_p(actions.data_ptr()), int(seed), int(counter), int(path_first), int(path_count)),
                   "step_autoreset")
+
+    def step_autoreset_n(self, actions: torch.Tensor, slab: torch.Tensor | None = None, seed: int = 0, counter0: int | None = None,
+                         path_first: int | None = None, path_count: int | None = None):
+        """``actions.shape[0]`` fused steps in ONE launch (``sigmaenv_step_autoreset_n``): ``actions`` float32 CUDA ``[T, B, N, 2]``, optional record
+        ``slab`` ``[T, B, N*(D+1)+1]``; same end state, record and reset draws as T calls of ``step_autoreset`` with counters ``counter0 + t``."""
+        if not (isinstance(actions, torch.Tensor) and actions.is_cuda and actions.dtype == torch.float32 and actions.is_contiguous()):
+            raise TypeError("actions must be a contiguous float32 CUDA tensor")
+        if actions.dim() != 4 or tuple(actions.shape[1:]) != (self.B, self.N, 2) or actions.shape[0] < 1:
+            raise ValueError(f"actions must have shape (T, {self.B}, {self.N}, 2), got {tuple(actions.shape)}")
+        T = int(actions.shape[0])
+        W = self.N * (self.D + 1) + 1
+        if slab is not None:
+            if not (slab.is_cuda and slab.dtype == torch.float32 and slab.is_contiguous() and tuple(slab.shape) == (T, self.B, W)):
+                raise ValueError(f"slab must be a contiguous float32 CUDA tensor of shape {(T, self.B, W)}")
+            self._warn_noise_free("the rollout slab")
+        if counter0 is None:
+            counter0 = self._reset_counter
+            self._reset_counter += T
+        if path_first is None:
+            path_first, path_count = self.map.list_first[0], self.map.list_count[0]
+        self.step_autoreset_n_ptr(actions.data_ptr(), T, self.B * self.N * 2, slab.data_ptr() if slab is not None else 0, self.B * W, seed, counter0,
+                                  path_first, path_count)
+
+    def step_autoreset_n_ptr(self, actions_ptr: int, n_steps: int, action_stride: int, slab_ptr: int, slab_stride: int, seed: int, counter0: int,
+                             path_first: int, path_count: int):
+        """Pointer-level form (strides in floats): lets a caller step several env shards into one ``[T, B_total, W]`` chunk buffer."""
+        self._chk(self.lib.step_autoreset_n(self.h, C.c_void_p(actions_ptr), int(n_steps), int(action_stride), C.c_void_p(slab_ptr) if slab_ptr else None,
+                                            int(slab_stride), int(seed), int(counter0), int(path_first), int(path_count)), "step_autoreset_n")
 
     def auto_reset(self, seed: int = 0, counter: int | None = None, path_first: int | None = None, path_count: int | None = None):
         if counter is None:

@@ -149,7 +149,7 @@ def check_supported(p: Parameters) -> None:
 CPM_LANE_WIDTH = 0.15
 
 
-def make_config(p: Parameters, map_table, n_envs: int, make_world_scenario_type: str = "cpm_entire") -> capi.Config:
+def make_config(p: Parameters, map_table, n_envs: int, make_world_scenario_type: str = "cpm_entire", env_index_base: int = 0) -> capi.Config:
     """Thresholds/penalties exactly as ``ScenarioRoadTraffic._init_params`` derives them when ``scenario.parameters``
     is pre-set (``sigmarl/scenarios/road_traffic.py:132-175,214-270``)."""
     check_supported(p)
@@ -160,6 +160,7 @@ def make_config(p: Parameters, map_table, n_envs: int, make_world_scenario_type:
     c = capi.Config()
     c.abi_version = capi.ABI_VERSION
     c.n_envs = int(n_envs)
+    c.env_index_base = int(env_index_base)  # this handle's first env in the whole batch (shard_range begin): keys the device-side random draws
     c.n_agents = n_agents
     c.distance_type = capi.DIST_MTV if mtv else capi.DIST_C2C
     c.rew_flags = capi.rew_flags_from_method(p.rew_method, bool(p.is_solve_qp))

@@ -78,11 +78,16 @@ class RolloutExchange:
         shape = (self.T, local_envs, slab_width(n_agents, obs_dim))
         self.chunks = [torch.empty(shape, dtype=torch.float32, device=device) for _ in range(2)]
         self.recv = None
+        # mode "alltoall": rank r receives the time slice [slices[r], slices[r + 1]) of every rank's chunk; T need not be a multiple of the world
+        # size (the driver's 20-step run on 8 GPUs: slices of 2 or 3 steps)
+        self.slices = [(r * self.T) // self.world for r in range(self.world + 1)]
         if self.collective and mode == "alltoall":
-            if self.T % self.world:
-                raise ValueError(f"alltoall exchange: chunk_steps ({self.T}) must be a multiple of the world size ({self.world})")
+            my = self.slices[self.rank + 1] - self.slices[self.rank]
             # [source rank, steps of my time slice, envs of the source rank, W]
-            self.recv = [torch.empty((self.world, self.T // self.world) + shape[1:], dtype=torch.float32, device=device) for _ in range(2)]
+            self.recv = [torch.empty((self.world, my) + shape[1:], dtype=torch.float32, device=device) for _ in range(2)]
+            row = shape[1] * shape[2]
+            self._in_splits = [(self.slices[r + 1] - self.slices[r]) * row for r in range(self.world)]
+            self._out_splits = [my * row] * self.world
         elif self.rank == dst and self.collective:
             self.recv = [[torch.empty(shape, dtype=torch.float32, device=device) for _ in range(self.world)] for _ in range(2)]
         self.pending = [None, None]
@@ -103,6 +108,19 @@ class RolloutExchange:
             self.pending[self.cur] = None
         return self.chunks[self.cur][self.t]
 
+    def chunk(self, writer_streams=None) -> torch.Tensor:
+        """The whole ``[T, B, W]`` buffer the next T steps must be recorded into by ONE n-step launch (``SigmaEnv.step_autoreset_n``); follow
+        the launch with ``commit``."""
+        if self.t != 0:
+            raise RuntimeError("chunk(): the current buffer is partly filled by per-step slots")
+        self.slot(writer_streams)
+        return self.chunks[self.cur]
+
+    def commit(self, n_steps: int | None = None, writer_streams=None):
+        """The launch that fills ``chunk()`` (its first ``n_steps`` rows, default all) has been enqueued: ship the buffer."""
+        self.t = self.T if n_steps is None else int(n_steps)
+        self.flush(writer_streams)
+
     def advance(self, writer_streams=None):
         """Call after the step that filled ``slot()`` has been enqueued; ships the chunk when it is full.  ``writer_streams``: as in ``slot``."""
         self.t += 1
@@ -122,7 +140,8 @@ class RolloutExchange:
                     cur.wait_stream(st)
         self.valid_steps[k] = self.t
         if self.collective and self.mode == "alltoall":
-            self.pending[k] = dist.all_to_all_single(self.recv[k].view(-1), self.chunks[k].view(-1), group=self.group, async_op=True)
+            self.pending[k] = dist.all_to_all_single(self.recv[k].view(-1), self.chunks[k].view(-1), self._out_splits, self._in_splits, group=self.group,
+                                                     async_op=True)
         elif self.collective:
             self.pending[k] = dist.gather(self.chunks[k], self.recv[k] if self.rank == self.dst else None, dst=self.dst, group=self.group,
                                           async_op=True)
@@ -145,8 +164,8 @@ class RolloutExchange:
         return self.recv[k] if self.rank == self.dst else None
 
     def time_slice(self, k):
-        """mode "alltoall": this rank's share of buffer k (after ``wait_all``): ``[T / W, W * B, W_row]`` -- steps
-        ``[rank T/W, (rank+1) T/W)`` of the chunk for the envs of ALL ranks (ranks own contiguous env ranges, in rank order)."""
+        """mode "alltoall": this rank's share of buffer k (after ``wait_all``): ``[my steps, W * B, W_row]`` -- steps
+        ``[slices[rank], slices[rank + 1])`` of the chunk for the envs of ALL ranks (ranks own contiguous env ranges, in rank order)."""
         if not self.collective:
             return self.chunks[k]
         r = self.recv[k]  # [source rank, T / W, B, W_row]

@@ -35,17 +35,20 @@ def test_default_line_follows_the_contract():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["algorithmic_bytes_per_agent_env_step"] == 44 + 251 + 5 * 16
     assert abs(r["achieved"] - 375 * d["value"] / 1e9) <= 1e-6 * r["achieved"]
     assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-12
-    assert r["kernel"] == "sigmaenv_step_wave_kernel" and r["kernel_launches"] >= 8 and 0.0 < r["kernel_avg_ms"] < 1.0
+    # 24 timed steps = ONE launch of the in-kernel step loop (sigmaenv_step_autoreset_n)
+    assert c["steps_per_launch"] == 24 and r["steps_per_launch"] == 24.0
+    assert r["kernel"] == "sigmaenv_step_wave_kernel" and r["kernel_launches"] >= 1 and 0.0 < r["kernel_ms_per_step"] < 1.0
+    assert abs(r["kernel_ms_per_step"] * 24 - r["kernel_avg_ms"]) <= 1e-9 and r["algorithmic_bytes_per_launch"] == 375 * 16 * 4096 * 24
     assert r["achieved_incl_record"] > r["achieved"] and 0.0 < r["frac"] < 1.0
     assert r["traffic"] is None or "traffic_source" in r
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
-    assert c["one_stream"]["ms_per_step"] > 0
+    assert c["per_step_launch"]["ms_per_step"] > 0 and c["per_step_launch"]["env_shards_per_gpu"] == 2
 
 
 def test_config4_and_qp_lines_name_their_workload():
-    d = _run("--cpu-seconds", "0", "--no-one-stream", "--scenario", "on_ramp_1", "--agents", "32", "--envs-per-gpu", "1024")
+    d = _run("--cpu-seconds", "0", "--no-compare", "--scenario", "on_ramp_1", "--agents", "32", "--envs-per-gpu", "1024")
     assert "on_ramp_1" in d["config"]["workload"] and d["config"]["n_agents"] == 32 and "cpu_baseline" not in d
     assert d["roofline"]["algorithmic_bytes_per_agent_env_step"] == 44 + 251 + 5 * 32
-    d = _run("--cpu-seconds", "0", "--no-one-stream", "--cbf-qp", "--envs-per-gpu", "512")
+    d = _run("--cpu-seconds", "0", "--no-compare", "--cbf-qp", "--envs-per-gpu", "512")
     assert "cbf" in d["config"] and d["value"] > 0

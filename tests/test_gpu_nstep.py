@@ -1,0 +1,160 @@
+"""``sigmaenv_step_autoreset_n`` (the reference's rollout loop over a chunk of steps, helper_training.py:687-788, as ONE launch in which every
+wavefront walks its env tile through the steps): bit-identical to n calls of ``sigmaenv_step_autoreset`` -- every buffer, every record row,
+every reset draw -- and, through the oracle, to the reference path.  Also the scan's work-list bound for tiles of one and two agent slots."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from sigmarl_amd import capi
+from sigmarl_amd.maps import load_map
+from sigmarl_amd.params import Parameters, make_config
+from test_gpu_parity import FLT_BUFS, INT_BUFS, _compare_all, _hip_env
+
+pytestmark = pytest.mark.gpu
+
+
+def _actions(rng, T, B, N, wild):
+    if wild:
+        a = np.stack([rng.uniform(-0.2, 1.3, (T, B, N)), rng.uniform(-0.7, 0.7, (T, B, N))], axis=-1)
+        a[2::3] = np.stack([rng.uniform(0.0, 0.3, (T, B, N)), rng.uniform(-0.05, 0.05, (T, B, N))], axis=-1)[2::3]
+    else:
+        a = np.stack([rng.uniform(0, 1, (T, B, N)), rng.uniform(-0.25, 0.25, (T, B, N))], axis=-1)
+    return a.astype(np.float32)
+
+
+NSTEP_CASES = [
+    # scenario, N, B, mtv, rew_method, dt, testing, T, wild actions
+    ("cpm_entire", 16, 4096, False, "distance", 0.05, False, 6, False),      # BASELINE config 2
+    ("cpm_entire", 32, 8192, False, "distance", 0.05, False, 3, False),      # config 4's shape
+    ("cpm_entire", 16, 200, True, "ttc_sparse", 0.1, False, 12, True),
+    ("cpm_entire", 5, 33, False, "sparse", 0.05, False, 9, True),            # ragged tile (generic instantiation)
+    ("cpm_entire", 8, 24, True, "sparse", 0.1, True, 12, True),              # testing mode: per-agent re-placement inside the loop
+    ("cpm_entire", 4, 64, False, "distance", 0.05, False, 10, True),         # 4 x 4 tile
+    ("intersection_1", 4, 40, False, "distance", 0.1, False, 16, True),      # non-loop map: entry / exit requests
+    ("on_ramp_1", 6, 40, True, "ttc", 0.1, False, 16, True),
+]
+
+
+@pytest.mark.parametrize("scen,N,B,mtv,rew,dt,testing,T,wild", NSTEP_CASES)
+def test_nstep_launch_equals_n_single_launches(scen, N, B, mtv, rew, dt, testing, T, wild):
+    import torch
+    from sigmarl_amd.shard import slab_width
+
+    p = Parameters(n_agents=N, scenario_type=scen, is_use_mtv_distance=mtv, rew_method=rew, dt=dt, is_testing_mode=testing,
+                   is_apply_mask=False, is_obs_noise=False, max_steps=9)
+    mp = load_map(scen)
+    cfg = make_config(p, mp, B)
+    pf, pc = mp.list_first[0], mp.list_count[0]
+    one, many = _hip_env(cfg, mp), _hip_env(cfg, mp)
+    for d in (one, many):
+        d.env.buffer(capi.BUF_DONE).fill_(1)
+        d.auto_reset(5, 0, pf, pc)
+    W = slab_width(N, one.env.D)
+    acts = torch.as_tensor(_actions(np.random.default_rng(11), T, B, N, wild)).cuda()
+    rec_one = torch.full((T, B, W), float("nan"), device="cuda")
+    rec_many = torch.full((T, B, W), float("nan"), device="cuda")
+    done_total = 0
+    for t in range(T):
+        one.env.set_slab(rec_one[t])
+        one.env.step_autoreset(acts[t], 5, 100 + t, pf, pc)
+        done_total += int(one.env.buffer(capi.BUF_TIMER)[:, 3].sum().item())
+    one.env.set_slab(None)
+    many.env.step_autoreset_n(acts, rec_many, 5, 100, pf, pc)
+    many.env.sync()
+    assert torch.equal(rec_one.view(torch.int32), rec_many.view(torch.int32)), "record rows differ"
+    for w in INT_BUFS + FLT_BUFS:
+        a, b = one.get(w), many.get(w)
+        assert a.tobytes() == b.tobytes(), f"buffer {w} differs between {T} launches and the one {T}-step launch"
+    assert done_total > 0  # envs finished and were re-placed inside the loop
+    # a second chunk continues exactly where the first one stopped (stride 0: the same action block every step; no record)
+    for t in range(3):
+        one.env.step_autoreset(acts[0], 5, 200 + t, pf, pc)
+    many.env.step_autoreset_n_ptr(acts.data_ptr(), 3, 0, 0, 0, 5, 200, pf, pc)
+    for w in INT_BUFS + FLT_BUFS:
+        assert one.get(w).tobytes() == many.get(w).tobytes(), f"buffer {w} differs after the second chunk"
+    one.close()
+    many.close()
+
+
+@pytest.mark.parametrize("scen,N,B,mtv,rew,T", [("cpm_entire", 16, 256, False, "distance", 10), ("intersection_1", 4, 64, True, "ttc", 12)])
+def test_nstep_launch_against_the_oracle(scen, N, B, mtv, rew, T):
+    """The n-step launch against the CPU oracle stepping and resetting one call at a time: masks / indices bit-exact, fp32 within 1e-5, and
+    every record row == the oracle's terminal observation / reward / done of that step."""
+    import torch
+    from sigmarl_amd.shard import slab_width, unpack_slab
+
+    p = Parameters(n_agents=N, scenario_type=scen, is_use_mtv_distance=mtv, rew_method=rew, dt=0.1, is_apply_mask=False, is_obs_noise=False, max_steps=9)
+    mp = load_map(scen)
+    cfg = make_config(p, mp, B)
+    pf, pc = mp.list_first[0], mp.list_count[0]
+    dev, ora = _hip_env(cfg, mp), ob.OracleEnv(cfg, mp)
+    dev.env.buffer(capi.BUF_DONE).fill_(1)
+    ora.get(capi.BUF_DONE, copy=False)[:] = 1
+    dev.auto_reset(3, 0, pf, pc)
+    ora.auto_reset(3, 0, pf, pc)
+    acts = _actions(np.random.default_rng(2), T, B, N, True)
+    rec = torch.full((T, B, slab_width(N, dev.env.D)), float("nan"), device="cuda")
+    dev.env.step_autoreset_n(torch.as_tensor(acts).cuda(), rec, 3, 50, pf, pc)
+    obs, rew_, dn = unpack_slab(rec, N, dev.env.D)
+    n_done = 0
+    for t in range(T):
+        ora.step(acts[t])
+        assert np.abs(obs[t].cpu().numpy() - ora.get(capi.BUF_OBS)).max() <= 1e-5
+        assert np.abs(rew_[t].cpu().numpy() - ora.get(capi.BUF_REWARD)).max() <= 1e-5
+        assert np.array_equal(dn[t].cpu().numpy(), ora.get(capi.BUF_DONE).astype(bool))
+        n_done += int(ora.get(capi.BUF_DONE).sum())
+        ora.auto_reset(3, 50 + t, pf, pc)
+    _compare_all(dev, ora, f"after the {T}-step launch")
+    assert n_done > 0
+    dev.close()
+    ora.close()
+
+
+def test_nstep_rejects_what_it_cannot_do():
+    import torch
+
+    mp = load_map("cpm_entire")
+    p = Parameters(n_agents=4, scenario_type="cpm_entire", rew_method="cbf", is_solve_qp=False, is_using_cbf_training=True, is_apply_mask=False, is_obs_noise=False)
+    dev = _hip_env(make_config(p, mp, 8), mp)
+    acts = torch.zeros((2, 8, 4, 2), device="cuda")
+    with pytest.raises(RuntimeError, match="cbf"):
+        dev.env.step_autoreset_n(acts)
+    dev.env.step_autoreset_n(acts[:1])  # one step is the plain fused launch
+    with pytest.raises(ValueError):
+        dev.env.step_autoreset_n(acts[0])
+    dev.close()
+
+
+@pytest.mark.parametrize("N", [1, 2])
+def test_one_and_two_agent_tiles_far_from_their_path(N):
+    """Tiles of one or two agent slots (the balanced scan's work list is at its minimum size there) with agents far from their own path: every
+    candidate chunk of a polyline then passes the box test, up to 64 per task.  The list holds at least one whole task, so the scan ends -- and
+    gives the oracle's (full-scan) result."""
+    B = 12
+    mp = load_map("cpm_entire")
+    p = Parameters(n_agents=N, scenario_type="cpm_entire", is_use_mtv_distance=False, rew_method="distance", is_apply_mask=False, is_obs_noise=False,
+                   n_nearing_agents_observed=N - 1)
+    cfg = make_config(p, mp, B)
+    dev, ora = _hip_env(cfg, mp), ob.OracleEnv(cfg, mp)
+    rng = np.random.default_rng(N)
+    st = np.zeros((B, N, 8), np.float32)
+    ids = np.zeros((B, N, 4), np.int32)
+    for b in range(B):
+        for i in range(N):
+            gp = mp.list_first[0] + int(rng.integers(mp.list_count[0]))
+            ids[b, i] = (gp, 0, gp - mp.list_first[0], 5)
+            # anywhere in (and beyond) the world, unrelated to the path: the closest-segment hint (point 5) is stale by metres
+            st[b, i, 0:2] = rng.uniform(-1.0, 5.5, 2)
+            st[b, i, 2] = rng.uniform(-3, 3)
+    ei, ai = np.repeat(np.arange(B, dtype=np.int32), N), np.tile(np.arange(N, dtype=np.int32), B)
+    for e in (dev, ora):
+        e.reset(ei, ai, ids.reshape(-1, 4), st.reshape(-1, 8), 1)
+        e.observe()
+    _compare_all(dev, ora, "far-from-path start")
+    for t in range(3):
+        act = np.stack([rng.uniform(0, 1, (B, N)), rng.uniform(-0.3, 0.3, (B, N))], axis=-1).astype(np.float32)
+        dev.step(act)
+        ora.step(act)
+        _compare_all(dev, ora, f"far-from-path step {t}")
+    dev.close()
+    ora.close()
