@@ -599,7 +599,7 @@ __device__ inline void topk_nearest(const float* Drow, int N, int K, int* out) {
 // over "virtual" slots v = (position in env_sel) * N + agent, so that the lanes stay densely used.
 template <bool WAVE = false>
 __device__ inline void observe_tile(const sigmaenv_config_t& c, const Smem& s, const DevBufs& g, const Tile& t, int ts_base = -1,
-                                    const int* env_sel = nullptr, int n_sel = 0) {
+                                    const int* env_sel = nullptr, int n_sel = 0, bool write_global = true) {
   const int N = t.N, K = t.K, D = t.D;
   const int TID = Grp<WAVE>::tid(), NTHR = Grp<WAVE>::size();
   const int n_slots = env_sel ? n_sel * N : t.slots;
@@ -735,7 +735,7 @@ __device__ inline void observe_tile(const sigmaenv_config_t& c, const Smem& s, c
       for (int k = TID; k < ND; k += NTHR) g.obs[(t.a0 + e * N) * D + k] = s.obs[e * ND + k];
       for (int k = TID; k < NK; k += NTHR) g.nearing[(t.a0 + e * N) * K + k] = s.near[e * NK + k];
     }
-  } else {
+  } else if (write_global) {  // (false: an intermediate step of the in-kernel step loop -- the rows stay in LDS for the record, HBM gets the last step's)
     if ((D & 3) == 0) {  // rows are whole float4s: both the LDS staging area and the tile's slice of g.obs are 16-byte aligned
       const float4* so4 = reinterpret_cast<const float4*>(s.obs);
       float4* go4 = reinterpret_cast<float4*>(g.obs + t.a0 * D);
@@ -1651,7 +1651,7 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
     if (const char* e = getenv("SIGMAENV_WAVE_SPEC")) { if (atoi(e) == 0) h->wave_spec = 0; }  // A/B: the generic instantiation
     h->wave_wpb = 1;
     if (const char* e = getenv("SIGMAENV_WPB")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) h->wave_wpb = v; }
-    h->wave_tile_lds = (((Smem::bytes(wg * N, N, K, h->D, true) + 15) & ~(size_t)15) + 16 * (size_t)wg + 16 + 15) & ~(size_t)15;
+    h->wave_tile_lds = (((Smem::bytes(wg * N, N, K, h->D, true) + 15) & ~(size_t)15) + 16 * (size_t)wg + 16 + 16 * (size_t)wg + 15) & ~(size_t)15;  // tile | masks, flags, env list | timers
     const int tiles = (B + wg - 1) / wg;
     h->wave_grid = (tiles + h->wave_wpb - 1) / h->wave_wpb;
     if (h->wave_tile_lds * h->wave_wpb > 64 * 1024) {
