@@ -353,11 +353,14 @@ def timed(run, steps, start_t, use_dist, dist, torch, device):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run.run_steps(start_t, steps)
+    t1 = time.perf_counter()
     run.finish_chunk()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("BENCH_DEBUG_TIMING"):
+        print(f"[bench] timed region: enqueue {1e6 * (t1 - t0):.1f} us, total {1e6 * elapsed:.1f} us", file=sys.stderr)
     el = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if use_dist:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -437,14 +440,17 @@ def main():
 
     B, N = args.envs_per_gpu, args.agents
     run = GpuRun(args, device, B, world, rank, T=T)
+    # nothing but the warm-up steps runs on the GPU right before the timed region (no reduction kernel, no device-to-host copy: both would let the
+    # queue run empty and the first timed launch pay for it)
+    run.arm_timing()  # arms the HIP-event bracketing of the step launches (on the env's stream)
+    resets_before = run.episodes_reset()
     run.run_steps(0, args.warmup)
     run.finish_chunk()
     torch.cuda.synchronize()
-    run.arm_timing()  # arms the HIP-event bracketing of the step launches (on the env's stream)
-    resets_before = run.episodes_reset()
+    run.kernel_timing()  # drops the warm-up launches' brackets
     elapsed = timed(run, args.steps, args.warmup, use_dist, dist, torch, device)
     kernel_ms, n_launch = run.kernel_timing()
-    dones = run.episodes_reset() - resets_before
+    dones = (run.episodes_reset() - resets_before) * args.steps / max(1, args.steps + args.warmup)  # (finished episodes of warm-up + timed steps, pro rata)
     req_last, entry_exit_last = run.agent_requests()
     S, Bs, D = run.S, run.Bs, run.D
     total_agent_steps = N * B * world * args.steps
