@@ -367,6 +367,81 @@ def timed(run, steps, start_t, use_dist, dist, torch, device):
     return float(el.item())
 
 
+def dry_run(args):
+    """The N-rank run without its GPU work (see --dry-run): fails loudly on any inconsistency, prints the contract's JSON line from rank 0."""
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    import torch
+    import torch.distributed as dist
+    from sigmarl_amd import capi
+    from sigmarl_amd.shard import RolloutExchange, shard_range, slab_width
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("gloo")
+        assert dist.get_rank() == rank and dist.get_world_size() == world
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    B, N = args.envs_per_gpu, args.agents
+    plain = not (args.policy or args.cbf or args.cbf_qp or args.no_reset or args.separate_reset)
+    T = 1 if not plain else (args.chunk if args.chunk >= 1 else pick_chunk(args.steps))
+    b0, b1 = shard_range(B * world, rank, world)
+    assert (b0, b1) == (rank * B, (rank + 1) * B), (b0, b1)  # weak scaling: rank r owns envs [r B, (r + 1) B) -- its env_index_base
+    Bd, D = min(B, 8), capi.obs_dim(2)
+    chunk_steps = T if T > 1 else args.chunk_steps
+    ex = RolloutExchange(Bd, N, D, chunk_steps, "cpu", mode=args.exchange)
+    W = slab_width(N, D)
+    t0 = time.perf_counter()
+    n_chunks = 0
+    for c0 in range(0, args.steps, chunk_steps):
+        k = min(chunk_steps, args.steps - c0)
+        buf = ex.chunk()
+        for t in range(k):
+            buf[t].fill_(float(1000 * rank + c0 + t))  # what the step kernel would record: tagged by (rank, step)
+        ex.commit(k)
+        n_chunks += 1
+    ex.wait_all()
+    # check the last chunk's exchange
+    kbuf, valid = ex.completed[-1]
+    c0 = (n_chunks - 1) * chunk_steps
+    if ex.collective and ex.mode == "alltoall":
+        mine = ex.time_slice(kbuf)  # [my steps, world * Bd, W]
+        lo, hi = ex.slices[rank], ex.slices[rank + 1]
+        assert tuple(mine.shape) == (hi - lo, world * Bd, W), tuple(mine.shape)
+        for q in range(lo, min(hi, valid)):
+            for r in range(world):
+                got = mine[q - lo, r * Bd:(r + 1) * Bd]
+                assert bool((got == float(1000 * r + c0 + q)).all()), (rank, q, r)
+    elif ex.collective and rank == ex.dst:
+        parts = ex.gathered(kbuf)
+        for r in range(world):
+            for q in range(valid):
+                assert bool((parts[r][q] == float(1000 * r + c0 + q)).all()), (rank, q, r)
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    out = {
+        "metric": f"env-steps/sec (agents x envs x steps), {'CPM' if args.scenario.startswith('cpm') else args.scenario} scenario, {N} agents",
+        "value": 0.0, "unit": "agent-env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
+        "config": {"workload": f"DRY RUN (no GPU work): {args.scenario} map, {N} agents x {B} envs per GPU ({B * world} envs total)", "n_agents": N, "envs_per_gpu": B,
+                   "envs_total": B * world, "steps_per_launch": T, "exchange": ex.mode if ex.collective else "none", "time_slices": ex.slices,
+                   "env_index_base": b0, "local_rank": local_rank, "chunks": n_chunks},
+    }
+    if world > 1:
+        dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    if rank == 0:
+        os.write(1, (json.dumps(out) + "\n").encode())
+    os.dup2(2, 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -408,7 +483,12 @@ def main():
                          "gather: everything to rank 0 (the 7 links into one GPU bound the rate)")
     ap.add_argument("--chunk-steps", type=int, default=32, help="steps per rollout chunk exchanged (N > 1)")
     ap.add_argument("--force-dist", action="store_true", help="diagnostic: init RCCL and run the exchange even with one rank")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU work: everything AROUND the step of an N-rank run -- RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* handling, "
+                    "rendezvous, env ranges, the chunk exchange (gloo, host buffers tagged by rank and step, checked), barrier / MAX reduction, ONE JSON line from "
+                    "rank 0 (`dry_run: true`, `value: 0`) -- so that `torch.distributed.run ... bench.py --gpus 8` can be rehearsed on a box without GPUs")
     args = ap.parse_args()
+    if args.dry_run:
+        return dry_run(args)
 
     # the contract is ONE JSON line on stdout: libraries (RCCL prints a version banner) get stderr instead
     real_stdout = os.dup(1)

@@ -218,6 +218,38 @@ mine = ex2.time_slice(ex2.completed[0][0])          # [1, TOTAL, W]: step `rank`
 obs, rew, done = unpack_slab(mine, N, env2.D)
 assert tuple(obs.shape[:2]) == (1, TOTAL)
 assert np.array_equal(obs[0].numpy(), ref2[rank][0]) and np.array_equal(rew[0].numpy(), ref2[rank][1]) and np.array_equal(done[0].numpy(), ref2[rank][2])
+# a chunk of 5 steps over 2 ranks: uneven time slices (2 + 3 steps), filled as ONE n-step launch fills it (chunk / commit), and device-style
+# resets keyed on the env's index in the WHOLE batch (env_index_base): the sharded run draws what the unsharded one draws
+def make_random(lo, hi):
+    e = ob.OracleEnv(make_config(p, mp, hi - lo, env_index_base=lo), mp)
+    e.get(capi.BUF_DONE, copy=False)[:] = 1
+    e.auto_reset(9, 0, mp.list_first[0], mp.list_count[0])
+    return e
+env3, full3 = make_random(b0, b1), make_random(0, TOTAL)
+assert np.array_equal(env3.get(capi.BUF_STATE), full3.get(capi.BUF_STATE)[b0:b1]) and np.array_equal(env3.get(capi.BUF_PATH), full3.get(capi.BUF_PATH)[b0:b1])
+T5 = 5
+ex3 = RolloutExchange(b1 - b0, N, env3.D, T5, "cpu", mode="alltoall")
+assert ex3.slices == [0, 2, 5]
+rng = np.random.default_rng(1)
+buf = ex3.chunk()
+ref3 = []
+for t in range(T5):
+    act = np.stack([rng.uniform(-0.2, 1.3, (TOTAL, N)), rng.uniform(-0.7, 0.7, (TOTAL, N))], -1).astype(np.float32)
+    env3.step(act[b0:b1]); full3.step(act)
+    pack_slab(torch.from_numpy(env3.get(capi.BUF_OBS)), torch.from_numpy(env3.get(capi.BUF_REWARD)), torch.from_numpy(env3.get(capi.BUF_DONE)), out=buf[t])
+    ref3.append((full3.get(capi.BUF_OBS), full3.get(capi.BUF_REWARD), full3.get(capi.BUF_DONE).astype(bool)))
+    env3.auto_reset(9, 1 + t, mp.list_first[0], mp.list_count[0]); full3.auto_reset(9, 1 + t, mp.list_first[0], mp.list_count[0])
+    for w in (capi.BUF_STATE, capi.BUF_PATH, capi.BUF_OBS, capi.BUF_TIMER):
+        assert np.array_equal(env3.get(w), full3.get(w)[b0:b1]), ("sharded reset differs from the unsharded one", t, w)
+assert sum(int(r[2].sum()) for r in ref3) > 0
+ex3.commit()
+ex3.wait_all()
+mine = ex3.time_slice(ex3.completed[0][0])
+lo, hi = ex3.slices[rank], ex3.slices[rank + 1]
+obs, rew, done = unpack_slab(mine, N, env3.D)
+assert tuple(obs.shape[:2]) == (hi - lo, TOTAL)
+for q in range(lo, hi):
+    assert np.array_equal(obs[q - lo].numpy(), ref3[q][0]) and np.array_equal(rew[q - lo].numpy(), ref3[q][1]) and np.array_equal(done[q - lo].numpy(), ref3[q][2])
 try:  # shards of different size cannot share one exchange (ADVICE r1): loud error, no hang
     RolloutExchange(3 + rank, N, env.D, 2, "cpu", dst=0)
     raise SystemExit("unequal shards were accepted")
@@ -237,6 +269,25 @@ def test_two_rank_sharding_gloo(tmp_path):
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                           "--master-port", "29517", str(script), ROOT], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "SHARD_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_bench_dry_run_eight_ranks_gloo():
+    """`torch.distributed.run --nproc-per-node 8 bench.py --gpus 8 --steps 20 --warmup 5 --dry-run`: the driver's 8-GPU command line with everything but
+    the GPU work -- env-variable handling, rendezvous on 127.0.0.1, env ranges, the chunk exchange with uneven time slices (20 steps over 8 ranks),
+    barrier + MAX reduction, and exactly ONE JSON line on stdout (from rank 0)."""
+    import json
+
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1", "--master-port", "29523",
+                          os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5", "--dry-run"], env=env, capture_output=True, text=True,
+                         timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["n_gpus"] == 8 and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "weak"
+    c = d["config"]
+    assert c["envs_total"] == 32768 and c["steps_per_launch"] == 20 and c["exchange"] == "alltoall" and c["time_slices"] == [0, 2, 5, 7, 10, 12, 15, 17, 20]
 
 
 @pytest.mark.parametrize("tag,testing", [("train", False), ("test", True)])
