@@ -93,11 +93,22 @@ def cpu_baseline(args, n_envs, target_seconds):
         env.auto_reset(0, 0, pf, pc)
     rng = np.random.default_rng(0)
     acts = [np.stack([rng.uniform(0, 1, (n_envs, N)), rng.uniform(-0.25, 0.25, (n_envs, N))], axis=-1).astype(np.float32) for _ in range(8)]
+    pre = lambda a: None  # noqa: E731
+    what = ""
+    if args.cbf_qp or args.cbf:  # the same launch order as the GPU leg: CBF module on the action about to be applied, then the step
+        from sigmarl_amd import cbf as cbfmod
+
+        seg_l, seg_r = cbfmod.load_segment_tables(mp)
+        env.cbf_attach(cbfmod.make_cbf_config(p), seg_l, seg_r)
+        pre = (lambda a: env.cbf_qp(a)) if args.cbf_qp else (lambda a: env.cbf_rewards(a, want_margins=False))
+        what = " + centralized CBF-QP before every step" if args.cbf_qp else " + CBF margin rewards before every step"
+    pre(acts[0])
     env.step(acts[0])  # warm-up (also spins the OpenMP team up)
     env.auto_reset(0, 1, pf, pc)
     t0 = time.perf_counter()
     k = 0
     while True:
+        pre(acts[k % 8])
         env.step(acts[k % 8])
         env.auto_reset(0, k + 2, pf, pc)
         k += 1
@@ -113,7 +124,7 @@ def cpu_baseline(args, n_envs, target_seconds):
     threads = int(os.environ.get("OMP_NUM_THREADS", cores))
     return {
         "value": N * n_envs * k / el, "unit": "agent-env-steps/s", "cores": threads, "kind": "port",
-        "sample": f"C oracle (oracle/sigmaenv_oracle.c, OpenMP over envs), {p.scenario_type}, {N} agents x {n_envs} envs x {k} steps incl. resets, {el:.1f} s",
+        "sample": f"C oracle (oracle/sigmaenv_oracle.c, OpenMP over envs), {p.scenario_type}, {N} agents x {n_envs} envs x {k} steps incl. resets{what}, {el:.1f} s",
     }
 
 
@@ -193,13 +204,21 @@ class GpuRun:
             try:  # the rollout exchange must never take the benchmark down: fall back to "no gather" and say so in the JSON line
                 self.chunk_steps = T if T > 1 else args.chunk_steps
                 self.gather = RolloutExchange(B, N, self.D, self.chunk_steps, device, force_collective=args.force_dist, mode=args.exchange)
-                slot0 = self.gather.slot()
-                for k, e in enumerate(self.envs):
-                    e.set_slab(slot0[k * Bs:(k + 1) * Bs])
-                    e.step(self.acts[0][k * Bs:(k + 1) * Bs])
-                torch.cuda.synchronize()
-                self.gather.advance()
-                self.gather.flush(self.streams if S > 1 else None)
+                # one exchange before anything is timed (a failure here disables the exchange instead of the benchmark); with T > 1 it is a launch
+                # like all the others (T steps), so that per-launch profiles average over equal launches
+                if T > 1:
+                    self.envs[0].step_autoreset_n_ptr(self.acts.data_ptr(), T, B * N * 2, self.gather.chunk().data_ptr(), B * (N * (self.D + 1) + 1), self.seed, 1 << 20,
+                                                      self.pf, self.pc)
+                    torch.cuda.synchronize()
+                    self.gather.commit()
+                else:
+                    slot0 = self.gather.slot()
+                    for k, e in enumerate(self.envs):
+                        e.set_slab(slot0[k * Bs:(k + 1) * Bs])
+                        e.step(self.acts[0][k * Bs:(k + 1) * Bs])
+                    torch.cuda.synchronize()
+                    self.gather.advance()
+                    self.gather.flush(self.streams if S > 1 else None)
                 self.gather.wait_all()
                 torch.cuda.synchronize()
                 for k, e in enumerate(self.envs):
@@ -328,9 +347,15 @@ class GpuRun:
             e.step_time_ms()
 
     def kernel_timing(self):
-        timings = [e.step_time_ms() for e in self.envs]
-        n_launch = sum(n for _, n in timings)
-        return sum(ms * n for ms, n in timings) / max(1, n_launch), n_launch
+        """{kernel id: (average launch duration in ms by HIP events, bracketed launches)} over the env shards, for every timed kernel that ran"""
+        from sigmarl_amd import capi
+        out = {}
+        for kid in range(len(capi.KERNEL_NAMES)):
+            timings = [e.kernel_time_ms(kid) for e in self.envs]
+            n_launch = sum(n for _, n in timings)
+            if n_launch:
+                out[kid] = (sum(ms * n for ms, n in timings) / n_launch, n_launch)
+        return out
 
     def episodes_reset(self):
         from sigmarl_amd import capi
@@ -529,7 +554,11 @@ def main():
     torch.cuda.synchronize()
     run.kernel_timing()  # drops the warm-up launches' brackets
     elapsed = timed(run, args.steps, args.warmup, use_dist, dist, torch, device)
-    kernel_ms, n_launch = run.kernel_timing()
+    ktimes = run.kernel_timing()
+    from sigmarl_amd import capi as _capi
+    # the kernel with the largest share of GPU time in the timed region names the roofline (every timed kernel is bracketed with the same stride)
+    dom = max(ktimes, key=lambda k: ktimes[k][0] * ktimes[k][1]) if ktimes else _capi.KERNEL_STEP
+    kernel_ms, n_launch = ktimes.get(_capi.KERNEL_STEP, (0.0, 0))
     dones = (run.episodes_reset() - resets_before) * args.steps / max(1, args.steps + args.warmup)  # (finished episodes of warm-up + timed steps, pro rata)
     req_last, entry_exit_last = run.agent_requests()
     S, Bs, D = run.S, run.Bs, run.D
@@ -607,6 +636,31 @@ def main():
             **valu,
         },
     }
+    out["roofline"]["kernel_time_share"] = {_capi.KERNEL_NAMES[k]: {"avg_ms": v[0], "launches_bracketed": v[1]} for k, v in ktimes.items()}
+    if dom != _capi.KERNEL_STEP:
+        # The dominant kernel is not the step: name IT, with its own algorithmic traffic per launch (what it must read and write per vehicle) over its
+        # own average duration.  All of these are compute-bound kernels (fp64 Newton solve / fp16-fp64 margin stencils / MFMA): the HBM fraction says so.
+        dms, dn = ktimes[dom]
+        per_vehicle = {_capi.KERNEL_CBF_QP: 44 + 16, _capi.KERNEL_CBF_MARGIN: 44 + 12, _capi.KERNEL_MLP32: 4 * D + 16, _capi.KERNEL_ACTOR_BF16: 4 * D + 8}[dom]
+        dom_bytes = per_vehicle * N * Bs
+        step_r = dict(out["roofline"])
+        out["roofline"] = {
+            "bound": "hbm", "achieved": dom_bytes / (dms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": dom_bytes / (dms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "traffic": None, "kernel": _capi.KERNEL_NAMES[dom], "kernel_avg_ms": dms, "kernel_launches": dn, "launches_per_step": S,
+            "algorithmic_bytes_per_agent_env_step": per_vehicle, "algorithmic_bytes_per_launch": dom_bytes,
+            "achieved_basis": "the DOMINANT kernel of this workload (largest share of GPU time by HIP events): bytes it must move per vehicle (state 32 + action 8 + path id 4 "
+                              "in; safe + nominal action / reward channels / action out) x vehicles per launch / its average launch duration.  It is compute-bound "
+                              "(float64 projected-Newton solve, fp16 / float64 margin stencils, or MFMA), which is what the small HBM fraction states",
+            "kernel_time_share": step_r["kernel_time_share"], "step_kernel": {k: step_r[k] for k in ("achieved", "frac", "kernel_avg_ms", "kernel_launches", "algorithmic_bytes_per_launch")},
+        }
+        try:  # fp64 / MFMA issue figures of that kernel from its committed PMC pass (tools/make_valu_json.py --kernel)
+            with open(os.path.join(ROOT, "profiles", "valu_dominant_latest.json")) as f:
+                vj = json.load(f)
+            if vj.get("kernel") in _capi.KERNEL_NAMES[dom] and vj.get("n_agents") == N and vj.get("envs_per_launch") == Bs:
+                out["roofline"].update({"f64_flops_per_launch": vj.get("f64_flops_per_launch"), "f64_flop_frac": vj.get("f64_flops_per_launch", 0) / (dms * 1e-3) / 78.6e12,
+                                        "valu_insts_per_launch": vj.get("valu_insts_per_launch"), "valu_source": vj.get("source")})
+        except Exception:  # noqa: BLE001
+            pass
     run.close()
     if T > 1 and not args.no_compare and world == 1 and not use_dist:
         # the same workload with ONE launch per step (two env shards on two streams, the round-2 form): what the step loop inside the kernel buys

@@ -247,6 +247,15 @@ int sigmaenv_sync(sigmaenv_t* h);
 /* Average device time (ms) of the last `sigmaenv_step` launches measured with HIP events on the handle's stream
  * since the previous call; n_launches receives the count.  Profiling aid for bench.py. */
 int sigmaenv_step_time_ms(sigmaenv_t* h, double* avg_ms, int32_t* n_launches);
+/* The same for the other kernels a rollout step can be made of (bench.py names the one with the largest share of GPU time in its roofline):
+ * the first call of either function arms the bracketing for all of them. */
+#define SIGMAENV_KERNEL_STEP 0        /* sigmaenv_step_wave_kernel (sigmaenv_step / _autoreset / _autoreset_n) */
+#define SIGMAENV_KERNEL_CBF_QP 1      /* cbf::sigmaenv_cbf_qp_kernel (sigmaenv_cbf_qp) */
+#define SIGMAENV_KERNEL_CBF_MARGIN 2  /* cbf::sigmaenv_cbf_kernel (sigmaenv_cbf_rewards) */
+#define SIGMAENV_KERNEL_MLP32 3       /* sigmaenv_mlp32_kernel (sigmaenv_mlp32_forward / sigmaenv_actor_forward_f32) */
+#define SIGMAENV_KERNEL_ACTOR_BF16 4  /* sigmaenv_actor_kernel (sigmaenv_actor_forward) */
+#define SIGMAENV_KERNEL_COUNT 5
+int sigmaenv_kernel_time_ms(sigmaenv_t* h, int32_t kernel_id, double* avg_ms, int32_t* n_launches);
 
 /* The device side of the arithmetic contract's trigonometry (include/sigma_trig_f32.h; torch.sin / cos / tan / atan as called by
  * sigmarl/dynamics.py:103-111,161-168 and helper_scenario.py:795-810), evaluated on arrays: kind 0 sin, 1 cos, 2 tan, 3 atan of

@@ -1304,12 +1304,15 @@ struct sigmaenv {
   int32_t *d_env_idx = nullptr, *d_agent_idx = nullptr, *d_path_ids = nullptr;
   float* d_state8 = nullptr;
   size_t staging_cap = 0;
-  // step timing
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
-  std::vector<int> ev_used;
+  // kernel timing (HIP events on the handle's stream around a sample of the launches), one pool per timed kernel (SIGMAENV_KERNEL_*)
+  struct KernelTimer {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    std::vector<int> used;
+    unsigned long long launch_count = 0;
+  };
+  KernelTimer timers[SIGMAENV_KERNEL_COUNT];
   bool timing = false;
   int timing_stride = 8;
-  unsigned long long launch_count = 0;
   // QP-free CBF margin reward (sigmaenv_cbf.inc)
   sigmaenv_cbf_config_t cbf_cfg{};
   void *cbf_seg4 = nullptr, *cbf_segl = nullptr, *cbf_cxy = nullptr, *cbf_u = nullptr, *cbf_kin = nullptr, *cbf_clf = nullptr, *cbf_safe = nullptr;
@@ -1362,7 +1365,8 @@ extern "C" void sigmaenv_destroy(sigmaenv_t* h) {
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   for (void* p : h->allocs) (void)hipFree(p);
-  for (auto& ev : h->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  for (auto& tm : h->timers)
+    for (auto& ev : tm.pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   delete h;
 }
 
@@ -1729,6 +1733,26 @@ extern "C" int sigmaenv_reset(sigmaenv_t* h, int32_t n, const int32_t* env_idx, 
   return SIGMAENV_OK;
 }
 
+// HIP-event bracketing of a SAMPLE of the launches of kernel `id` (every timing_stride-th): every event pair costs a few microseconds of queue
+// time, bracketing all launches would slow down the very region it measures.  timer_begin returns the slot to close with timer_end, or -1.
+static int timer_begin(sigmaenv* h, int id) {
+  if (!h->timing) return -1;
+  sigmaenv::KernelTimer& tm = h->timers[id];
+  if ((tm.launch_count++ % (unsigned long long)h->timing_stride) != 0) return -1;
+  const int slot = (int)tm.used.size();
+  if (slot >= (int)tm.pool.size()) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1;
+    tm.pool.emplace_back(a, b);
+  }
+  if (hipEventRecord(tm.pool[slot].first, h->stream) != hipSuccess) return -1;
+  tm.used.push_back(slot);
+  return slot;
+}
+static void timer_end(sigmaenv* h, int id, int slot) {
+  if (slot >= 0) (void)hipEventRecord(h->timers[id].pool[slot].second, h->stream);
+}
+
 // n_steps launches' worth of fused steps in ONE launch when n_steps > 1 (sigmaenv_step_autoreset_n): step t reads actions + t * act_stride, draws its
 // resets from counter + t and records into slab + t * slab_stride (floats)
 static int launch_step(sigmaenv* h, const float* actions, uint64_t seed, uint64_t counter, int path_first, int path_count, int n_steps = 1, size_t act_stride = 0,
@@ -1736,20 +1760,7 @@ static int launch_step(sigmaenv* h, const float* actions, uint64_t seed, uint64_
   if (!h || !actions) return SIGMAENV_EINVAL;
   if (slab_from_handle) slab = h->buf.slab;
   HIPCHK(h, hipSetDevice(h->device));  // handles on several GPUs may live in one process: every entry point that enqueues work selects its device
-  int slot = -1;
-  // HIP-event bracketing of a SAMPLE of the launches (every timing_stride-th): every event pair costs a few microseconds of
-  // queue time, bracketing all launches would slow down the very region it measures
-  if (h->timing && (h->launch_count++ % h->timing_stride) == 0) {
-    slot = (int)h->ev_used.size();
-    if (slot >= (int)h->ev_pool.size()) {
-      hipEvent_t a, b;
-      HIPCHK(h, hipEventCreate(&a));
-      HIPCHK(h, hipEventCreate(&b));
-      h->ev_pool.emplace_back(a, b);
-    }
-    h->ev_used.push_back(slot);
-    HIPCHK(h, hipEventRecord(h->ev_pool[slot].first, h->stream));
-  }
+  const int slot = timer_begin(h, SIGMAENV_KERNEL_STEP);
   {
     // instantiations: exact shared-reciprocal division or plain `/` in the scan (DevMap::fast_div), lane pair per agent in the dynamics or not
     const bool par = 2 * h->wave_G * h->N <= 64;
@@ -1768,7 +1779,7 @@ static int launch_step(sigmaenv* h, const float* actions, uint64_t seed, uint64_
     hipLaunchKernelGGL(kern, dim3(h->wave_grid), dim3(64 * h->wave_wpb), h->wave_tile_lds * h->wave_wpb, h->stream, (const sigmaenv_config_t*)h->d_cfg, ka);
   }
   HIPCHK(h, hipGetLastError());
-  if (slot >= 0) HIPCHK(h, hipEventRecord(h->ev_pool[slot].second, h->stream));
+  timer_end(h, SIGMAENV_KERNEL_STEP, slot);
   return launch_obs_variant(h);
 }
 
@@ -1873,24 +1884,28 @@ extern "C" int sigmaenv_debug_timestamps(sigmaenv_t* h, unsigned long long* out,
   return n;
 }
 
-// Enables HIP-event bracketing of every subsequent step launch (first call) and reports/clears the collected launches.
-extern "C" int sigmaenv_step_time_ms(sigmaenv_t* h, double* avg_ms, int32_t* n_launches) {
-  if (!h || !avg_ms || !n_launches) return SIGMAENV_EINVAL;
+// Enables HIP-event bracketing of the subsequent launches of the timed kernels (first call) and reports / clears the collected launches of kernel
+// `kernel_id` (SIGMAENV_KERNEL_*).
+extern "C" int sigmaenv_kernel_time_ms(sigmaenv_t* h, int32_t kernel_id, double* avg_ms, int32_t* n_launches) {
+  if (!h || !avg_ms || !n_launches || kernel_id < 0 || kernel_id >= SIGMAENV_KERNEL_COUNT) return SIGMAENV_EINVAL;
   *avg_ms = 0.0;
   *n_launches = 0;
   if (!h->timing) { h->timing = true; return SIGMAENV_OK; }
+  HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  sigmaenv::KernelTimer& tm = h->timers[kernel_id];
   double total = 0.0;
-  for (int slot : h->ev_used) {
+  for (int slot : tm.used) {
     float ms = 0.f;
-    HIPCHK(h, hipEventElapsedTime(&ms, h->ev_pool[slot].first, h->ev_pool[slot].second));
+    HIPCHK(h, hipEventElapsedTime(&ms, tm.pool[slot].first, tm.pool[slot].second));
     total += ms;
   }
-  *n_launches = (int32_t)h->ev_used.size();
+  *n_launches = (int32_t)tm.used.size();
   if (*n_launches) *avg_ms = total / *n_launches;
-  h->ev_used.clear();
+  tm.used.clear();
   return SIGMAENV_OK;
 }
+extern "C" int sigmaenv_step_time_ms(sigmaenv_t* h, double* avg_ms, int32_t* n_launches) { return sigmaenv_kernel_time_ms(h, SIGMAENV_KERNEL_STEP, avg_ms, n_launches); }
 
 __global__ void sigmaenv_trig_selftest_kernel(int kind, int n, const float* __restrict__ in, float* __restrict__ out) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;

@@ -347,6 +347,13 @@ class SigmaEnv:
     def sync(self):
         self._chk(self.lib.sync(self.h), "sync")
 
+    def kernel_time_ms(self, kernel_id: int):
+        """(average ms, launches) of the HIP-event brackets of kernel ``capi.KERNEL_*`` since the last call; the first call arms the bracketing."""
+        avg = C.c_double()
+        n = C.c_int32()
+        self._chk(self.lib.kernel_time_ms(self.h, int(kernel_id), C.byref(avg), C.byref(n)), "kernel_time_ms")
+        return avg.value, n.value
+
     def step_time_ms(self):
         avg = C.c_double()
         n = C.c_int32()

@@ -52,3 +52,39 @@ def test_config4_and_qp_lines_name_their_workload():
     assert d["roofline"]["algorithmic_bytes_per_agent_env_step"] == 44 + 251 + 5 * 32
     d = _run("--cpu-seconds", "0", "--no-compare", "--cbf-qp", "--envs-per-gpu", "512")
     assert "cbf" in d["config"] and d["value"] > 0
+
+
+def _trace_top_kernel(tmp_path, *bench_args):
+    """bench.py under `rocprofv3 --kernel-trace --stats`: (the JSON line, {kernel name: total ns} from the trace's kernel stats)."""
+    import csv
+    import glob
+
+    out_dir = str(tmp_path / "trace")
+    env = dict(os.environ, TMPDIR="/tmp")
+    cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", out_dir, "-o", "t", "--", sys.executable, os.path.join(ROOT, "bench.py"),
+           "--cpu-seconds", "0", "--no-compare", *bench_args]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd="/tmp", env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.strip().startswith("{")][-1])
+    totals = {}
+    for f in glob.glob(os.path.join(out_dir, "**", "*kernel_stats.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            totals[row["Name"]] = totals.get(row["Name"], 0.0) + float(row["TotalDurationNs"])
+    assert totals, "no kernel stats produced"
+    return d, totals
+
+
+@pytest.mark.parametrize("args,expect", [
+    (["--steps", "32", "--warmup", "32"], "sigmaenv_step_wave_kernel"),                                   # the headline: the step kernel
+    (["--steps", "16", "--warmup", "4", "--cbf-qp", "--envs-per-gpu", "1024"], "sigmaenv_cbf_qp_kernel"),  # config 5: the QP kernel dominates
+])
+def test_roofline_names_the_kernel_the_trace_ranks_first(tmp_path, args, expect):
+    """`roofline.kernel` is the kernel with the largest share of GPU time -- checked against rocprofv3's own kernel statistics of the same command --
+    and its HIP-event average agrees with the trace's average."""
+    d, totals = _trace_top_kernel(tmp_path, *args)
+    ours = {k: v for k, v in totals.items() if "sigmaenv" in k}
+    top = max(ours, key=ours.get)
+    r = d["roofline"]
+    assert expect in r["kernel"] and expect in top, (r["kernel"], top)
+    assert r["kernel"].split("::")[-1] in top
+    assert 0.0 < r["frac"] < 1.0 and r["kernel_avg_ms"] > 0

@@ -285,7 +285,7 @@ def test_config4_onramp_32_agents_8192_envs():
     _compare_all(dev, ora, "injected start")
     rng = np.random.default_rng(3)
     n_exit = n_req = n_done = 0
-    for t in range(4):
+    for t in range(12):
         act = np.stack([rng.uniform(0, 1, (B, N)), rng.uniform(-0.25, 0.25, (B, N))], axis=-1).astype(np.float32)
         dev.step_autoreset(act, 5, t, pf, pc)
         ora.step(act)

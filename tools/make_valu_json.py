@@ -6,16 +6,20 @@
   fp32_flops_per_launch        (ADD_F32 + MUL_F32 + TRANS_F32 + 2 FMA_F32) x mean active lanes per VALU instruction
                                (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU / 4 ... approximated by thread-cycles per instruction, <= 64)
 bench.py scales them by its own launch rate: valu_issue_frac = busy cycles per second / (1024 SIMDs x clock), fp32_flop_frac = flops per
-second / 157.3e12.  Usage: tools/make_valu_json.py <pmc_outdir> <n_agents> <envs_per_launch> <out.json> [scenario] [source-note]"""
+second / 157.3e12.  Usage: tools/make_valu_json.py <pmc_outdir> <n_agents> <envs_per_launch> <out.json> [scenario] [source-note]
+Environment: KERNEL_SUBSTR (default sigmaenv_step_wave_kernel) selects the kernel, STEPS_PER_LAUNCH (default 1) records how many env steps ONE
+launch of the profiled run held (the in-kernel step loop, sigmaenv_step_autoreset_n): bench.py divides the per-launch counts by it."""
 import csv, glob, json, os, sys, collections
 
 out_dir, n_agents, envs, dst = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
 scenario = sys.argv[5] if len(sys.argv) > 5 else "cpm_entire"
 note = sys.argv[6] if len(sys.argv) > 6 else "profiles/valu_latest.json (rocprofv3 --pmc SQ passes, tools/pmc_passes.sh)"
+KSUB = os.environ.get("KERNEL_SUBSTR", "sigmaenv_step_wave_kernel")
+STEPS = float(os.environ.get("STEPS_PER_LAUNCH", "1"))
 acc = collections.defaultdict(list)
 for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
-        if "sigmaenv_step_wave_kernel" in row.get("Kernel_Name", ""):
+        if KSUB in row.get("Kernel_Name", ""):
             acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
 avg = {k: sum(v) / len(v) for k, v in acc.items()}
 valu = avg["SQ_INSTS_VALU"]
@@ -23,7 +27,7 @@ lanes = min(64.0, avg["SQ_THREAD_CYCLES_VALU"] / max(1.0, avg["SQ_ACTIVE_INST_VA
 lanes = min(64.0, avg.get("SQ_THREAD_CYCLES_VALU", 64.0 * valu) / valu)
 fp32 = avg.get("SQ_INSTS_VALU_ADD_F32", 0) + avg.get("SQ_INSTS_VALU_MUL_F32", 0) + avg.get("SQ_INSTS_VALU_TRANS_F32", 0) + 2 * avg.get("SQ_INSTS_VALU_FMA_F32", 0)
 rec = {
-    "kernel": "sigmaenv_step_wave_kernel", "scenario": scenario, "n_agents": n_agents, "envs_per_launch": envs, "source": note,
+    "kernel": KSUB, "steps_per_launch": STEPS, "scenario": scenario, "n_agents": n_agents, "envs_per_launch": envs, "source": note,
     "n_simd": 1024, "clock_hz": 2.4e9,
     "valu_insts_per_launch": valu, "salu_insts_per_launch": avg.get("SQ_INSTS_SALU"), "lds_insts_per_launch": avg.get("SQ_INSTS_LDS"),
     "valu_busy_cycles_per_launch": 4.0 * avg["SQ_ACTIVE_INST_VALU"],
@@ -32,6 +36,7 @@ rec = {
     "int32_insts_per_launch": avg.get("SQ_INSTS_VALU_INT32"), "int64_insts_per_launch": avg.get("SQ_INSTS_VALU_INT64"),
     "f64_insts_per_launch": avg.get("SQ_INSTS_VALU_ADD_F64", 0) + avg.get("SQ_INSTS_VALU_MUL_F64", 0) + avg.get("SQ_INSTS_VALU_FMA_F64", 0) + avg.get("SQ_INSTS_VALU_TRANS_F64", 0),
     "fp32_flops_per_launch": fp32 * lanes,
+    "f64_flops_per_launch": (avg.get("SQ_INSTS_VALU_ADD_F64", 0) + avg.get("SQ_INSTS_VALU_MUL_F64", 0) + avg.get("SQ_INSTS_VALU_TRANS_F64", 0) + 2 * avg.get("SQ_INSTS_VALU_FMA_F64", 0)) * lanes,
     "wave_cycles_per_launch": 4.0 * avg.get("SQ_WAVE_CYCLES", 0), "wait_any_frac": avg.get("SQ_WAIT_ANY", 0) / max(1.0, avg.get("SQ_WAVE_CYCLES", 1)),
     "lds_bank_conflict_frac": avg.get("SQ_LDS_BANK_CONFLICT", 0) / max(1.0, avg.get("SQ_LDS_IDX_ACTIVE", 1)),
 }
