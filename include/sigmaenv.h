@@ -109,9 +109,15 @@ typedef struct sigmaenv_config {
                                  * 0): every device-side random draw -- reset sampler, observation noise, action sampling -- is keyed on
                                  * (seed, counter, env_index_base + local env, agent, draw), so a sharded batch draws exactly what the unsharded
                                  * batch draws, whatever the number of shards */
-  float obs_noise_level;        /* Parameters.obs_noise_level when Parameters.is_obs_noise, else 0: amplitude of the uniform noise
-                                 * `obs + level * (2 U[0,1) - 1)`... see sigmaenv_set_obs_noise; 0 = no noise on the device */
-  int32_t reserved[6];          /* must be 0 */
+  float obs_noise_level;        /* Parameters.obs_noise_level when Parameters.is_obs_noise, else 0 (no noise).  observation_provider_rt.py:613-618:
+                                 * `obs + obs_noise_level * rand_like(obs)`, i.e. uniform noise in [0, level) on every element of every observation
+                                 * row, drawn at every observation() call.  Here element k of agent i of env b receives level * u with
+                                 * u = (rng(obs_noise_seed, episodes_reset(b) * 65537 + timer.step(b), env_index_base + b, i, 9000 + k) >> 8) / 2^24
+                                 * (the counter-based generator the reset sampler uses): a pure function of the env's own counters, hence the same in the
+                                 * fused / separate / n-step launches and for any sharding.  Applied on the DEVICE to SIGMAENV_BUF_OBS, to the rollout
+                                 * record and therefore to what sigmaenv_actor_* / sigmaenv_rollout read. */
+  uint32_t obs_noise_seed_lo, obs_noise_seed_hi; /* Parameters.random_seed */
+  int32_t reserved[4];          /* must be 0 */
 } sigmaenv_config_t;
 
 /* Unpadded reference-path table (output of the map parser, sigmarl/map_manager.py:13-40).  The library builds the padded
@@ -305,6 +311,13 @@ int sigmaenv_actor_forward_f32(sigmaenv_t* h, sigmaenv_mlp32_t* m, const float* 
  * env steps with the QP's safe actions. */
 int sigmaenv_rollout(sigmaenv_t* h, sigmaenv_actor_t* a, int32_t n_steps, float* actions_buf, float* slab_base, float* logp_base, float* actions_rec,
                      uint64_t seed, uint64_t counter0, int32_t path_first, int32_t path_count, int32_t deterministic);
+/* The same with the actor in the REFERENCE's precision (an fp32 torch MLP, decision_making_module.py:34-82): sigmaenv_actor_forward_f32 in front of
+ * every step instead of the bf16 kernel; `m` from sigmaenv_mlp32_create (obs_dim -> 256 -> 256 -> 256 -> 4), low / high HOST pointers (2 floats each),
+ * scratch device f32 [B * N * 4].  Step t == sigmaenv_actor_forward_f32(.., seed, counter0 + t, ..) then sigmaenv_step_autoreset(.., seed, counter0 + t, ..)
+ * bit for bit.  The policy reads SIGMAENV_BUF_OBS, i.e. the observation incl. the sensor noise when sigmaenv_config_t.obs_noise_level > 0. */
+int sigmaenv_rollout_f32(sigmaenv_t* h, sigmaenv_mlp32_t* m, const float* low, const float* high, float* scratch, int32_t n_steps, float* actions_buf,
+                         float* slab_base, float* logp_base, float* actions_rec, uint64_t seed, uint64_t counter0, int32_t path_first, int32_t path_count,
+                         int32_t deterministic);
 
 /* ---- QP-free CBF margin reward ---------------------------------------------------------------------------
  * CBFQP.update_qp with Parameters.is_solve_qp == False (sigmarl/cbf_qp.py:2534-2560): the nominal CBF constraint margins of every

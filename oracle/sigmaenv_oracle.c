@@ -66,6 +66,7 @@ static inline float cr_tan(float x) { return sigma_tanf(x); }
 static inline float cr_atan(float x) { return sigma_atanf(x); }
 static inline float cr_atan2(float y, float x) { return (float)atan2((double)y, (double)x); }
 /* torch.norm(..., dim=<len-2 dim>) on PyTorch-CPU == sqrt(fma(y,y,x*x)) */
+static inline uint32_t rng_u32(uint64_t seed, uint64_t counter, uint32_t env, uint32_t agent, uint32_t draw);  /* below (device-side resets) */
 static inline float norm2(float x, float y) { return sqrtf(fmaf(y, y, x * x)); }
 static inline float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 /* torch.remainder(a, b), b > 0 (fmod, then shift negatives): dynamics.py:158, helper_scenario.py:1286-1289 */
@@ -564,6 +565,16 @@ static void agent_observation(oracle_t* o, int b, int i) {
     }
   }
 #undef OBS_POINT
+  /* sensor noise, observation_provider_rt.py:613-618: obs + obs_noise_level * rand_like(obs), uniform in [0, level).  The draw is the shared
+   * specification of sigmaenv_config_t.obs_noise_level: the counter-based generator keyed on the env's own counters (episodes_reset, timer.step) */
+  if (c->obs_noise_level > 0.0f) {
+    const uint64_t seed = ((uint64_t)c->obs_noise_seed_hi << 32) | c->obs_noise_seed_lo;
+    const uint64_t counter = (uint64_t)(uint32_t)o->timer[b * 4 + 3] * 65537ull + (uint64_t)(uint32_t)o->timer[b * 4];
+    for (int k = 0; k < p; ++k) {
+      const float u = (float)(rng_u32(seed, counter, (uint32_t)(c->env_index_base + b), (uint32_t)i, 9000u + (uint32_t)k) >> 8) * (1.0f / 16777216.0f);
+      ob[k] = ob[k] + c->obs_noise_level * u;
+    }
+  }
 }
 
 /* done(), road_traffic.py:1368-1487 (flags only; the resets it triggers are requests to the host) */

@@ -134,8 +134,6 @@ class Actor:
                 obs: torch.Tensor | None = None, seed: int = 0, counter: int = 0, deterministic: bool = False, precision: str | None = None):
         """actions[B,N,2] := policy(env.obs or ``obs``); enqueued on the env's stream."""
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
-        if obs is None:
-            env._warn_noise_free("the on-device actor")
         if (precision or self.precision) == "fp32":
             if self._scratch4 is None or self._scratch4.shape[0] != env.B * env.N or self._scratch4.device != env.device:
                 self._scratch4 = torch.empty((env.B * env.N, 4), dtype=torch.float32, device=env.device)
@@ -152,15 +150,26 @@ class Actor:
 
     def rollout(self, env: SigmaEnv, n_steps: int, slab: torch.Tensor | None = None, log_prob: torch.Tensor | None = None,
                 actions: torch.Tensor | None = None, seed: int = 0, counter0: int = 0, path_first: int | None = None, path_count: int | None = None,
-                deterministic: bool = False):
+                deterministic: bool = False, precision: str | None = None):
         """``n_steps`` x (policy -> fused step + record + resets) enqueued back to back; optional records ``slab [T,B,W]``,
-        ``log_prob [T,B,N]``, ``actions [T,B,N,2]`` (CUDA float32, contiguous)."""
+        ``log_prob [T,B,N]``, ``actions [T,B,N,2]`` (CUDA float32, contiguous).  ``precision`` (default: the actor's): "fp32" = the reference's
+        arithmetic (``sigmaenv_rollout_f32``), "bf16" = the fast inference variant (``sigmaenv_rollout``)."""
         if path_first is None:
             path_first, path_count = env.map.list_first[0], env.map.list_count[0]
         if not hasattr(self, "_scratch") or self._scratch.shape[0] != env.B or self._scratch.device != env.device:
             self._scratch = torch.zeros((env.B, env.N, 2), dtype=torch.float32, device=env.device)
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
-        rc = self.lib.rollout(env.h, self.h, int(n_steps), p(self._scratch), p(slab), p(log_prob), p(actions), int(seed), int(counter0), int(path_first),
+        if (precision or self.precision) == "fp32":
+            if self._scratch4 is None or self._scratch4.shape[0] != env.B * env.N or self._scratch4.device != env.device:
+                self._scratch4 = torch.empty((env.B * env.N, 4), dtype=torch.float32, device=env.device)
+            lo, hi = self._keep[-2], self._keep[-1]
+            rc = self.lib.rollout_f32(env.h, self._mlp32.h, lo.ctypes.data_as(C.c_void_p), hi.ctypes.data_as(C.c_void_p), p(self._scratch4), int(n_steps),
+                                      p(self._scratch), p(slab), p(log_prob), p(actions), int(seed), int(counter0), int(path_first), int(path_count),
+                                      int(bool(deterministic)))
+            if rc != 0:
+                raise RuntimeError(f"sigmaenv_rollout_f32 failed with code {rc}: {env.lib.last_error(env.h).decode()}")
+            return
+        rc = self.lib.rollout(env.h, self._bf16_handle(), int(n_steps), p(self._scratch), p(slab), p(log_prob), p(actions), int(seed), int(counter0), int(path_first),
                               int(path_count), int(bool(deterministic)))
         if rc != 0:
             raise RuntimeError(f"sigmaenv_rollout failed with code {rc}: {env.lib.last_error(env.h).decode()}")

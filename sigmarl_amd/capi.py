@@ -50,7 +50,8 @@ class Config(C.Structure):
         ("ttc_low", C.c_float), ("ttc_high", C.c_float),
         ("penalty_deviate_from_cbf_vel", C.c_float), ("penalty_deviate_from_cbf_steer", C.c_float),
         ("is_apply_mask", C.c_int32), ("distance_mask_agents", C.c_float), ("obs_flags", C.c_int32), ("reset_agent_fixed_duration", C.c_float),
-        ("env_index_base", C.c_int32), ("obs_noise_level", C.c_float), ("reserved", C.c_int32 * 6),
+        ("env_index_base", C.c_int32), ("obs_noise_level", C.c_float), ("obs_noise_seed_lo", C.c_uint32), ("obs_noise_seed_hi", C.c_uint32),
+        ("reserved", C.c_int32 * 4),
     ]
 
 
@@ -155,6 +156,8 @@ _PRODUCT_ONLY = {
     "mlp32_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "actor_forward_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
                                     C.c_int32]),
+    "rollout_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
+                              C.c_int32, C.c_int32, C.c_int32]),
     "rollout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32,
                           C.c_int32, C.c_int32]),
 }

@@ -599,7 +599,9 @@ __device__ inline void topk_nearest(const float* Drow, int N, int K, int* out) {
 // over "virtual" slots v = (position in env_sel) * N + agent, so that the lanes stay densely used.
 template <bool WAVE = false>
 __device__ inline void observe_tile(const sigmaenv_config_t& c, const Smem& s, const DevBufs& g, const Tile& t, int ts_base = -1,
-                                    const int* env_sel = nullptr, int n_sel = 0, bool write_global = true) {
+                                    const int* env_sel = nullptr, int n_sel = 0, bool write_global = true, const int* tim = nullptr) {
+  // tim: the timer rows [nenv][4] of the tile's envs (LDS copy of the step kernel's step loop; default: SIGMAENV_BUF_TIMER) -- the observation
+  // noise is keyed on an env's (episodes_reset, timer.step)
   const int N = t.N, K = t.K, D = t.D;
   const int TID = Grp<WAVE>::tid(), NTHR = Grp<WAVE>::size();
   const int n_slots = env_sel ? n_sel * N : t.slots;
@@ -728,6 +730,16 @@ __device__ inline void observe_tile(const sigmaenv_config_t& c, const Smem& s, c
   TSO(3);
   Grp<WAVE>::sync();
   TSO(4);
+  if (c.obs_noise_level > 0.0f) {  // sensor noise on every element of the rows just assembled (observation_provider_rt.py:613-618)
+    if (!tim) tim = g.timer + (size_t)t.env0 * 4;
+    for (int w = TID; w < n_slots * D; w += NTHR) {
+      const int v = w / D, k = w - v * D;
+      const int sl = real_slot(v);
+      const int e = fdiv(sl, g.mN), i = sl - e * N;
+      s.obs[sl * D + k] = s.obs[sl * D + k] + obs_noise(c, c.env_index_base + t.env0 + e, i, k, tim[e * 4 + 3], tim[e * 4]);
+    }
+    Grp<WAVE>::sync();
+  }
   if (env_sel) {  // only the rows of the selected envs (they are contiguous per env)
     const int ND = N * D, NK = N * K;
     for (int q = 0; q < n_sel; ++q) {
@@ -790,7 +802,7 @@ struct ResetPrefetch {
 template <bool WAVE = false>
 __device__ inline void auto_reset_tile(const sigmaenv_config_t& c, const DevMap& m, const DevBufs& g, const Smem& s, const Tile& t,
                                        const unsigned long long* s_mask, const int* s_full, uint64_t seed, uint64_t counter, int path_first,
-                                       int path_count, int obs_mode, const ResetPrefetch& pre, int g_cap = 64);
+                                       int path_count, int obs_mode, const ResetPrefetch& pre, int g_cap = 64, int* lds_tim = nullptr);
 #define MAX_G 64
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -842,7 +854,7 @@ __global__ void sigmaenv_reset_scatter_kernel(DevBufs g, int N, int n, const int
 // per-env agent bit mask, full[e] the full-env flag.  All threads of the block participate.
 template <bool WAVE = false>
 __device__ inline void reset_finish_body(const sigmaenv_config_t& c, const DevBufs& g, const Smem& s, const Tile& t,
-                                         const unsigned long long* agent_mask, const int* full, int with_obs, int g_cap = 64);
+                                         const unsigned long long* agent_mask, const int* full, int with_obs, int g_cap = 64, int* lds_tim = nullptr);
 __device__ inline void reset_derive_body(const sigmaenv_config_t& c, const DevMap& m, const DevBufs& g, const Smem& s, const Tile& t,
                                          const unsigned long long* agent_mask, const int* full, int with_obs) {
   const int N = t.N;
@@ -918,7 +930,7 @@ __device__ inline void reset_derive_body(const sigmaenv_config_t& c, const DevMa
 // agents in LDS and HBM.
 template <bool WAVE>
 __device__ inline void reset_finish_body(const sigmaenv_config_t& c, const DevBufs& g, const Smem& s, const Tile& t,
-                                         const unsigned long long* agent_mask, const int* full, int with_obs, int g_cap) {
+                                         const unsigned long long* agent_mask, const int* full, int with_obs, int g_cap, int* lds_tim) {
   const int N = t.N;
   const int tid = Grp<WAVE>::tid();
 #define TS2(k) PROF_TS2(g, tid, k)
@@ -942,7 +954,10 @@ __device__ inline void reset_finish_body(const sigmaenv_config_t& c, const DevBu
     if (full[e]) reinterpret_cast<float2*>(g.action)[gi] = make_float2(0.f, 0.f);
     if (i == 0) {
       int b = t.env0 + e;
-      if (full[e]) { g.timer[b * 4] = 0; g.timer[b * 4 + 3] += 1; g.done[b] = 0; }
+      if (full[e]) {
+        g.timer[b * 4] = 0; g.timer[b * 4 + 3] += 1; g.done[b] = 0;
+        if (lds_tim) { lds_tim[e * 4] = 0; lds_tim[e * 4 + 3] += 1; }  // the step loop's LDS copy of the timer rows
+      }
       g.reset_mask[b] = 0ull;
       g.reset_full[b] = 0;
     }
@@ -960,7 +975,7 @@ __device__ inline void reset_finish_body(const sigmaenv_config_t& c, const DevBu
         env_sel[0] = cnt;
       }
       Grp<WAVE>::sync();
-      observe_tile<WAVE>(c, s, g, t, -1, env_sel + 1, env_sel[0]);
+      observe_tile<WAVE>(c, s, g, t, -1, env_sel + 1, env_sel[0], true, lds_tim);
     } else {
       load_tile_for_observation(s, g, t);
       observe_tile<WAVE>(c, s, g, t);
@@ -1141,7 +1156,7 @@ __device__ __forceinline__ void place_from_start_table(const DevMap& m, const De
 template <bool WAVE>
 __device__ inline void auto_reset_tile(const sigmaenv_config_t& c, const DevMap& m, const DevBufs& g, const Smem& s, const Tile& t,
                                        const unsigned long long* s_mask, const int* s_full, uint64_t seed, uint64_t counter, int path_first,
-                                       int path_count, int obs_mode, const ResetPrefetch& pre, int g_cap) {
+                                       int path_count, int obs_mode, const ResetPrefetch& pre, int g_cap, int* lds_tim) {
   const int N = t.N;
   const int tid = Grp<WAVE>::tid(), lane = tid & 63, wave = tid >> 6, n_waves = Grp<WAVE>::size() >> 6;
   const ResetDraw rd{seed, counter, path_first, path_count, c.is_testing_mode, c.env_index_base};
@@ -1231,7 +1246,7 @@ __device__ inline void auto_reset_tile(const sigmaenv_config_t& c, const DevMap&
   __threadfence_block();
   Grp<WAVE>::sync();
   TS2(2);
-  reset_finish_body<WAVE>(c, g, s, t, s_mask, s_full, obs_mode, g_cap);
+  reset_finish_body<WAVE>(c, g, s, t, s_mask, s_full, obs_mode, g_cap, lds_tim);
 #undef TS2
 }
 
@@ -1384,7 +1399,7 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
   if (!cfg || !map || !out) return SIGMAENV_EINVAL;
   *out = nullptr;
   if (cfg->abi_version != SIGMAENV_ABI_VERSION) return SIGMAENV_EINVAL;
-  for (int k = 0; k < 6; ++k) if (cfg->reserved[k] != 0) return SIGMAENV_EINVAL;
+  for (int k = 0; k < 4; ++k) if (cfg->reserved[k] != 0) return SIGMAENV_EINVAL;
   if (cfg->env_index_base < 0 || !(cfg->obs_noise_level >= 0.0f)) return SIGMAENV_EINVAL;
   if (cfg->n_envs < 1 || cfg->n_agents < 1 || cfg->n_agents > SIGMAENV_MAX_AGENTS) return SIGMAENV_EINVAL;
   if (cfg->n_nearing < 0 || cfg->n_nearing > SIGMAENV_MAX_NEARING || cfg->n_nearing > cfg->n_agents - 1) return SIGMAENV_EINVAL;

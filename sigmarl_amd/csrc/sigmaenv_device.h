@@ -398,4 +398,13 @@ __device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint64_t counter, uin
   return h;
 }
 
+// observation noise of element k of agent `agent` of env `env_global` at the env's counters (episodes_reset, timer.step): level * U[0, 1)
+// (observation_provider_rt.py:613-618; specification shared with the oracle, see sigmaenv_config_t.obs_noise_level)
+__device__ __forceinline__ float obs_noise(const sigmaenv_config_t& c, int env_global, int agent, int k, int episodes, int step) {
+  const uint64_t seed = ((uint64_t)c.obs_noise_seed_hi << 32) | c.obs_noise_seed_lo;
+  const uint64_t counter = (uint64_t)(uint32_t)episodes * 65537ull + (uint64_t)(uint32_t)step;
+  const float u = (float)(rng_u32(seed, counter, (uint32_t)env_global, (uint32_t)agent, 9000u + (uint32_t)k) >> 8) * (1.0f / 16777216.0f);
+  return c.obs_noise_level * u;
+}
+
 }  // namespace sigmadev

@@ -284,7 +284,6 @@ class SigmaEnv:
         if slab is not None:
             if not (slab.is_cuda and slab.dtype == torch.float32 and slab.is_contiguous() and tuple(slab.shape) == (T, self.B, W)):
                 raise ValueError(f"slab must be a contiguous float32 CUDA tensor of shape {(T, self.B, W)}")
-            self._warn_noise_free("the rollout slab")
         if counter0 is None:
             counter0 = self._reset_counter
             self._reset_counter += T
@@ -307,16 +306,6 @@ class SigmaEnv:
             path_first, path_count = self.map.list_first[0], self.map.list_count[0]
         self._chk(self.lib.auto_reset(self.h, int(seed), int(counter), int(path_first), int(path_count)), "auto_reset")
 
-    def _warn_noise_free(self, what: str):
-        """``is_obs_noise`` (Parameters' default is True) is applied by ``ScenarioRoadTraffic.observation()`` on the host side of the plugin
-        surface (observation_provider_rt.py:613-618); consumers that read ``BUF_OBS`` on the device see the noise-free observation."""
-        if getattr(self.parameters, "is_obs_noise", False) and not getattr(self, "_noise_warned", False):
-            import warnings
-
-            self._noise_warned = True
-            warnings.warn(f"sigmarl_amd: is_obs_noise=True, but {what} reads the observation buffer on the device, where no noise is added "
-                          "(the noise is applied in ScenarioRoadTraffic.observation() only); pass is_obs_noise=False to make this explicit", stacklevel=3)
-
     def _warn_cbf_noise(self):
         """With ``is_obs_noise`` the reference perturbs the policy's action before it enters the "rl" nominal controller of the CBF module
         (``rl_i + rand_like(rl_i) * obs_noise_level``, cbf_qp.py:1060-1061, :2608-2609); the device path takes the action as given."""
@@ -334,7 +323,6 @@ class SigmaEnv:
             return
         if not (slab.is_cuda and slab.dtype == torch.float32 and slab.is_contiguous() and tuple(slab.shape) == (self.B, self.N * (self.D + 1) + 1)):
             raise ValueError(f"slab must be a contiguous float32 CUDA tensor of shape {(self.B, self.N * (self.D + 1) + 1)}")
-        self._warn_noise_free("the rollout slab")
         self._chk(self.lib.set_slab(self.h, C.c_void_p(slab.data_ptr())), "set_slab")
 
     # pointer-level variants for rollout loops that precompute their device addresses (no per-call tensor checks / views)

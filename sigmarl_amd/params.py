@@ -198,6 +198,9 @@ def make_config(p: Parameters, map_table, n_envs: int, make_world_scenario_type:
     c.distance_mask_agents = A["length"] * 5  # road_traffic.py:663
     c.reset_agent_fixed_duration = float(p.reset_agent_fixed_duration or 0.0)  # road_traffic.py:1388-1397
     c.obs_flags = obs_flags(p)
+    # observation noise (observation_provider_rt.py:613-618) is added on the device, from the counter-based generator seeded by Parameters.random_seed
+    c.obs_noise_level = float(p.obs_noise_level) if p.is_obs_noise else 0.0
+    c.obs_noise_seed_lo, c.obs_noise_seed_hi = int(p.random_seed or 0) & 0xFFFFFFFF, (int(p.random_seed or 0) >> 32) & 0xFFFFFFFF
     c.penalty_deviate_from_cbf_vel = c.penalty_deviate_from_cbf_steer = -5 / r_p_normalizer  # road_traffic.py:238-243
     c.ttc_low = p.ttc_low if p.ttc_low is not None else 0
     c.ttc_high = p.ttc_high if p.ttc_high is not None else 3.75

@@ -233,7 +233,6 @@ class ScenarioRoadTraffic(BaseScenario):
         if abs(float(p.lane_width) - self.map.parser_lane_width) > 1e-12 and "cpm" not in p.scenario_type:
             raise NotImplementedError(
                 f"map table of {p.scenario_type!r} was parsed with lane_width={self.map.parser_lane_width}; Parameters.lane_width={p.lane_width} needs the map compiler (SURVEY.md 8f-2)")
-        self._noise = bool(p.is_obs_noise)
         cfg = make_config(p, self.map, batch_dim, make_world_scenario_type)
         self.env = SigmaEnv(cfg=cfg, map_table=self.map, device=device)
         self.n_agents = p.n_agents
@@ -399,15 +398,13 @@ class ScenarioRoadTraffic(BaseScenario):
         return self.env.reward[:, self._index(agent)]
 
     def observation(self, agent):
-        """[B, obs_dim] fp32 (road_traffic.py:1334-1366); uniform noise as observation_provider_rt.py:613-618 when enabled."""
+        """[B, obs_dim] fp32 (road_traffic.py:1334-1366); uniform noise as observation_provider_rt.py:613-618 when enabled (device side)."""
         i = self._index(agent)
         if i == 0 and self._obs_dirty:
             self.env.observe()
             self._obs_dirty = False
-        obs = self.env.obs[:, i]
-        if self._noise:
-            obs = obs + float(self.parameters.obs_noise_level) * torch.rand_like(obs)
-        self.stored_observations[i] = obs
+        obs = self.env.obs[:, i]  # incl. the sensor noise: added on the device (sigmaenv_config_t.obs_noise_level), so the rollout record and the
+        self.stored_observations[i] = obs  # on-device actor see the same noisy observation the trainer does
         return obs
 
     def done(self):

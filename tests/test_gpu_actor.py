@@ -264,3 +264,75 @@ def test_rollout_with_cbf_qp_equals_stepwise_calls():
         e.close()
     actor.close()
     actor2.close()
+
+
+def test_fp32_rollout_equals_stepwise_fp32_calls_with_observation_noise():
+    """sigmaenv_rollout_f32 (the reference's precision AND its default observation noise, both on the device) == the same T steps issued one by one:
+    sigmaenv_actor_forward_f32 on the (noisy) observation buffer, then the fused step / record / reset -- bit for bit."""
+    from sigmarl_amd import capi
+    from sigmarl_amd.actor import Actor
+    from sigmarl_amd.shard import slab_width
+
+    kw = dict(is_obs_noise=True, obs_noise_level=0.05, random_seed=3)
+    setups = []
+    for _ in range(2):
+        import torch
+        from sigmarl_amd.actor import make_mlp
+        from sigmarl_amd.env import SigmaEnv
+        from sigmarl_amd.params import Parameters
+
+        torch.manual_seed(1)
+        env = SigmaEnv(Parameters(n_agents=16, scenario_type="cpm_entire", is_use_mtv_distance=False, is_apply_mask=False, **kw), n_envs=96, device="cuda:0")
+        env.reset_random(seed=3)
+        mlp = make_mlp(env.D)
+        setups.append((env, Actor(mlp, low=[-1.0, -0.6], high=[1.0, 0.6])))  # default precision: fp32
+    (env, actor), (env2, actor2) = setups
+    assert actor.precision == "fp32" and env.cfg.obs_noise_level > 0
+    T, W = 6, slab_width(env.N, env.D)
+    slab, slab2 = torch.zeros((T, env.B, W), device="cuda"), torch.zeros((T, env.B, W), device="cuda")
+    lp, lp2 = torch.zeros((T, env.B, env.N), device="cuda"), torch.zeros((T, env.B, env.N), device="cuda")
+    acts = torch.zeros((T, env.B, env.N, 2), device="cuda")
+    actor.rollout(env, T, slab=slab, log_prob=lp, actions=acts, seed=9, counter0=100)
+    env.sync()
+    a = torch.zeros((env2.B, env2.N, 2), device="cuda")
+    for t in range(T):
+        actor2.forward(env2, a, lp2[t], seed=9, counter=100 + t)
+        env2.set_slab(slab2[t])
+        env2.step_autoreset(a, seed=9, counter=100 + t)
+        env2.sync()
+        assert torch.equal(a, acts[t])
+    assert torch.equal(slab, slab2) and torch.equal(lp, lp2)
+    for w in (capi.BUF_OBS, capi.BUF_STATE, capi.BUF_TIMER, capi.BUF_REWARD):
+        assert torch.equal(env.buffer(w), env2.buffer(w))
+    for e, ac in setups:
+        e.close()
+        ac.close()
+
+
+def test_actor_for_an_observation_width_the_bf16_kernel_does_not_take():
+    """is_obs_steering gives obs_dim 35: the exact-fp32 network takes any width, the bf16 kernel only 8 / 16 / 24 / 32 -- an Actor can be built and run
+    in fp32, and asking it for bf16 raises a clear error instead of failing at construction."""
+    import torch
+    from sigmarl_amd.actor import Actor, make_mlp
+    from sigmarl_amd.env import SigmaEnv
+    from sigmarl_amd.params import Parameters
+
+    env = SigmaEnv(Parameters(n_agents=8, scenario_type="cpm_entire", is_use_mtv_distance=False, is_apply_mask=False, is_obs_noise=False, is_obs_steering=True),
+                   n_envs=32, device="cuda:0")
+    env.reset_random(seed=1)
+    assert env.D == 35
+    torch.manual_seed(0)
+    mlp = make_mlp(env.D)
+    actor = Actor(mlp, low=[-1.0, -0.6], high=[1.0, 0.6])
+    act = torch.zeros((env.B, env.N, 2), device="cuda")
+    ls = torch.zeros((env.B, env.N, 4), device="cuda")
+    actor.forward(env, act, None, ls, deterministic=True)
+    env.sync()
+    want = mlp(env.obs.reshape(-1, env.D).cpu()).detach().numpy()
+    assert np.abs(ls.reshape(-1, 4)[:, :2].cpu().numpy() - want[:, :2]).max() <= 1e-5
+    with pytest.raises(ValueError, match="bf16"):
+        actor.forward(env, act, precision="bf16")
+    with pytest.raises(ValueError, match="bf16"):
+        Actor(mlp, low=[-1.0, -0.6], high=[1.0, 0.6], precision="bf16")
+    env.close()
+    actor.close()

@@ -110,6 +110,57 @@ def test_nstep_launch_against_the_oracle(scen, N, B, mtv, rew, T):
     ora.close()
 
 
+@pytest.mark.parametrize("scen,N,B,testing", [("cpm_entire", 16, 96, False), ("intersection_1", 4, 40, False), ("cpm_entire", 8, 24, True)])
+def test_observation_noise_on_the_device(scen, N, B, testing):
+    """is_obs_noise (the reference's default): the uniform noise of observation_provider_rt.py:613-618 is added ON THE DEVICE -- observation buffer,
+    rollout record, what the on-device actor reads.  HIP == oracle (same draws), the T-step launch == T launches bit for bit, and the noise has
+    the reference's scaling (range [0, level), mean level / 2)."""
+    import torch
+    from sigmarl_amd.shard import slab_width, unpack_slab
+
+    T, level = 8, 0.05
+    mp = load_map(scen)
+    pf, pc = mp.list_first[0], mp.list_count[0]
+    kw = dict(n_agents=N, scenario_type=scen, is_use_mtv_distance=False, rew_method="distance", dt=0.1, is_apply_mask=False, max_steps=9, is_testing_mode=testing)
+    cfg = make_config(Parameters(is_obs_noise=True, obs_noise_level=level, random_seed=11, **kw), mp, B)
+    cfg0 = make_config(Parameters(is_obs_noise=False, **kw), mp, B)
+    assert abs(cfg.obs_noise_level - level) < 1e-9 and cfg0.obs_noise_level == 0.0
+    one, many, clean, ora = _hip_env(cfg, mp), _hip_env(cfg, mp), _hip_env(cfg0, mp), ob.OracleEnv(cfg, mp)
+    for d in (one, many, clean):
+        d.env.buffer(capi.BUF_DONE).fill_(1)
+        d.auto_reset(5, 0, pf, pc)
+    ora.get(capi.BUF_DONE, copy=False)[:] = 1
+    ora.auto_reset(5, 0, pf, pc)
+    _compare_all(one, ora, "noisy initial observation")
+    acts = _actions(np.random.default_rng(4), T, B, N, True)
+    W = slab_width(N, one.env.D)
+    rec_one = torch.full((T, B, W), float("nan"), device="cuda")
+    rec_many = torch.full((T, B, W), float("nan"), device="cuda")
+    rec_clean = torch.full((T, B, W), float("nan"), device="cuda")
+    ta = torch.as_tensor(acts).cuda()
+    for t in range(T):
+        one.env.set_slab(rec_one[t])
+        one.env.step_autoreset(ta[t], 5, 100 + t, pf, pc)
+        ora.step(acts[t])
+        obs_t = unpack_slab(rec_one[t], N, one.env.D)[0].cpu().numpy()
+        assert np.abs(obs_t - ora.get(capi.BUF_OBS)).max() <= 1e-5, f"noisy record row, step {t}"
+        ora.auto_reset(5, 100 + t, pf, pc)
+        _compare_all(one, ora, f"noisy step {t}")
+    many.env.step_autoreset_n(ta, rec_many, 5, 100, pf, pc)
+    clean.env.step_autoreset_n(ta, rec_clean, 5, 100, pf, pc)
+    many.env.sync()
+    assert torch.equal(rec_one.view(torch.int32), rec_many.view(torch.int32))
+    for w in INT_BUFS + FLT_BUFS:
+        assert one.get(w).tobytes() == many.get(w).tobytes(), f"buffer {w}"
+    # the noise itself: noisy record - noise-free record (same states: the noise touches nothing but the observation)
+    d = (unpack_slab(rec_many, N, one.env.D)[0] - unpack_slab(rec_clean, N, one.env.D)[0]).double().cpu().numpy().ravel()
+    assert d.min() >= -1e-6 and d.max() < level + 1e-6 and abs(d.mean() - level / 2) < 1e-3 and abs(d.var() - level ** 2 / 12) < 1e-4
+    for w in INT_BUFS + [capi.BUF_STATE, capi.BUF_REWARD]:
+        assert many.get(w).tobytes() == clean.get(w).tobytes()
+    for e in (one, many, clean, ora):
+        e.close()
+
+
 def test_nstep_rejects_what_it_cannot_do():
     import torch
 

@@ -306,3 +306,47 @@ def test_device_sampler_specification_matches_the_reference_distribution(tag, te
     got = rdc.sample_histograms(env, mp, rounds=4)
     env.close()
     rdc.compare(tag, got)
+
+
+def test_observation_noise_specification_matches_the_reference_scaling():
+    """`obs + obs_noise_level * rand_like(obs)` (observation_provider_rt.py:613-618): uniform in [0, level) on every element, fresh at every step.  The
+    oracle side of the shared specification (the HIP kernels draw the same numbers: tests/test_gpu_nstep.py): range, mean level / 2, variance
+    level^2 / 12, no element repeated from one step to the next, a function of (random_seed, env index in the batch) only."""
+    import numpy as np
+    import oracle_binding as ob
+    from sigmarl_amd import capi
+    from sigmarl_amd.maps import load_map
+    from sigmarl_amd.params import Parameters, make_config
+
+    mp = load_map("cpm_entire")
+    N, B, level = 8, 96, 0.05
+    kw = dict(n_agents=N, scenario_type="cpm_entire", is_apply_mask=False, is_use_mtv_distance=False, max_steps=9)
+    pf, pc = mp.list_first[0], mp.list_count[0]
+
+    def run(noise, seed=0, base=0, lo=0, hi=B):
+        p = Parameters(is_obs_noise=noise, obs_noise_level=level, random_seed=seed, **kw)
+        e = ob.OracleEnv(make_config(p, mp, hi - lo, env_index_base=base + lo), mp)
+        e.get(capi.BUF_DONE, copy=False)[:] = 1
+        e.auto_reset(3, 0, pf, pc)
+        rng = np.random.default_rng(0)
+        out = [e.get(capi.BUF_OBS).copy()]
+        for t in range(6):
+            act = np.stack([rng.uniform(0, 1, (B, N)), rng.uniform(-0.25, 0.25, (B, N))], -1).astype(np.float32)
+            e.step(act[lo:hi])
+            out.append(e.get(capi.BUF_OBS).copy())
+            e.auto_reset(3, t + 1, pf, pc)
+        e.close()
+        return np.stack(out)
+
+    clean, noisy = run(False), run(True)
+    assert make_config(Parameters(is_obs_noise=False, **kw), mp, 4).obs_noise_level == 0.0
+    d = (noisy.astype(np.float64) - clean).ravel()
+    assert d.min() >= -1e-7 and d.max() < level + 1e-7                      # [0, level)
+    assert abs(d.mean() - level / 2) < 2e-4 and abs(d.var() - level ** 2 / 12) < 2e-5
+    h, _ = np.histogram(d, bins=10, range=(0, level))
+    assert h.min() > 0.9 * d.size / 10 and h.max() < 1.1 * d.size / 10      # flat
+    n = noisy.astype(np.float64) - clean
+    assert abs(np.corrcoef(n[2].ravel(), n[3].ravel())[0, 1]) < 0.02        # fresh numbers every step
+    assert np.array_equal(noisy, run(True)) and not np.array_equal(noisy, run(True, seed=7))
+    # the draws follow the env's index in the WHOLE batch: a shard sees what the unsharded batch sees
+    assert np.array_equal(run(True, lo=32, hi=64), noisy[:, 32:64])
