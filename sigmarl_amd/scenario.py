@@ -13,8 +13,15 @@ VMAS drives a scenario as ``world.step()`` then ``reward(a)`` for all agents, ``
 (dynamics -> distances/collisions -> rewards -> observations -> done flags); the callbacks only hand out views of the results
 and ``done()`` performs the host-driven per-agent resets the reference performs there (RNG stays in torch, as in the reference).
 
-vmas itself is optional: when it is importable the classes derive from its base classes (so ``VmasEnv`` accepts them); in this
-build image it is absent and light stand-ins are used.  A CUDA/HIP device is mandatory -- there is no CPU fallback.
+vmas itself is absent from the build image (and cannot be installed: no network), so what is verified is this: ``ScenarioRoadTraffic`` derives
+from ``vmas.simulator.scenario.BaseScenario`` when vmas is importable and from a stand-in with the same five entry points otherwise;
+``WorldCustom`` and ``Vehicle`` are plain classes (NOT subclasses of ``vmas.simulator.core.World`` / ``Agent``) that carry every attribute
+``vmas.simulator.environment.Environment`` touches on them while it resets, sets actions, steps and collects results -- ``world.policy_agents``,
+``world.dim_c`` / ``dim_p``, ``world.to``, ``agent.action_size``, ``agent.silent`` / ``movable`` / ``action_script``, ``agent.action.u``,
+``action.u_range_tensor`` / ``u_multiplier_tensor`` / ``u_noise`` -- and ``tests/vmas_env_shim.py`` restates that driver (attribute accesses of
+VMAS 1.4.3's ``Environment.__init__ / reset / reset_at / step / _set_action / get_from_scenario / done``, from its published source; third-party,
+unverifiable here) and ``tests/test_gpu_scenario.py`` runs the mirror under it.  It has never run under the real ``VmasEnv``.
+A CUDA/HIP device is mandatory -- there is no CPU fallback.
 """
 from __future__ import annotations
 
@@ -94,8 +101,21 @@ class KinematicBicycleModel:
 
 
 class _Action:
-    def __init__(self):
-        self.u = None  # None before the first step (road_traffic.py:1505, observation_provider_rt.py:948)
+    """``vmas.simulator.core.Action`` as ``Environment._set_action`` uses it: ``u`` (None before the first step, road_traffic.py:1505,
+    observation_provider_rt.py:948), the per-dimension range / multiplier tensors, no action noise."""
+
+    def __init__(self, u_range, u_multiplier, device):
+        self.u = None
+        self.c = None
+        self.u_range, self.u_multiplier, self.u_noise = u_range, u_multiplier, 0.0
+        self.action_size = len(u_range)
+        self.u_range_tensor = torch.tensor([float(x) for x in u_range], dtype=torch.float32, device=device)
+        self.u_multiplier_tensor = torch.tensor([float(x) for x in u_multiplier], dtype=torch.float32, device=device)
+        self.u_noise_tensor = torch.zeros(self.action_size, dtype=torch.float32, device=device)
+
+    def to(self, device):
+        for k in ("u_range_tensor", "u_multiplier_tensor", "u_noise_tensor"):
+            setattr(self, k, getattr(self, k).to(device))
 
 
 class VehicleState:
@@ -127,9 +147,17 @@ class Vehicle:
         self.max_speed = max_speed
         self.dynamics = dynamics
         self._state = VehicleState(state_row)
-        self._action = _Action()
         self.batch_dim = state_row.shape[0]
         self.device = state_row.device
+        self._action = _Action(u_range, self.u_multiplier, self.device)
+        # what vmas' Environment reads on an agent while it sets actions and collects results (Agent(..., dynamics=...) derives action_size from
+        # dynamics.needed_action_size; road_traffic.py:788-813 passes collide=False, render_action=False, no action script, silent by default)
+        self.action_size = dynamics.needed_action_size
+        self.silent, self.movable, self.rotatable, self.action_script, self.is_scripted_ai = True, True, True, None, False
+        self.obs_range, self.obs_noise, self.discrete_action_nvec = None, None, [3] * self.action_size
+
+    def to(self, device):  # TorchVectorizedObject.to: the state lives in the library's device buffers, only the small tensors move
+        self._action.to(device)
 
     @property
     def state(self):
@@ -178,6 +206,21 @@ class WorldCustom:
         self.parameters = None
         self._actions = torch.zeros((env.B, env.N, 2), dtype=torch.float32, device=env.device)
         self._scenario = None
+        self.dim_c, self.dim_p = 0, 2  # no communication channel, planar positions (vmas World defaults; Environment._set_action reads dim_c)
+
+    def to(self, device):
+        """``TorchVectorizedObject.to``: the env shard lives on the GPU it was created on; moving it is not possible."""
+        if torch.device(device) != self.device and not (torch.device(device).type == "cuda" and torch.device(device).index in (None, self.device.index)):
+            raise RuntimeError(f"the environment lives on {self.device}; create the scenario on the target device instead")
+        for a in self._agents:
+            a.to(self.device)
+
+    @property
+    def scripted_agents(self):
+        return []
+
+    def zero_grad(self):
+        return
 
     @property
     def agents(self):

@@ -303,3 +303,44 @@ def test_solver_regressions_converge_to_the_solution_of_the_original_problem(tag
         assert compare_with_original_problem(env, u, con, unom, kw["nom_controller_type"], 1) <= 1e-5
     check_kkt(env, u, con, unom, kw["nom_controller_type"], tol=1e-8) if not kw.get("is_grouping_agents") else None
     env.close()
+
+
+# ---- the instance of the randomised differential run (tools/fuzz_cbf.py, seed 13) on which HIP and oracle once differed by 1.4e-7 ------------
+FUZZ_INSTANCE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "qp_fuzz_instance.npz")
+FUZZ_IP_TOL = 1e-6  # against the interior-point solution of the ORIGINAL grouped problems (observed worst: 1.7e-7; OSQP's own tolerance is 1e-5)
+
+
+def fuzz_instance(make_env):
+    """11 envs x 14 vehicles, grouped QPs (max_group_size 4, 2 circles, observation_range 0.3, lambda penalty): the states of a fuzz step whose
+    1e9-weighted rows leave the minimiser determined to ~1e-7.  (The groups are formed from these states at the first call; the fuzz run's own
+    grouping, formed steps earlier, was not recorded.)"""
+    z = np.load(FUZZ_INSTANCE)
+    kw = eval(str(z["kw"]))
+    mp = load_map(kw["scenario_type"])
+    p = Parameters(**kw)
+    B, N = z["state"].shape[0], kw["n_agents"]
+    env = make_env(make_config(p, mp, B), mp)
+    seg_l, seg_r = cbf.load_segment_tables(mp)
+    env.cbf_attach(cbf.make_cbf_config(p), seg_l, seg_r)
+    env.reset(np.repeat(np.arange(B), N).astype(np.int32), np.tile(np.arange(N), B).astype(np.int32), z["path"].reshape(-1, 4), z["state"].reshape(-1, 8), 1)
+    return env, z["act"].astype(np.float32), z["short"], kw
+
+
+def fuzz_instance_ground_truth():
+    """(oracle env with the rows built, its solution u [B, N, 2], the interior-point solutions of the original group problems [B, 2 N])"""
+    import test_cbf_grouped as tg
+
+    env, act, short, kw = fuzz_instance(ob.OracleEnv)
+    env.get(4, copy=False)[:] = short
+    safe, u, info, con, unom = env.cbf_qp(act, with_data=True)
+    assert info[:, 1].all()
+    x = np.stack([tg.solve_grouped_original(env, con[b], unom[b], kw["nom_controller_type"], b, Cc=int(kw["n_circles_approximate_vehicle"])) for b in range(len(u))])
+    return env, u, x
+
+
+def test_fuzz_instance_oracle_equals_the_interior_point_solution():
+    env, u, x = fuzz_instance_ground_truth()
+    err = np.abs(x - u.reshape(len(u), -1)).max(axis=1)
+    print("oracle vs interior point per env:", " ".join(f"{e:.1e}" for e in err))
+    assert err.max() <= FUZZ_IP_TOL
+    env.close()

@@ -45,7 +45,9 @@ def test_hip_vs_reference_goldens(name):
     rep = tr.replay(env, z, meta, mp)
     env.close()
     assert rep.total_mismatch() == 0, str(rep)
-    assert rep.cbf_ok(), str(rep)
+    if rep.cbf_count:
+        print(f"{name}: {rep}")
+    assert rep.cbf_ok(name), str(rep)
     for key, err in rep.max_abs.items():
         tol = MTV_TOL if (meta["is_use_mtv_distance"] and key in ("dist_agents", "obs", "reward", "rew_total", "rew_near_other_agents")) else FTOL
         assert err <= tol, (key, err, str(rep))

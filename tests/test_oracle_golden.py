@@ -142,7 +142,9 @@ def test_trajectory(name):
     rep = tr.replay(env, z, meta, mp)
     env.close()
     assert rep.total_mismatch() == 0, str(rep)  # masks, indices, counters, done: bit-exact
-    assert rep.cbf_ok(), str(rep)
+    if rep.cbf_count:
+        print(f"{name}: {rep}")  # observed worst and outlier count per CBF quantity (pytest -s / on failure)
+    assert rep.cbf_ok(name), str(rep)
     for key, err in rep.max_abs.items():
         tol = MTV_TOL if (meta["is_use_mtv_distance"] and key in ("dist_agents", "obs", "reward", "rew_total", "rew_near_other_agents")) else FTOL
         assert err <= tol, (key, err, str(rep))
@@ -205,7 +207,8 @@ def test_cbf_margins_on_set_states():
     ri = env.get(capi.BUF_REWARD_INFO)
     rep.cbf("rew", np.stack([ri[5], ri[6], ri[4]]), z["p2_rew"])
     env.close()
-    assert rep.cbf_ok(), str(rep)
+    print(f"cbf_functions: {rep}")
+    assert rep.cbf_ok("cbf_functions"), str(rep)
     assert (z["p2_pair"] < 0).sum() > 100 and (z["p2_lane_left"] < 0).sum() > 100  # the case exercises violations
 
 

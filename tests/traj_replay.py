@@ -24,10 +24,14 @@ TRAJ_NAMES = ["cpm16_c2c", "cpm16_mtv", "intersection4_c2c", "onramp6_mtv", "cpm
 # one-ulp difference in a float32 circle centre (torch's cos / sin -- a closed vector math library, within 1 ulp of the correctly rounded
 # value the oracle and the HIP path compute and NOT restatable, see include/sigma_trig_f32.h -- ) can flip
 # an fp16 rounding and move a margin by up to ~5e-3.  Against the reference goldens the CBF quantities are therefore checked as:
-# all but a fraction CBF_OUTLIER_FRAC within CBF_TOL (scaled by max(1, |value|)), every entry within CBF_OUTLIER_TOL.
+# every entry within CBF_TOL (scaled by max(1, |value|)) -- observed worst over all goldens: 3.3e-7 -- EXCEPT the individually listed
+# outliers: per golden and quantity the number of entries that were observed beyond CBF_TOL (one each, three in total over ~105 000
+# compared entries) and a bound of twice their observed deviation.  A new outlier, or a larger one, fails.
 CBF_TOL = 2e-6
-CBF_OUTLIER_TOL = 2e-2
-CBF_OUTLIER_FRAC = 2e-3
+CBF_KNOWN_OUTLIERS = {  # golden -> quantity -> (entries allowed beyond CBF_TOL, bound on them = 2 x the observed deviation)
+    "onramp4_cbf_clf": {"cbf_lane_right": (1, 2 * 2.93e-3)},                          # 1 of 864 margins, off by 2.92e-3
+    "cbf_functions": {"lane_right": (1, 2 * 2.44e-6), "rew": (1, 2 * 1.22e-5)},        # 1 of 2304 margins (2.4e-6) and the reward channel it feeds (1.2e-5)
+}
 
 
 def load_fixture(name):
@@ -87,9 +91,12 @@ class Report:
         self.cbf_count[key] = self.cbf_count.get(key, 0) + int(d.size)
         self.cbf_worst[key] = max(self.cbf_worst.get(key, 0.0), float(d.max()) if d.size else 0.0)
 
-    def cbf_ok(self):
+    def cbf_ok(self, golden=None):
+        """every CBF entry within CBF_TOL, except the known outliers of `golden` (count and size bounded by what was observed x 2)"""
+        known = CBF_KNOWN_OUTLIERS.get(golden, {})
         for k, n in self.cbf_count.items():
-            if self.cbf_worst[k] > CBF_OUTLIER_TOL or self.cbf_bad[k] > max(1, int(CBF_OUTLIER_FRAC * n)):
+            allowed, bound = known.get(k, (0, CBF_TOL))
+            if self.cbf_bad[k] > allowed or self.cbf_worst[k] > max(bound, CBF_TOL):
                 return False
         return True
 
