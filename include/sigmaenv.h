@@ -241,6 +241,15 @@ int sigmaenv_step_autoreset_n(sigmaenv_t* h, const float* actions, int32_t n_ste
 
 int sigmaenv_get(sigmaenv_t* h, sigmaenv_buf_t which, void** dev_ptr, size_t* bytes);
 
+/* The lanelet tables of the map for the lanelet-relation mask of the BIRD-VIEW observation (sigmarl/map_manager.py:41-118,
+ * observation_provider_rt.py:577-665): with SIGMAENV_OBS_BIRD_VIEW and is_apply_mask an observed neighbour is masked when its lanelet is not
+ * listed among the neighbouring lanelets of the ego's lanelet (OR the distance criterion).  centers: HOST f32 [n_lanelets, max_points, 2], the
+ * centre lines of parser.lanelets_all stacked and ZERO-padded as MapManager.determine_current_lanelet pads them (the padding is a candidate point
+ * at the origin there, and here); an agent's lanelet = argmin over lanelets of the minimal squared distance to its points, first index on ties.
+ * neighbors: HOST u64 [n_lanelets], bit j of entry i = lanelet j is in parser.neighboring_lanelets_idx[i].  n_lanelets <= 64.  Maps whose parser
+ * has no neighbour table (the CPM map) do not call this: the mask by lanelets then masks nobody, as in the reference.  Copied to the device. */
+int sigmaenv_set_lanelets(sigmaenv_t* h, int32_t n_lanelets, int32_t max_points, const float* centers, const uint64_t* neighbors);
+
 /* Rollout slab (wire format of the learner-boundary exchange): when dev_ptr != NULL every following sigmaenv_step also writes
  * one contiguous fp32 row per env, [N*D observation | N reward | 1 done], to dev_ptr ([B, N*(D+1)+1]).  The caller rotates the
  * pointer through its rollout buffer; NULL disables the record.  Replaces the per-step tensordict stacking of

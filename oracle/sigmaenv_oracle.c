@@ -54,6 +54,9 @@ typedef struct sigmaenv_oracle {
   int cbf_groups_valid;
   float *seg_left, *seg_right;  /* [n_paths][seg_stride][5] */
   int seg_stride;
+  float* lanelet_centers;       /* [n_lanelets][lanelet_pts][2] zero-padded centre lines of parser.lanelets_all (sigmaenv_oracle_set_lanelets) */
+  uint64_t* lanelet_neigh;      /* [n_lanelets] bit j: lanelet j is in parser.neighboring_lanelets_idx[i] */
+  int n_lanelets, lanelet_pts;
   char err[256];
 } oracle_t;
 
@@ -444,6 +447,37 @@ static inline void ego_transform(float pix, float piy, float rot_i, float pjx, f
 
 /* observation of one agent (ego view, partial observation): observation_provider_rt.py:345-588 (latest slot only), :594-925.  obs_flags = 0 is
  * the default layout; the SIGMAENV_OBS_* switches add / drop / replace columns exactly where _observe_self / _observe_other_agents do. */
+/* MapManager.determine_current_lanelet (map_manager.py:41-92): squared distances of the position to every centre-line point of every lanelet (the
+ * stacked tensor is zero-padded, the padding counts), minimum per lanelet, argmin over the lanelets (first index on ties) */
+static int current_lanelet(const oracle_t* o, float px, float py) {
+  int best = 0;
+  float bd = INFINITY;
+  for (int l = 0; l < o->n_lanelets; ++l) {
+    float md = INFINITY;
+    const float* c = o->lanelet_centers + (size_t)l * o->lanelet_pts * 2;
+    for (int q = 0; q < o->lanelet_pts; ++q) {
+      float dx = px - c[2 * q], dy = py - c[2 * q + 1];
+      float d = dx * dx + dy * dy;                               /* torch.sum((a - c) ** 2, dim=4) */
+      if (d < md) md = d;
+    }
+    if (md < bd) { bd = md; best = l; }
+  }
+  return best;
+}
+
+int sigmaenv_oracle_set_lanelets(oracle_t* o, int32_t n_lanelets, int32_t max_points, const float* centers, const uint64_t* neighbors) {
+  if (!o || n_lanelets < 1 || n_lanelets > 64 || max_points < 1 || !centers || !neighbors) return SIGMAENV_EINVAL;
+  free(o->lanelet_centers); free(o->lanelet_neigh);
+  o->lanelet_centers = (float*)malloc((size_t)n_lanelets * max_points * 2 * sizeof(float));
+  o->lanelet_neigh = (uint64_t*)malloc((size_t)n_lanelets * sizeof(uint64_t));
+  if (!o->lanelet_centers || !o->lanelet_neigh) return SIGMAENV_ENOMEM;
+  memcpy(o->lanelet_centers, centers, (size_t)n_lanelets * max_points * 2 * sizeof(float));
+  memcpy(o->lanelet_neigh, neighbors, (size_t)n_lanelets * sizeof(uint64_t));
+  o->n_lanelets = n_lanelets;
+  o->lanelet_pts = max_points;
+  return SIGMAENV_OK;
+}
+
 static void agent_observation(oracle_t* o, int b, int i) {
   int N = o->N, K = o->K, D = o->D;
   const sigmaenv_config_t* c = &o->cfg;
@@ -472,6 +506,10 @@ static void agent_observation(oracle_t* o, int b, int i) {
   }
   int p = 0;
   const int bird = (F & SIGMAENV_OBS_BIRD_VIEW) != 0;            /* is_ego_view == False: world frame, normalizers.pos_world (:537-575) */
+  /* mask by lanelet relation (:638-665, map_manager.py:94-118): the agents' lanelets exist in bird view only (:577-588), the neighbour table on
+   * OSM maps only; an ego lanelet beyond the table (interchange_3 lists 20 of its 22 lanelets) raises IndexError in the reference, masks here */
+  const int lane_mask = bird && c->is_apply_mask && o->n_lanelets > 0;
+  const uint64_t ego_neigh = lane_mask ? o->lanelet_neigh[current_lanelet(o, si[0], si[1])] : ~0ull;
   const float nwx = c->world_x_dim, nwy = c->world_y_dim;
 #define OBS_POINT(tx, ty, ox, oy) do { if (bird) { ox = (tx) / nwx; oy = (ty) / nwy; } else { float ex_, ey_; ego_transform(si[0], si[1], si[2], (tx), (ty), &ex_, &ey_); ox = ex_ / n_pos; oy = ey_ / n_pos; } } while (0)
   if (bird) {                                                    /* [own] position and rotation (:862-877) */
@@ -527,7 +565,8 @@ static void agent_observation(oracle_t* o, int b, int i) {
     size_t bj = (size_t)b * N + j;
     const float* sj = o->state + bj * 8;
     const float* vj = o->vertices + bj * 10;
-    const int masked = c->is_apply_mask && Drow[j] >= c->distance_mask_agents;
+    int masked = c->is_apply_mask && Drow[j] >= c->distance_mask_agents;
+    if (lane_mask) masked = masked || !((ego_neigh >> current_lanelet(o, sj[0], sj[1])) & 1ull);
     if (!(F & SIGMAENV_OBS_NO_VERTICES)) {
       for (int q = 0; q < 4; ++q) {
         float ox, oy;
@@ -847,7 +886,7 @@ void sigmaenv_oracle_destroy(oracle_t* o) {
   void* ptrs[] = {o->center, o->left, o->right, o->yaw, o->n_center, o->n_left, o->n_right, o->is_loop, o->state, o->prev_pos,
                   o->vertices, o->short_term, o->dist_ref, o->dist_left, o->dist_right, o->dist_bound, o->dist_agents, o->reward,
                   o->reward_info, o->obs, o->action, o->path, o->closest, o->nearing, o->timer, o->col_agents, o->col_flags, o->done,
-                  o->seg_left, o->seg_right, o->cbf_nominal, o->cbf_groups, o->fresh};
+                  o->seg_left, o->seg_right, o->cbf_nominal, o->cbf_groups, o->fresh, o->lanelet_centers, o->lanelet_neigh};
   for (size_t k = 0; k < sizeof(ptrs) / sizeof(ptrs[0]); ++k) free(ptrs[k]);
   free(o);
 }

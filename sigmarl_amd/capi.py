@@ -134,6 +134,7 @@ _SIGS = {
     "auto_reset": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32]),
     "get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "sync": (C.c_int, [C.c_void_p]),
+    "set_lanelets": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "cbf_attach": (C.c_int, [C.c_void_p, C.POINTER(CbfConfig), C.c_void_p, C.c_void_p, C.c_int32]),
     "cbf_rewards": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cbf_qp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

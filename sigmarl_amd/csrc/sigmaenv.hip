@@ -1332,6 +1332,9 @@ struct sigmaenv {
   sigmaenv_cbf_config_t cbf_cfg{};
   void *cbf_seg4 = nullptr, *cbf_segl = nullptr, *cbf_cxy = nullptr, *cbf_u = nullptr, *cbf_kin = nullptr, *cbf_clf = nullptr, *cbf_safe = nullptr;
   int cbf_seg_stride = 0;
+  float* lanelet_centers = nullptr;           // [n_lanelets, lanelet_pts, 2] zero-padded centre lines (sigmaenv_set_lanelets)
+  unsigned long long* lanelet_neigh = nullptr;  // [n_lanelets] neighbour bit masks
+  int n_lanelets = 0, lanelet_pts = 0;
   float* obs_var = nullptr;       // [B,N,D_pub]: the public observation buffer when cfg.obs_flags != 0 (sigmaenv_obs_variant.inc)
   int D_pub = 0;                  // its row width (= D for the default flags)
   int32_t* cbf_groups = nullptr;  // [B,N] group index of every vehicle (grouped CBF-QPs), formed by the first sigmaenv_cbf_qp call
@@ -1695,8 +1698,26 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
 static int launch_obs_variant(sigmaenv* h) {
   if (!h->obs_var) return SIGMAENV_OK;
   const size_t BN = (size_t)h->B * h->N;
-  hipLaunchKernelGGL(obsvar::sigmaenv_observe_variant_kernel, dim3((unsigned)((BN + 255) / 256)), dim3(256), 0, h->stream, h->cfg, h->map, h->buf, h->obs_var, h->D_pub);
+  hipLaunchKernelGGL(obsvar::sigmaenv_observe_variant_kernel, dim3((unsigned)((BN + 255) / 256)), dim3(256), 0, h->stream, h->cfg, h->map, h->buf, h->obs_var, h->D_pub,
+                     (const float*)h->lanelet_centers, (const unsigned long long*)h->lanelet_neigh, h->n_lanelets, h->lanelet_pts);
   HIPCHK(h, hipGetLastError());
+  return SIGMAENV_OK;
+}
+
+extern "C" int sigmaenv_set_lanelets(sigmaenv_t* h, int32_t n_lanelets, int32_t max_points, const float* centers, const uint64_t* neighbors) {
+  if (!h) return SIGMAENV_EINVAL;
+  if (n_lanelets < 1 || n_lanelets > 64 || max_points < 1 || !centers || !neighbors) { h->err = "set_lanelets: 1..64 lanelets with their centre lines and neighbour masks"; return SIGMAENV_EINVAL; }
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->lanelet_centers) { dev_free(h, h->lanelet_centers); dev_free(h, h->lanelet_neigh); h->lanelet_centers = nullptr; h->lanelet_neigh = nullptr; h->n_lanelets = 0; }
+  int rc;
+  if ((rc = dev_alloc(h, (void**)&h->lanelet_centers, (size_t)n_lanelets * max_points * 2 * sizeof(float))) != SIGMAENV_OK) return rc;
+  if ((rc = dev_alloc(h, (void**)&h->lanelet_neigh, (size_t)n_lanelets * sizeof(uint64_t))) != SIGMAENV_OK) return rc;
+  HIPCHK(h, hipMemcpyAsync(h->lanelet_centers, centers, (size_t)n_lanelets * max_points * 2 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->lanelet_neigh, neighbors, (size_t)n_lanelets * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->n_lanelets = n_lanelets;
+  h->lanelet_pts = max_points;
   return SIGMAENV_OK;
 }
 

@@ -140,6 +140,12 @@ class SigmaEnv:
             assert int(np.prod(shape)) * _TORCH_DTYPES[kind][2] == nb.value, (which, shape, nb.value)
             self._views[which] = device_view(p.value, shape, kind, self.device.index, self)
         self._reset_counter = 0
+        # bird view + is_apply_mask: the lanelet-relation mask needs the map's lanelet tables (none on the CPM map: the mask is empty there)
+        if (int(getattr(cfg, "obs_flags", 0)) & capi.OBS_BIRD_VIEW) and cfg.is_apply_mask and map_table.lanelet_tables() is not None:
+            centers, neigh = map_table.lanelet_tables()
+            self._lanelets = (centers, neigh)
+            self._chk(self.lib.set_lanelets(self.h, int(centers.shape[0]), int(centers.shape[1]), centers.ctypes.data_as(C.c_void_p), neigh.ctypes.data_as(C.c_void_p)),
+                      "set_lanelets")
 
     # ---- plumbing ---------------------------------------------------------------------------------------------
     def _chk(self, rc, what):

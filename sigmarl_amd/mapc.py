@@ -103,7 +103,29 @@ def _yaw(center: np.ndarray) -> np.ndarray:
     return np.arctan2(v[:, 1].astype(np.float64), v[:, 0].astype(np.float64)).astype(f32)
 
 
-def compile_osm(src: MapSource, reference_paths_ids: List[List[int]], lane_width: float, scale: float) -> dict:
+def lanelet_tables(lanelets: Dict[int, np.ndarray], neighboring_lanelet_ids: Optional[List[List[int]]]) -> dict:
+    """What ``MapManager.determine_current_lanelet`` / ``determine_masked_agents_by_lanelets`` (map_manager.py:41-118) work on: the centre lines of
+    ``lanelets_all`` (lanelet ids 1 .. max in id order, parse_osm.py:166-171) stacked into ``[L, max_len, 2]`` and ZERO-padded -- the reference pads
+    with ``torch.nn.functional.pad``, so the padded entries are real candidate points at the origin --, and ``neighboring_lanelets_idx``
+    (parse_osm.py:256-262: 0-based index lists) as one bit mask per lanelet (bit j: lanelet j is visible from this lanelet)."""
+    L = max(lanelets) if lanelets else 0
+    ml = max((len(c) for c in lanelets.values()), default=1)
+    centers = np.zeros((L, ml, 2), f32)
+    n_pts = np.zeros(L, np.int32)
+    for lid, c in lanelets.items():
+        centers[lid - 1, : len(c)] = c
+        n_pts[lid - 1] = len(c)
+    masks = np.zeros(L, np.uint64)
+    if neighboring_lanelet_ids:
+        if len(neighboring_lanelet_ids) > 64 or L > 64:
+            raise ValueError("more than 64 lanelets: the neighbour masks are 64-bit")
+        for i, ids in enumerate(neighboring_lanelet_ids):
+            for n in ids:
+                masks[i] |= np.uint64(1) << np.uint64(int(n) - 1)
+    return {"lanelet_centers": centers, "n_lanelet_points": n_pts, "lanelet_neighbors": masks, "has_lanelet_neighbors": np.int32(bool(neighboring_lanelet_ids))}
+
+
+def compile_osm(src: MapSource, reference_paths_ids: List[List[int]], lane_width: float, scale: float, neighboring_lanelet_ids: Optional[List[List[int]]] = None) -> dict:
     """The reference-path table of an OSM scenario, with the keys of ``assets/maps/<scenario>.npz``.
 
     ``lane_width`` is the width ``MapManager`` is constructed with -- the scenario passes ``Parameters.lane_width`` (0.25 by default,
@@ -131,7 +153,9 @@ def compile_osm(src: MapSource, reference_paths_ids: List[List[int]], lane_width
             center = center[:-1]                             # ... and a loop's last node repeats its first
         left, right = _boundaries(center, lane_width)
         paths.append({"center": center, "yaw": _yaw(center), "left": left, "right": right, "is_loop": is_loop, "lanelet_ids": [int(x) - 1 for x in ids]})
-    return _pack(paths, lane_width)
+    out = _pack(paths, lane_width)
+    out.update(lanelet_tables(lanelets, neighboring_lanelet_ids))
+    return out
 
 
 def _pack(paths: List[dict], parser_lane_width: float) -> dict:
@@ -286,7 +310,7 @@ def compile_scenario(scenario_type: str, lane_width: float = 0.25, osm_path: Opt
         out["n_lanelets_all"] = np.int32(len(src.lanelet_id))
         return out
     src = read_osm(osm_path) if osm_path else load_source(scenario_type)
-    out = compile_osm(src, spec["reference_paths_ids"], lane_width, float(spec["scale"]))
+    out = compile_osm(src, spec["reference_paths_ids"], lane_width, float(spec["scale"]), spec.get("neighboring_lanelet_ids"))
     out["lane_width"] = np.float64(spec["lane_width"])
     out["default_n_agents"] = np.int32(spec["n_agents"])
     return out

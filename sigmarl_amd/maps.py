@@ -37,6 +37,7 @@ class MapTable:
         self.scenario_type = scenario_type
         self.name = scenario_type
         self.from_asset = table is None  # the shipped table (pseudo-distance segment assets exist for these only)
+        self._table = dict(table) if table is not None else None
         self.n_paths = int(z["center"].shape[0])
         stride = max(z["center"].shape[1], z["left"].shape[1], z["right"].shape[1])
         self.stride = int(stride)
@@ -72,6 +73,25 @@ class MapTable:
             rows = np.nonzero(self.list_id == li)[0]
             self.list_first[li] = int(rows[0]) if len(rows) else 0
             self.list_count[li] = int(len(rows))
+
+    def lanelet_tables(self):
+        """(centers f32 [L, max_len, 2] zero-padded, neighbour bit masks u64 [L]) of the map's lanelets -- what the lanelet-relation mask of the
+        bird-view observation works on (map_manager.py:41-118) -- or None when the map has no neighbour table (the CPM map: its parser leaves
+        ``neighboring_lanelets_idx`` empty and the mask masks nobody, observation_provider_rt.py:647-665).  A compiled table carries them; for a
+        shipped OSM table they are compiled from the shipped map source (``sigmarl_amd.mapc``)."""
+        if getattr(self, "_lanelets", None) is None:
+            t = self._table if self._table is not None and "lanelet_centers" in self._table else None
+            if t is None and self.from_asset and "cpm" not in self.scenario_type:
+                from . import mapc
+
+                spec = mapc.scenario_specs().get(self.scenario_type)
+                if spec is not None and spec["map_path"].endswith(".osm"):
+                    t = mapc.compile_scenario(self.scenario_type, lane_width=self.parser_lane_width)
+            if t is None or not int(t.get("has_lanelet_neighbors", 0)):
+                self._lanelets = ()
+            else:
+                self._lanelets = (np.ascontiguousarray(t["lanelet_centers"], np.float32), np.ascontiguousarray(t["lanelet_neighbors"], np.uint64))
+        return self._lanelets or None
 
     def global_path(self, scenario_id: int, path_id: int) -> int:
         """(scenario_id, list-local path_id) -> global row.  scenario_id 0 = all paths, 1..3 = CPM sub-scenarios."""

@@ -103,10 +103,8 @@ def obs_flags(p: Parameters) -> int:
 def check_supported(p: Parameters) -> None:
     """Raise for observation/feature flags the fused step does not implement (fail loudly, never silently differ)."""
     bad = []
-    if not p.is_ego_view and p.is_apply_mask:
-        # bird view itself is built (capi.OBS_BIRD_VIEW); with is_apply_mask the reference then also masks by lanelet relation, which needs the
-        # parsers' neighbouring-lanelet tables (observation_provider_rt.py:577-588, map_manager.py:41-118): not built
-        bad.append("is_ego_view=False together with is_apply_mask=True (lanelet-relation mask)")
+    # bird view with is_apply_mask (the lanelet-relation mask, observation_provider_rt.py:577-665 / map_manager.py:41-118) IS built: SigmaEnv hands the
+    # map's lanelet tables to the library (sigmaenv_set_lanelets); maps without a neighbour table (the CPM map) mask by distance only, as in the reference
     if not p.is_partial_observation:
         bad.append("is_partial_observation=False")
     # is_apply_mask: in ego view (the only view built) only the DISTANCE criterion is live in the reference -- the lanelet of every agent

@@ -81,6 +81,9 @@ def snapshot(env, prefix, with_obs=None, rew=None):
     if with_obs is not None:
         d[prefix + "obs"] = np_(torch.stack(with_obs, dim=1))
         d[prefix + "nearing_idx"] = np_(sc.observation_provider.observations.nearing_agents_indices)
+        cur = sc.observation_provider.map.current_lanelet_idx  # bird view + is_apply_mask only (map_manager.py:41-92): the agents' lanelets
+        if isinstance(cur, torch.Tensor) and cur.numel():
+            d[prefix + "current_lanelet"] = np_(cur.reshape(cur.shape[0], -1)).astype(np.int32)
     if rew is not None:
         d[prefix + "reward"] = np_(torch.stack(rew, dim=1))
         for f in REWARD_FIELDS:
@@ -680,6 +683,14 @@ TRAJS = {
                                  rew_method="distance", is_observe_distance_to_boundaries=False),
     "onramp4_boundary_points_bird": dict(T=32, B=3, seed=34, mode_pattern=[1, 1, 0], n_agents=4, scenario_type="on_ramp_1", dt=0.1, is_use_mtv_distance=False,
                                          rew_method="distance", is_observe_distance_to_boundaries=False, is_ego_view=False, is_apply_mask=False),
+    # bird view WITH is_apply_mask: the lanelet-relation mask (observation_provider_rt.py:577-665, map_manager.py:41-118) -- on OSM maps the parser's
+    # neighbouring-lanelet table masks observed neighbours whose lanelet the ego's lanelet does not list; on the CPM map the table is empty
+    "intersection4_birdview_mask": dict(T=40, B=3, seed=35, mode_pattern=[1, 1, 0], n_agents=4, scenario_type="intersection_1", dt=0.1, is_use_mtv_distance=False,
+                                        rew_method="distance", is_ego_view=False, is_apply_mask=True),
+    "roundabout6_birdview_mask": dict(T=32, B=3, seed=36, mode_pattern=[1, 0, 1], n_agents=6, scenario_type="roundabout_2", dt=0.1, is_use_mtv_distance=True,
+                                      rew_method="ttc", is_ego_view=False, is_apply_mask=True, is_observe_vertices=False),
+    "cpm8_birdview_mask": dict(T=24, B=3, seed=37, mode_pattern=[1, 0, 1], n_agents=8, scenario_type="cpm_entire", dt=0.05, is_use_mtv_distance=False,
+                               rew_method="distance", is_ego_view=False, is_apply_mask=True),
     # BASELINE config 4: 32 agents on the on-ramp map.  The reference's rejection sampler cannot place them, so the
     # start is injected (Parameters.predefined_ref_path_idx / init_state); vehicles overlap from the first step on, every env is "done" at
     # every step and none is reset: non-reset steps only, as the survey prescribes for this configuration

@@ -36,6 +36,9 @@ def main():
                 spec[k] = sc[k]
         if "reference_paths_ids" in sc:
             spec["reference_paths_ids"] = [[int(x) for x in path] for path in sc["reference_paths_ids"]]
+        if "neighboring_lanelet_ids" in sc:  # constants.py: per lanelet id (1-based keys) the ids it may see (parse_osm.py:256-262 turns them into 0-based index lists)
+            nb = sc["neighboring_lanelet_ids"]
+            spec["neighboring_lanelet_ids"] = [[int(x) for x in nb[str(i + 1)]] for i in range(max(int(k) for k in nb))]
         specs[name] = spec
         if not sc["map_path"].endswith(".osm"):
             continue

@@ -103,6 +103,9 @@ class OracleEnv:
         if rc != 0:
             raise RuntimeError(f"sigmaenv_oracle_create failed: {rc}")
         self.h = h
+        if (int(getattr(cfg, "obs_flags", 0)) & capi.OBS_BIRD_VIEW) and cfg.is_apply_mask and map_table.lanelet_tables() is not None:
+            centers, neigh = map_table.lanelet_tables()  # the lanelet-relation mask of the bird-view observation (map_manager.py:41-118)
+            assert self.lib.set_lanelets(self.h, int(centers.shape[0]), int(centers.shape[1]), ptr(centers), ptr(neigh)) == 0
 
     def close(self):
         if self.h:

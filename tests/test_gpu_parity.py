@@ -766,3 +766,43 @@ def test_observation_variants_hip_vs_oracle(kw):
         dev.env.set_slab(torch.zeros((B, N * (D + 1) + 1), device="cuda"))
     dev.close()
     ora.close()
+
+
+@pytest.mark.parametrize("scen,N", [("roundabout_2", 6), ("intersection_4", 8), ("cpm_entire", 8)])
+def test_birdview_lanelet_mask_hip_vs_oracle(scen, N):
+    """Bird view + is_apply_mask: the lanelet-relation mask (current lanelet of every vehicle from the map's lanelet centre lines, neighbour table of the
+    map's parser; observation_provider_rt.py:577-665, map_manager.py:41-118) -- HIP == oracle on seeded episodes, and on the OSM maps the mask really
+    masks neighbours the distance criterion alone would show.  (The oracle is pinned to the reference on three goldens, tests/test_oracle_golden.py.)"""
+    B = 40
+    p = Parameters(n_agents=N, scenario_type=scen, is_use_mtv_distance=False, rew_method="distance", dt=0.1, is_ego_view=False, is_apply_mask=True,
+                   is_obs_noise=False, max_steps=9)
+    mp = load_map(scen)
+    cfg = make_config(p, mp, B)
+    dev, ora = _hip_env(cfg, mp), ob.OracleEnv(cfg, mp)
+    cfg_nomask = make_config(Parameters(n_agents=N, scenario_type=scen, is_use_mtv_distance=False, rew_method="distance", dt=0.1, is_ego_view=False,
+                                        is_apply_mask=False, is_obs_noise=False, max_steps=9), mp, B)
+    plain = ob.OracleEnv(cfg_nomask, mp)
+    for e in (dev, ora, plain):
+        if e is dev:
+            e.env.buffer(capi.BUF_DONE).fill_(1)
+        else:
+            e.get(capi.BUF_DONE, copy=False)[:] = 1
+        e.auto_reset(5, 0, mp.list_first[0], mp.list_count[0])
+    rng = np.random.default_rng(3)
+    masked_more = 0
+    for t in range(10):
+        act = np.stack([rng.uniform(0.0, 1.0, (B, N)), rng.uniform(-0.4, 0.4, (B, N))], axis=-1).astype(np.float32)
+        for e in (dev, ora, plain):
+            e.step(act)
+        _compare_all(dev, ora, f"{scen} bird view + mask, step {t}")
+        far = ora.get(capi.BUF_DIST_AGENTS) >= cfg.distance_mask_agents
+        near_idx = ora.get(capi.BUF_NEARING).astype(np.int64)
+        not_far = ~np.take_along_axis(far, near_idx, axis=-1)                      # neighbours the distance criterion leaves visible ...
+        blk_m = ora.get(capi.BUF_OBS)[..., -2 * 11:].reshape(B, N, 2, 11)
+        blk_p = plain.get(capi.BUF_OBS)[..., -2 * 11:].reshape(B, N, 2, 11)
+        masked_more += int((not_far & (blk_m[..., 10] == 1.0) & (blk_p[..., 10] != 1.0)).sum())  # ... that the lanelet relation masks
+        for e in (dev, ora, plain):
+            e.auto_reset(5, t + 1, mp.list_first[0], mp.list_count[0])
+    assert (masked_more > 0) == (scen != "cpm_entire"), masked_more
+    for e in (dev, ora, plain):
+        e.close()

@@ -42,11 +42,12 @@ def test_rew_flags_follow_the_reference_string_tests():
 def test_unsupported_configurations_fail_loudly():
     ok = Parameters(is_apply_mask=False)
     check_supported(ok)
-    for kw in (dict(is_apply_mask=True, is_ego_view=False), dict(is_apply_mask=False, is_partial_observation=False), dict(is_apply_mask=False, is_using_cbf_training=True, is_grouping_agents=True, is_solve_qp=False),
+    for kw in (dict(is_apply_mask=False, is_partial_observation=False), dict(is_apply_mask=False, is_using_cbf_training=True, is_grouping_agents=True, is_solve_qp=False),
                dict(is_apply_mask=False, n_points_short_term=5)):
         with pytest.raises(NotImplementedError):
             check_supported(Parameters(**kw))
     check_supported(Parameters(is_apply_mask=False, is_ego_view=False))  # bird view without the lanelet-relation mask
+    check_supported(Parameters(is_apply_mask=True, is_ego_view=False))  # ... and with it (sigmaenv_set_lanelets)
     check_supported(Parameters(is_apply_mask=False, is_obs_steering=True, is_observe_vertices=False))  # observation switches
     check_supported(Parameters(is_apply_mask=True, scenario_type="cpm_entire"))  # the reference's default (distance mask)
     check_supported(Parameters(is_apply_mask=True, scenario_type="intersection_1"))
@@ -166,7 +167,7 @@ p = Parameters(n_agents=N, scenario_type="cpm_entire", is_apply_mask=False, is_u
 b0, b1 = shard_range(TOTAL, rank, world)
 # every rank steps ONLY its env shard (no data-path collective); the full batch on rank 0 is the cross-check
 def make(lo, hi):
-    e = ob.OracleEnv(make_config(p, mp, hi - lo), mp)
+    e = ob.OracleEnv(make_config(p, mp, hi - lo, env_index_base=lo), mp)  # (is_obs_noise defaults to True: the noise draws follow the env's index in the whole batch)
     ids = np.zeros((hi - lo, N, 4), np.int32); st = np.zeros((hi - lo, N, 8), np.float32)
     for b in range(lo, hi):
         for i in range(N):

@@ -19,7 +19,8 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TRAJ_NAMES = ["cpm16_c2c", "cpm16_mtv", "intersection4_c2c", "onramp6_mtv", "cpm16_c2c_noreset", "cpm8_mtv_noreset", "cpmmixed4_c2c",
               "cpm16_cbf", "intersection4_cbf", "onramp4_cbf_clf", "cpm16_mask", "intersection4_mask", "roundabout6_mask", "onramp32_c2c",
               "cpm8_fixed_reset", "intersection4_fixed_testing", "cpm8_obs_steer_ref", "intersection4_obs_novert", "cpm8_birdview",
-              "intersection4_birdview_novert", "cpm8_boundary_points", "onramp4_boundary_points_bird"]
+              "intersection4_birdview_novert", "cpm8_boundary_points", "onramp4_boundary_points_bird", "intersection4_birdview_mask",
+              "roundabout6_birdview_mask", "cpm8_birdview_mask"]
 # The reference rounds the pseudo distance to fp16 and differentiates it numerically (pseudo_distance.py:118, cbf_qp.py:624-644): a
 # one-ulp difference in a float32 circle centre (torch's cos / sin -- a closed vector math library, within 1 ulp of the correctly rounded
 # value the oracle and the HIP path compute and NOT restatable, see include/sigma_trig_f32.h -- ) can flip
