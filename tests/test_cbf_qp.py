@@ -194,8 +194,10 @@ def check_g10(con, unom, z, B, N, Cc):
     assert (pair_err <= 1e-9).mean() >= 0.80, (pair_err <= 1e-9).mean()
     assert np.abs(unom - z["g10_unom"][:B, :N]).max() <= 1e-5  # float32 arithmetic of rl_action_to_u
     lane_err = err[:, :n_lane]
-    assert (lane_err > tr.CBF_TOL).mean() <= tr.CBF_OUTLIER_FRAC, (lane_err > tr.CBF_TOL).mean()
-    assert lane_err.max() <= 0.5  # (a flipped float16 stencil value moves a finite-difference Hessian entry by up to 0.25 / step^2 * 2^-11)
+    # observed: ONE of the 27648 lane-row entries beyond CBF_TOL, by 2.44e-6 (the same flipped float16 stencil value as the margin golden's outlier,
+    # traj_replay.CBF_KNOWN_OUTLIERS["cbf_functions"]); the bar is that count and twice that size
+    assert int((lane_err > tr.CBF_TOL).sum()) <= 1, int((lane_err > tr.CBF_TOL).sum())
+    assert lane_err.max() <= 2 * 2.44e-6, lane_err.max()
     return dict(pair_max=float(pair_err.max()), pair_exact=float((pair_err <= 1e-9).mean()), lane_outliers=float((lane_err > tr.CBF_TOL).mean()),
                 lane_max=float(lane_err.max()))
 
