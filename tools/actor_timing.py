@@ -31,6 +31,13 @@ for t in range(200):
     actor.forward(env, act, lp, None, seed=1, counter=t)
 e.record(); torch.cuda.synchronize()
 print("actor forward: %.2f us per call (%d rows)" % (s.elapsed_time(e) / 200 * 1e3, B * N))
+from sigmarl_amd import capi
+env.kernel_time_ms(capi.KERNEL_MLP32)  # arm the HIP-event brackets, then time the fp32 MLP kernel alone
+for t in range(64):
+    actor.forward(env, act, lp, None, seed=1, counter=t)
+ms, n = env.kernel_time_ms(capi.KERNEL_MLP32)
+flops = 2.0 * B * N * (32 * 256 + 2 * 256 * 256 + 256 * 4)
+print("sigmaenv_mlp32_kernel alone: %.2f us per launch over %d brackets = %.1f TFLOP/s = %.1f %% of the 157.3 TFLOP/s fp32 matrix peak" % (ms * 1e3, n, flops / (ms * 1e-3) / 1e12, flops / (ms * 1e-3) / 157.3e12 * 100))
 T = 256
 for name, kw in (("rollout (policy + step)", {}),):
     torch.cuda.synchronize(); t0 = time.perf_counter()
