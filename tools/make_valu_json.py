@@ -23,14 +23,13 @@ for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recur
             acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
 avg = {k: sum(v) / len(v) for k, v in acc.items()}
 valu = avg["SQ_INSTS_VALU"]
-lanes = min(64.0, avg["SQ_THREAD_CYCLES_VALU"] / max(1.0, avg["SQ_ACTIVE_INST_VALU"]) / 4.0 * 4.0) if "SQ_THREAD_CYCLES_VALU" in avg else 64.0
 lanes = min(64.0, avg.get("SQ_THREAD_CYCLES_VALU", 64.0 * valu) / valu)
 fp32 = avg.get("SQ_INSTS_VALU_ADD_F32", 0) + avg.get("SQ_INSTS_VALU_MUL_F32", 0) + avg.get("SQ_INSTS_VALU_TRANS_F32", 0) + 2 * avg.get("SQ_INSTS_VALU_FMA_F32", 0)
 rec = {
     "kernel": KSUB, "steps_per_launch": STEPS, "scenario": scenario, "n_agents": n_agents, "envs_per_launch": envs, "source": note,
     "n_simd": 1024, "clock_hz": 2.4e9,
     "valu_insts_per_launch": valu, "salu_insts_per_launch": avg.get("SQ_INSTS_SALU"), "lds_insts_per_launch": avg.get("SQ_INSTS_LDS"),
-    "valu_busy_cycles_per_launch": 4.0 * avg["SQ_ACTIVE_INST_VALU"],
+    "valu_busy_cycles_per_launch": 4.0 * avg["SQ_ACTIVE_INST_VALU"] if "SQ_ACTIVE_INST_VALU" in avg else None,
     "mean_active_lanes_per_valu_inst": lanes,
     "fp32_arith_insts_per_launch": avg.get("SQ_INSTS_VALU_ADD_F32", 0) + avg.get("SQ_INSTS_VALU_MUL_F32", 0) + avg.get("SQ_INSTS_VALU_FMA_F32", 0) + avg.get("SQ_INSTS_VALU_TRANS_F32", 0),
     "int32_insts_per_launch": avg.get("SQ_INSTS_VALU_INT32"), "int64_insts_per_launch": avg.get("SQ_INSTS_VALU_INT64"),
