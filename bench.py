@@ -64,6 +64,29 @@ def needs_injected_start(mp, n_agents):
     return n_agents > 2 * mp.default_n_agents and mp.scenario_type != "cpm_entire"
 
 
+def usable_cores():
+    """Host cores this process may actually run on: the affinity mask clipped by the cgroup CPU quota (the GPU box shows 256 hardware
+    threads under a 16-CPU quota; an OpenMP team sized by the former is throttled to a ninth of the 16-thread rate)."""
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            parts = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = parts[0], float(parts[1])
+            else:
+                quota, period = parts[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                cores = max(1, min(cores, int(float(quota) / period + 0.5)))
+            break
+        except Exception:
+            continue
+    return cores
+
+
 def cpu_baseline(args, n_envs, target_seconds):
     """The CPU oracle (bit-checked C restatement of the reference path, OpenMP over envs) timed on this box's host cores on a
     bounded sample of the same workload.  Checker code used as the measured baseline leg only."""
@@ -74,6 +97,13 @@ def cpu_baseline(args, n_envs, target_seconds):
     from sigmarl_amd.maps import injected_start, load_map
     from sigmarl_amd.params import Parameters, make_config
 
+    threads = int(os.environ.get("OMP_NUM_THREADS", usable_cores()))
+    try:  # size the oracle's OpenMP team before its first parallel region
+        import ctypes
+
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(threads)
+    except OSError:
+        pass
     p = Parameters(**make_params_kw(args, n_envs))
     mp = load_map(p.scenario_type)
     cfg = make_config(p, mp, n_envs)
@@ -116,12 +146,6 @@ def cpu_baseline(args, n_envs, target_seconds):
         if el >= target_seconds or k >= 4096:
             break
     env.close()
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
-    threads = int(os.environ.get("OMP_NUM_THREADS", cores))
     return {
         "value": N * n_envs * k / el, "unit": "agent-env-steps/s", "cores": threads, "kind": "port",
         "sample": f"C oracle (oracle/sigmaenv_oracle.c, OpenMP over envs), {p.scenario_type}, {N} agents x {n_envs} envs x {k} steps incl. resets{what}, {el:.1f} s",
