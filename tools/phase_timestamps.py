@@ -26,7 +26,7 @@ ts = ts[:n, :8].astype(np.int64)
 ts = ts[ts[:, 0] > 0]
 d = np.diff(ts, axis=1)
 names = ["A dynamics", "S scan", "E edges", "B1 pairs", "C reward", "D obs+slab", "R resets"]
-print("tiles", len(ts), "kernel span (cycles)", ts[:, 7].max() - ts[:, 0].min(), "start spread", ts[:, 0].max() - ts[:, 0].min())
+print("tiles", len(ts), "(shader-clock cycles per tile and phase; the clocks of different XCDs are not comparable, only differences within a tile)")
 for k, nm in enumerate(names):
     print(f"{nm:12s} mean {d[:, k].mean():9.0f}  p10 {np.percentile(d[:, k], 10):9.0f}  p90 {np.percentile(d[:, k], 90):9.0f}")
 print("tile total mean", (ts[:, 7] - ts[:, 0]).mean())
