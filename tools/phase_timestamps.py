@@ -22,6 +22,7 @@ f = env.lib.cdll.sigmaenv_debug_timestamps
 f.restype = C.c_int; f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
 ts = np.zeros((B, 16), np.uint64)
 n = f(env.h, ts.ctypes.data_as(C.c_void_p), B)
+stats = ts[:n, 8:10].astype(np.int64)
 ts = ts[:n, :8].astype(np.int64)
 ts = ts[ts[:, 0] > 0]
 d = np.diff(ts, axis=1)
@@ -30,3 +31,6 @@ print("tiles", len(ts), "(shader-clock cycles per tile and phase; the clocks of 
 for k, nm in enumerate(names):
     print(f"{nm:12s} mean {d[:, k].mean():9.0f}  p10 {np.percentile(d[:, k], 10):9.0f}  p90 {np.percentile(d[:, k], 90):9.0f}")
 print("tile total mean", (ts[:, 7] - ts[:, 0]).mean())
+if stats[:, 1].sum():  # accumulated over the launches above
+    per = stats[:, 0] / np.maximum(stats[:, 1], 1)
+    print("scan work list: items per tile-step mean %.1f p10 %.0f p50 %.0f p90 %.0f max %.0f; rounds per step %.2f" % (per.mean(), np.percentile(per, 10), np.percentile(per, 50), np.percentile(per, 90), per.max(), stats[:, 1].sum() / (20.0 * len(stats))))
