@@ -185,6 +185,9 @@ int sigmaenv_obs_dim(int32_t n_nearing);
 #define SIGMAENV_OBS_BOUNDARY_POINTS 64 /* Parameters.is_observe_distance_to_boundaries == False: instead of the two boundary distances, [own] carries the 5 points
                                         * of each boundary around its closest point (world_state_rt.py:686-724: indices closest - 2 ... closest + 2 with the loop
                                         * rule of get_short_term_reference_path; a negative index addresses the padded polyline from its end, as torch does) */
+#define SIGMAENV_OBS_OPPONENT_PAD 128  /* Parameters.is_using_opponent_modeling: the row ends with n_nearing x 2 placeholder columns for the tentative actions of
+                                        * the observed neighbours (F.pad, observation_provider_rt.py:606-611), zero before the sensor noise is added;
+                                        * sigmaenv_opponent_fill writes the actions into them */
 int sigmaenv_obs_dim_ex(int32_t n_nearing, int32_t obs_flags);
 
 /* device_id: HIP device ordinal.  hip_stream: hipStream_t to enqueue on (NULL = the device's default stream). */
@@ -249,6 +252,12 @@ int sigmaenv_get(sigmaenv_t* h, sigmaenv_buf_t which, void** dev_ptr, size_t* by
  * neighbors: HOST u64 [n_lanelets], bit j of entry i = lanelet j is in parser.neighboring_lanelets_idx[i].  n_lanelets <= 64.  Maps whose parser
  * has no neighbour table (the CPM map) do not call this: the mask by lanelets then masks nobody, as in the reference.  Copied to the device. */
 int sigmaenv_set_lanelets(sigmaenv_t* h, int32_t n_lanelets, int32_t max_points, const float* centers, const uint64_t* neighbors);
+
+/* Opponent modelling, the observation half (opponent_modeling, helper_training.py:1117-1137): actions [B,N,2] (device) are the policy's tentative
+ * actions; column pair k of the placeholder tail of agent i's row in SIGMAENV_BUF_OBS receives the action of its k-th observed neighbour
+ * (nearing_agents_indices[b, i, k], SIGMAENV_BUF_NEARING).  Needs SIGMAENV_OBS_OPPONENT_PAD; the caller runs its policy before and after, as the
+ * reference does. */
+int sigmaenv_opponent_fill(sigmaenv_t* h, const float* actions);
 
 /* Rollout slab (wire format of the learner-boundary exchange): when dev_ptr != NULL every following sigmaenv_step also writes
  * one contiguous fp32 row per env, [N*D observation | N reward | 1 done], to dev_ptr ([B, N*(D+1)+1]).  The caller rotates the

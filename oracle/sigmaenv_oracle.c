@@ -478,6 +478,21 @@ int sigmaenv_oracle_set_lanelets(oracle_t* o, int32_t n_lanelets, int32_t max_po
   return SIGMAENV_OK;
 }
 
+/* opponent_modeling (helper_training.py:1117-1137): the tentative action of the k-th observed neighbour into the k-th placeholder pair at the row's end */
+int sigmaenv_oracle_opponent_fill(oracle_t* o, const float* actions) {
+  if (!o || !actions || !(o->cfg.obs_flags & SIGMAENV_OBS_OPPONENT_PAD)) return SIGMAENV_EINVAL;
+  const int N = o->N, K = o->K, D = o->D;
+  for (size_t b = 0; b < (size_t)o->B; ++b)
+    for (int ego = 0; ego < N; ++ego)
+      for (int j = 0; j < K; ++j) {
+        const int sur = o->nearing[(b * N + ego) * K + j];
+        float* dst = o->obs + (b * N + ego) * D + (D - (K - j) * 2);
+        dst[0] = actions[(b * N + sur) * 2];
+        dst[1] = actions[(b * N + sur) * 2 + 1];
+      }
+  return SIGMAENV_OK;
+}
+
 static void agent_observation(oracle_t* o, int b, int i) {
   int N = o->N, K = o->K, D = o->D;
   const sigmaenv_config_t* c = &o->cfg;
@@ -604,6 +619,9 @@ static void agent_observation(oracle_t* o, int b, int i) {
     }
   }
 #undef OBS_POINT
+  if (F & SIGMAENV_OBS_OPPONENT_PAD) {                             /* F.pad(obs, (0, n_nearing * n_actions)), :606-611: before the noise */
+    for (int k = 0; k < 2 * K; ++k) ob[p++] = 0.0f;
+  }
   /* sensor noise, observation_provider_rt.py:613-618: obs + obs_noise_level * rand_like(obs), uniform in [0, level).  The draw is the shared
    * specification of sigmaenv_config_t.obs_noise_level: the counter-based generator keyed on the env's own counters (episodes_reset, timer.step) */
   if (c->obs_noise_level > 0.0f) {
@@ -812,7 +830,7 @@ int sigmaenv_oracle_obs_dim_ex(int32_t n_nearing, int32_t f) {   /* observation_
   int s = (f & SIGMAENV_OBS_STEERING) ? 1 : 0, r = (f & SIGMAENV_OBS_REF_OTHERS) ? 1 : 0;
   int own = 1 + s + 2 * NS + ((f & SIGMAENV_OBS_NO_DIST_CENTER) ? 0 : 1) + ((f & SIGMAENV_OBS_BOUNDARY_POINTS) ? 20 : 2) + ((f & SIGMAENV_OBS_BIRD_VIEW) ? 4 : 0);
   int other = ((f & SIGMAENV_OBS_NO_VERTICES) ? 5 : 8) + 2 + s + ((f & SIGMAENV_OBS_NO_DIST_AGENTS) ? 0 : 1) + r * 2 * NS;
-  return own + n_nearing * other;
+  return own + n_nearing * other + ((f & SIGMAENV_OBS_OPPONENT_PAD) ? 2 * n_nearing : 0);
 }
 
 static void* xcalloc(size_t n, size_t sz) { return calloc(n ? n : 1, sz); }

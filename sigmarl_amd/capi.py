@@ -107,7 +107,7 @@ def rew_flags_from_method(rew_method: str, is_solve_qp: bool = True) -> int:
 
 KERNEL_STEP, KERNEL_CBF_QP, KERNEL_CBF_MARGIN, KERNEL_MLP32, KERNEL_ACTOR_BF16 = range(5)
 KERNEL_NAMES = ("sigmaenv_step_wave_kernel", "cbf::sigmaenv_cbf_qp_kernel", "cbf::sigmaenv_cbf_kernel", "sigmaenv_mlp32_kernel", "sigmaenv_actor_kernel")
-OBS_STEERING, OBS_REF_OTHERS, OBS_NO_VERTICES, OBS_NO_DIST_AGENTS, OBS_NO_DIST_CENTER, OBS_BIRD_VIEW, OBS_BOUNDARY_POINTS = 1, 2, 4, 8, 16, 32, 64
+OBS_STEERING, OBS_REF_OTHERS, OBS_NO_VERTICES, OBS_NO_DIST_AGENTS, OBS_NO_DIST_CENTER, OBS_BIRD_VIEW, OBS_BOUNDARY_POINTS, OBS_OPPONENT_PAD = 1, 2, 4, 8, 16, 32, 64, 128
 
 
 def obs_dim(n_nearing: int, obs_flags: int = 0) -> int:
@@ -116,7 +116,7 @@ def obs_dim(n_nearing: int, obs_flags: int = 0) -> int:
     s, r = int(bool(obs_flags & OBS_STEERING)), int(bool(obs_flags & OBS_REF_OTHERS))
     own = 1 + s + 2 * N_SHORT_TERM + (0 if obs_flags & OBS_NO_DIST_CENTER else 1) + (20 if obs_flags & OBS_BOUNDARY_POINTS else 2) + (4 if obs_flags & OBS_BIRD_VIEW else 0)
     other = (5 if obs_flags & OBS_NO_VERTICES else 8) + 2 + s + (0 if obs_flags & OBS_NO_DIST_AGENTS else 1) + r * 2 * N_SHORT_TERM
-    return own + n_nearing * other
+    return own + n_nearing * other + (2 * n_nearing if obs_flags & OBS_OPPONENT_PAD else 0)
 
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
@@ -135,6 +135,7 @@ _SIGS = {
     "get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "sync": (C.c_int, [C.c_void_p]),
     "set_lanelets": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "opponent_fill": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cbf_attach": (C.c_int, [C.c_void_p, C.POINTER(CbfConfig), C.c_void_p, C.c_void_p, C.c_int32]),
     "cbf_rewards": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cbf_qp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -1373,7 +1373,7 @@ extern "C" int sigmaenv_obs_dim_ex(int32_t n_nearing, int32_t f) {  // observati
   const int s = (f & SIGMAENV_OBS_STEERING) ? 1 : 0, r = (f & SIGMAENV_OBS_REF_OTHERS) ? 1 : 0;
   const int own = 1 + s + 2 * NS + ((f & SIGMAENV_OBS_NO_DIST_CENTER) ? 0 : 1) + ((f & SIGMAENV_OBS_BOUNDARY_POINTS) ? 20 : 2) + ((f & SIGMAENV_OBS_BIRD_VIEW) ? 4 : 0);
   const int other = ((f & SIGMAENV_OBS_NO_VERTICES) ? 5 : 8) + 2 + s + ((f & SIGMAENV_OBS_NO_DIST_AGENTS) ? 0 : 1) + r * 2 * NS;
-  return own + n_nearing * other;
+  return own + n_nearing * other + ((f & SIGMAENV_OBS_OPPONENT_PAD) ? 2 * n_nearing : 0);
 }
 
 extern "C" const char* sigmaenv_last_error(const sigmaenv_t* h) { return h ? h->err.c_str() : "null handle"; }
@@ -1718,6 +1718,18 @@ extern "C" int sigmaenv_set_lanelets(sigmaenv_t* h, int32_t n_lanelets, int32_t 
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->n_lanelets = n_lanelets;
   h->lanelet_pts = max_points;
+  return SIGMAENV_OK;
+}
+
+extern "C" int sigmaenv_opponent_fill(sigmaenv_t* h, const float* actions) {
+  if (!h || !actions) return SIGMAENV_EINVAL;
+  if (!(h->cfg.obs_flags & SIGMAENV_OBS_OPPONENT_PAD) || !h->obs_var) { h->err = "opponent_fill: the configuration has no placeholder columns (SIGMAENV_OBS_OPPONENT_PAD)"; return SIGMAENV_EINVAL; }
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t n = (size_t)h->B * h->N * h->cfg.n_nearing;
+  if (n == 0) return SIGMAENV_OK;
+  hipLaunchKernelGGL(obsvar::sigmaenv_opponent_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->obs_var, h->D_pub, h->buf.nearing, actions, h->B, h->N,
+                     h->cfg.n_nearing);
+  HIPCHK(h, hipGetLastError());
   return SIGMAENV_OK;
 }
 

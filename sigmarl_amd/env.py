@@ -192,6 +192,15 @@ class SigmaEnv:
     def observe(self):
         self._chk(self.lib.observe(self.h), "observe")
 
+    def opponent_fill(self, actions: torch.Tensor):
+        """Opponent modelling (helper_training.py:1117-1137): writes the tentative ``actions`` [B, N, 2] of every agent's observed neighbours into
+        the placeholder columns at the end of its observation row (``is_using_opponent_modeling``)."""
+        if not (isinstance(actions, torch.Tensor) and actions.is_cuda and actions.dtype == torch.float32 and actions.is_contiguous()):
+            raise TypeError("actions must be a contiguous float32 CUDA tensor")
+        if tuple(actions.shape) != (self.B, self.N, 2):
+            raise ValueError(f"actions must have shape {(self.B, self.N, 2)}, got {tuple(actions.shape)}")
+        self._chk(self.lib.opponent_fill(self.h, C.c_void_p(actions.data_ptr())), "opponent_fill")
+
     # ---- QP-free CBF margin reward (sigmarl/cbf_qp.py:2534-2804) ------------------------------------------------------
     def cbf_attach(self, cbf_cfg=None, seg_left=None, seg_right=None):
         """Uploads the pseudo-distance segment tables of the env's map and the CBF constants.  Defaults: ``make_cbf_config`` of
@@ -411,6 +420,11 @@ class NumpyAdapter:
 
     def observe(self):
         self.env.observe()
+
+    def opponent_fill(self, actions):
+        a = torch.as_tensor(np.ascontiguousarray(actions, np.float32).reshape(self.B, self.N, 2)).to(self.env.device)
+        self.env.opponent_fill(a)
+        self.env.sync()
 
     def cbf_attach(self, cbf_cfg, seg_left, seg_right):
         self.env.cbf_attach(cbf_cfg, seg_left, seg_right)

@@ -97,6 +97,8 @@ def obs_flags(p: Parameters) -> int:
         f |= capi.OBS_BIRD_VIEW
     if not p.is_observe_distance_to_boundaries:
         f |= capi.OBS_BOUNDARY_POINTS
+    if getattr(p, "is_using_opponent_modeling", False):
+        f |= capi.OBS_OPPONENT_PAD
     return f
 
 
@@ -116,10 +118,11 @@ def check_supported(p: Parameters) -> None:
         bad.append(f"n_points_short_term={p.n_points_short_term} (only {capi.N_SHORT_TERM})")
     if p.is_challenging_initial_state_buffer:
         bad.append("is_challenging_initial_state_buffer=True")
-    # flags that change the observation layout or the distance definition elsewhere in the reference (opponent modelling pads the observation
-    # with predicted actions, observation_provider_rt.py:606-611; prioritised MARL adds action propagation; pseudo distances replace the boundary
-    # distances): none of them is built -- reject instead of silently running the default
-    for flag in ("is_using_opponent_modeling", "is_using_prioritized_marl", "is_using_pseudo_distance"):
+    # is_using_opponent_modeling IS built: the placeholder columns (observation_provider_rt.py:606-611, capi.OBS_OPPONENT_PAD) and the gather of the
+    # neighbours' tentative actions into them (SigmaEnv.opponent_fill; helper_training.py:1117-1137).
+    # flags that change the distance definition or the action flow elsewhere in the reference (prioritised MARL adds action propagation; pseudo
+    # distances replace the boundary distances): not built -- reject instead of silently running the default
+    for flag in ("is_using_prioritized_marl", "is_using_pseudo_distance"):
         if getattr(p, flag, False):
             bad.append(f"{flag}=True")
     if p.is_using_cbf_training or p.is_using_cbf_testing or "cbf" in p.rew_method:

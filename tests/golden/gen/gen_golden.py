@@ -691,6 +691,9 @@ TRAJS = {
                                       rew_method="ttc", is_ego_view=False, is_apply_mask=True, is_observe_vertices=False),
     "cpm8_birdview_mask": dict(T=24, B=3, seed=37, mode_pattern=[1, 0, 1], n_agents=8, scenario_type="cpm_entire", dt=0.05, is_use_mtv_distance=False,
                                rew_method="distance", is_ego_view=False, is_apply_mask=True),
+    # opponent modelling: the observation row ends with n_nearing x n_actions zero placeholders (observation_provider_rt.py:606-611)
+    "cpm8_opponent_pad": dict(T=24, B=3, seed=38, mode_pattern=[1, 0, 1], n_agents=8, scenario_type="cpm_entire", dt=0.05, is_use_mtv_distance=False,
+                              rew_method="distance", is_using_opponent_modeling=True),
     # BASELINE config 4: 32 agents on the on-ramp map.  The reference's rejection sampler cannot place them, so the
     # start is injected (Parameters.predefined_ref_path_idx / init_state); vehicles overlap from the first step on, every env is "done" at
     # every step and none is reset: non-reset steps only, as the survey prescribes for this configuration

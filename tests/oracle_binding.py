@@ -143,6 +143,10 @@ class OracleEnv:
     def observe(self):
         assert self.lib.observe(self.h) == 0
 
+    def opponent_fill(self, actions):
+        a = np.ascontiguousarray(actions, np.float32).reshape(self.B, self.N, 2)
+        assert self.lib.opponent_fill(self.h, ptr(a)) == 0
+
     def cbf_attach(self, cbf_cfg, seg_left, seg_right):
         seg_left = np.ascontiguousarray(seg_left, np.float32)
         seg_right = np.ascontiguousarray(seg_right, np.float32)

@@ -722,6 +722,8 @@ OBS_VARIANTS = [
     dict(is_observe_distance_to_boundaries=False),
     dict(is_observe_distance_to_boundaries=False, is_ego_view=False, is_obs_steering=True),
     dict(is_ego_view=False, is_obs_steering=True, is_observe_vertices=False, is_observe_ref_path_other_agents=True),
+    dict(is_using_opponent_modeling=True),
+    dict(is_using_opponent_modeling=True, is_ego_view=False, is_obs_steering=True),
 ]
 
 
@@ -764,6 +766,61 @@ def test_observation_variants_hip_vs_oracle(kw):
     _compare_all(dev, ora, "observe")
     with pytest.raises(RuntimeError):
         dev.env.set_slab(torch.zeros((B, N * (D + 1) + 1), device="cuda"))
+    dev.close()
+    ora.close()
+
+
+@pytest.mark.parametrize("noise", [False, True])
+def test_opponent_modeling_placeholders_and_fill(noise):
+    """is_using_opponent_modeling: the row ends with n_nearing x 2 placeholder columns (observation_provider_rt.py:606-611; zero, or pure sensor noise when
+    is_obs_noise -- the pad precedes the noise), and sigmaenv_opponent_fill gathers the tentative actions of the observed neighbours into them exactly as
+    opponent_modeling's loops do (helper_training.py:1117-1137, restated in numpy here).  HIP == oracle on every buffer before and after the fill."""
+    N, B, K = 8, 64, 2
+    p = Parameters(n_agents=N, scenario_type="cpm_entire", is_use_mtv_distance=False, rew_method="distance", dt=0.05, is_obs_noise=noise, max_steps=9,
+                   is_using_opponent_modeling=True)
+    mp = load_map("cpm_entire")
+    cfg = make_config(p, mp, B)
+    dev, ora = _hip_env(cfg, mp), ob.OracleEnv(cfg, mp)
+    D = capi.obs_dim(K, cfg.obs_flags)
+    assert D == 32 + 2 * K == dev.D == ora.D
+    dev.env.buffer(capi.BUF_DONE).fill_(1)
+    ora.get(capi.BUF_DONE, copy=False)[:] = 1
+    pf, pc = mp.list_first[0], mp.list_count[0]
+    dev.auto_reset(3, 0, pf, pc)
+    ora.auto_reset(3, 0, pf, pc)
+    rng = np.random.default_rng(5)
+    for t in range(6):
+        act = np.stack([rng.uniform(0, 1.0, (B, N)), rng.uniform(-0.4, 0.4, (B, N))], axis=-1).astype(np.float32)
+        dev.step(act)
+        ora.step(act)
+        _compare_all(dev, ora, f"step {t}")
+        obs = dev.get(capi.BUF_OBS)
+        tail = obs[..., D - 2 * K:]
+        if noise:
+            assert (tail >= 0).all() and (tail < cfg.obs_noise_level).all() and tail.std() > 0
+        else:
+            assert (tail == 0).all()
+        tentative = rng.normal(size=(B, N, 2)).astype(np.float32)
+        dev.opponent_fill(tentative)
+        ora.opponent_fill(tentative)
+        _compare_all(dev, ora, f"fill after step {t}")
+        near = dev.get(capi.BUF_NEARING).astype(np.int64)
+        want = obs.copy()
+        for ego in range(N):               # the reference's loops
+            for j in range(K):
+                sur = near[:, ego, j]
+                start = -(K - j) * 2
+                end = start + 2
+                want[:, ego, start:(end if end != 0 else None)] = tentative[np.arange(B), sur]
+        np.testing.assert_array_equal(dev.get(capi.BUF_OBS), want)
+        dev.auto_reset(3, t + 1, pf, pc)
+        ora.auto_reset(3, t + 1, pf, pc)
+    with pytest.raises(RuntimeError):      # no placeholder columns in the default layout
+        plain = _hip_env(make_config(Parameters(n_agents=N, scenario_type="cpm_entire", is_obs_noise=False), mp, 4), mp)
+        try:
+            plain.opponent_fill(np.zeros((4, N, 2), np.float32))
+        finally:
+            plain.close()
     dev.close()
     ora.close()
 

@@ -279,3 +279,27 @@ def test_fixtures_match_the_committed_manifest():
             a = np.ascontiguousarray(z[k])
             h.update(k.encode()); h.update(str(a.dtype).encode()); h.update(str(a.shape).encode()); h.update(a.tobytes())
         assert h.hexdigest() == man[f], f
+
+
+def test_opponent_fill_restates_the_reference_gather():
+    """sigmaenv_opponent_fill against opponent_modeling's own loops (helper_training.py:1117-1137: obs[:, ego, -(K - j) * 2 : ...] = actions[arange(B),
+    nearing[:, ego, j]]) on the oracle; the placeholder columns themselves are pinned on the reference trajectory cpm8_opponent_pad."""
+    N, B, K = 8, 5, 2
+    mp = load_map("cpm_entire")
+    cfg = make_config(Parameters(n_agents=N, scenario_type="cpm_entire", is_obs_noise=False, is_using_opponent_modeling=True), mp, B)
+    env = ob.OracleEnv(cfg, mp)
+    env.get(capi.BUF_DONE, copy=False)[:] = 1
+    env.auto_reset(1, 0, mp.list_first[0], mp.list_count[0])
+    obs = env.get(capi.BUF_OBS)
+    assert obs.shape == (B, N, 32 + 2 * K) and (obs[..., -2 * K:] == 0).all()
+    tentative = np.random.default_rng(0).normal(size=(B, N, 2)).astype(np.float32)
+    env.opponent_fill(tentative)
+    near = env.get(capi.BUF_NEARING).astype(np.int64)
+    want = obs.copy()
+    for ego in range(N):
+        for j in range(K):
+            start = -(K - j) * 2
+            end = start + 2
+            want[:, ego, start:(end if end != 0 else None)] = tentative[np.arange(B), near[:, ego, j]]
+    np.testing.assert_array_equal(env.get(capi.BUF_OBS), want)
+    env.close()
