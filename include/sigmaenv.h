@@ -65,7 +65,13 @@ extern "C" {
 #define SIGMAENV_REW_CBF 16         /* "cbf" in rew_method with Parameters.is_solve_qp == False: the step adds the three margin
                                      * channels written by sigmaenv_cbf_rewards (road_traffic.py:1112-1151) */
 
-#define SIGMAENV_N_SHORT_TERM 3     /* n_points_short_term (config.json:27) */
+/* n_points_short_term (config.json:27: 3) is a BUILD constant of the library: it sizes the observation row, the LDS tile layout and the start table, and
+ * the kernels unroll over it.  libsigmaenv.so is built for 3; `make NS=k` (1 <= k <= SIGMAENV_MAX_SHORT_TERM) builds libsigmaenv_ns<k>.so for another
+ * value from the same sources, and sigmaenv_n_short_term() reports what a loaded library was built for. */
+#ifndef SIGMAENV_N_SHORT_TERM
+#define SIGMAENV_N_SHORT_TERM 3
+#endif
+#define SIGMAENV_MAX_SHORT_TERM 8
 #define SIGMAENV_MAX_NEARING 4      /* n_nearing_agents_observed <= 4 (default 2) */
 #define SIGMAENV_MAX_AGENTS 64
 #define SIGMAENV_N_REWARD_INFO 12   /* RewardInfo fields, helper_scenario.py:101-114 */
@@ -117,7 +123,9 @@ typedef struct sigmaenv_config {
                                  * fused / separate / n-step launches and for any sharding.  Applied on the DEVICE to SIGMAENV_BUF_OBS, to the rollout
                                  * record and therefore to what sigmaenv_actor_* / sigmaenv_rollout read. */
   uint32_t obs_noise_seed_lo, obs_noise_seed_hi; /* Parameters.random_seed */
-  int32_t reserved[4];          /* must be 0 */
+  int32_t n_points_short_term;  /* Parameters.n_points_short_term; 0 = the library's build constant.  A value other than SIGMAENV_N_SHORT_TERM of the loaded
+                                 * library is refused (SIGMAENV_EINVAL): load the build for that value (libsigmaenv_ns<k>.so) */
+  int32_t reserved[3];          /* must be 0 */
 } sigmaenv_config_t;
 
 /* Unpadded reference-path table (output of the map parser, sigmarl/map_manager.py:13-40).  The library builds the padded
@@ -189,6 +197,7 @@ int sigmaenv_obs_dim(int32_t n_nearing);
                                         * the observed neighbours (F.pad, observation_provider_rt.py:606-611), zero before the sensor noise is added;
                                         * sigmaenv_opponent_fill writes the actions into them */
 int sigmaenv_obs_dim_ex(int32_t n_nearing, int32_t obs_flags);
+int sigmaenv_n_short_term(void);   /* SIGMAENV_N_SHORT_TERM of this build */
 
 /* device_id: HIP device ordinal.  hip_stream: hipStream_t to enqueue on (NULL = the device's default stream). */
 int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_t* map, int device_id, void* hip_stream,
@@ -218,6 +227,14 @@ int sigmaenv_observe(sigmaenv_t* h);
  * 1456-1473) is re-placed against all other agents, as sigmaenv_reset(full_env=0) would.  Touched envs get a fresh observation.
  * seed/counter select the counter-based random stream. */
 int sigmaenv_auto_reset(sigmaenv_t* h, uint64_t seed, uint64_t counter, int32_t path_first, int32_t path_count);
+
+/* scenario_type "cpm_mixed" (_reset_scenario_related_ref_paths, world_state_rt_sim.py:313-358): every finished env draws one of n_lists (<= 4)
+ * sub-scenarios with the given probabilities (torch.multinomial(cpm_scenario_probabilities): weights, normalised) -- sub-scenario k + 1 owns the paths
+ * [first[k], first[k] + count[k]) -- writes it to SIGMAENV_BUF_PATH[..., 1] of all its agents and places them on that list; a per-agent reset keeps the
+ * agent's sub-scenario (:325-328).  Every device-side reset entry point takes the lists instead of one path range when called with
+ * path_count = SIGMAENV_SCENARIO_LISTS (path_first is then ignored).  The draw is draw 5000 of agent 0 of the env's (seed, counter) stream. */
+#define SIGMAENV_SCENARIO_LISTS (-1)
+int sigmaenv_set_scenario_lists(sigmaenv_t* h, int32_t n_lists, const int32_t* first, const int32_t* count, const float* probabilities);
 
 /* sigmaenv_step immediately followed by sigmaenv_auto_reset, in ONE launch: after the record of the step is complete (all
  * buffers, and the rollout slab row with the terminal observation / reward / done flag), the workgroup that still holds the tile

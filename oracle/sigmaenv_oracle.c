@@ -57,6 +57,8 @@ typedef struct sigmaenv_oracle {
   float* lanelet_centers;       /* [n_lanelets][lanelet_pts][2] zero-padded centre lines of parser.lanelets_all (sigmaenv_oracle_set_lanelets) */
   uint64_t* lanelet_neigh;      /* [n_lanelets] bit j: lanelet j is in parser.neighboring_lanelets_idx[i] */
   int n_lanelets, lanelet_pts;
+  int n_lists, list_first[4], list_count[4];   /* cpm_mixed sub-scenario path lists (sigmaenv_oracle_set_scenario_lists) */
+  float list_cdf[4];
   char err[256];
 } oracle_t;
 
@@ -363,8 +365,9 @@ static float ttc_penalty(const oracle_t* o, int b, int i) {
   return risk * c->penalty_near_other_agents;                    /* :1330 */
 }
 
-/* weighting_ref_directions = linspace(1, 0.2, 3) / sum, road_traffic.py:536-543 (bit patterns read from the reference) */
-static const uint32_t W_REF_BITS[3] = {0x3F0E38E3u, 0x3EAAAAABu, 0x3DE38E39u};
+/* weighting_ref_directions = linspace(1, 0.2, n_points_short_term) / sum, road_traffic.py:536-543 (bit patterns read from the reference) */
+#include "../include/sigmaenv_ref_weights.h"
+static const uint32_t W_REF_BITS[NS] = SIGMAENV_W_REF_BITS;
 
 /* ScenarioRoadTraffic.reward for one agent, road_traffic.py:925-1253 (state updates excluded) */
 static float agent_reward(oracle_t* o, int b, int i, float* near_other_out, int* has_near, float* goal_out, float* pca_out, float* pcl_out) {
@@ -374,7 +377,7 @@ static float agent_reward(oracle_t* o, int b, int i, float* near_other_out, int*
   const float* s = o->state + bi * 8;
   const float* pp = o->prev_pos + bi * 2;
   const float* st = o->short_term + bi * NS * 2;
-  float w[3];
+  float w[NS];
   memcpy(w, W_REF_BITS, sizeof(w));
   float mvx = s[0] - pp[0], mvy = s[1] - pp[1];                 /* :972-974 */
   float acc = 0.0f;
@@ -785,6 +788,15 @@ static inline int reset_end_point(int testing, int t, int n) {
 /* Device-style auto reset of one env: rejection sampling of world_state_rt_sim.py:215-311 (non-testing mode: point in
  * [3, n/2), min centre distance 1.5*sqrt(l^2+w^2)), bounded to AUTO_RESET_MAX_TRIES per agent, then :143-213 and the tail. */
 static void auto_reset_env(oracle_t* o, int b, uint64_t seed, uint64_t counter, int path_first, int path_count) {
+  /* cpm_mixed (world_state_rt_sim.py:313-358): the env draws its sub-scenario (torch.multinomial(cpm_scenario_probabilities) there; draw 5000 of
+   * agent 0 against the cumulative distribution here) and takes that sub-scenario's path list */
+  int scenario_id = 0;
+  if (path_count == SIGMAENV_SCENARIO_LISTS) {
+    const float us = (float)(rng_u32(seed, counter, (uint32_t)(o->cfg.env_index_base + b), 0u, 5000u) >> 8) * (1.0f / 16777216.0f);
+    scenario_id = o->n_lists;
+    for (int k = o->n_lists - 2; k >= 0; --k) if (us < o->list_cdf[k]) scenario_id = k + 1;
+    path_first = o->list_first[scenario_id - 1]; path_count = o->list_count[scenario_id - 1];
+  }
   int N = o->N;
   const sigmaenv_config_t* c = &o->cfg;
   float min_d = sqrtf((float)((double)c->length * (double)c->length + (double)c->width * (double)c->width)) * 1.5f; /* road_traffic.py:679-684 */
@@ -817,7 +829,7 @@ static void auto_reset_env(oracle_t* o, int b, uint64_t seed, uint64_t counter, 
     s[2] = rot; s[3] = speed; s[4] = 0.0f; s[7] = 0.0f;
     s[5] = speed * cr_cos(0.0f + rot);                           /* :199-204 */
     s[6] = speed * cr_sin(0.0f + rot);
-    o->path[bi * 4 + 0] = path; o->path[bi * 4 + 1] = 0; o->path[bi * 4 + 2] = path - path_first; o->path[bi * 4 + 3] = pt;
+    o->path[bi * 4 + 0] = path; o->path[bi * 4 + 1] = scenario_id; o->path[bi * 4 + 2] = path - path_first; o->path[bi * 4 + 3] = pt;
   }
   for (int i = 0; i < N; ++i) reset_agent_derived(o, b, i);
   reset_env_tail(o, b, 1);
@@ -825,6 +837,7 @@ static void auto_reset_env(oracle_t* o, int b, uint64_t seed, uint64_t counter, 
 }
 
 /* ---- C-ABI twin --------------------------------------------------------------------------------------------------- */
+int sigmaenv_oracle_n_short_term(void) { return NS; }
 int sigmaenv_oracle_obs_dim(int32_t n_nearing) { return 1 + 2 * NS + 3 + n_nearing * 11; }
 int sigmaenv_oracle_obs_dim_ex(int32_t n_nearing, int32_t f) {   /* observation_provider_rt.py:803-925 */
   int s = (f & SIGMAENV_OBS_STEERING) ? 1 : 0, r = (f & SIGMAENV_OBS_REF_OTHERS) ? 1 : 0;
@@ -839,6 +852,7 @@ int sigmaenv_oracle_create(const sigmaenv_config_t* cfg, const sigmaenv_map_t* m
   (void)device_id; (void)stream;
   if (!cfg || !map || !out) return SIGMAENV_EINVAL;
   if (cfg->abi_version != SIGMAENV_ABI_VERSION) return SIGMAENV_EINVAL;
+  if (cfg->n_points_short_term != 0 && cfg->n_points_short_term != NS) return SIGMAENV_EINVAL;
   if (cfg->n_envs < 1 || cfg->n_agents < 1 || cfg->n_agents > SIGMAENV_MAX_AGENTS) return SIGMAENV_EINVAL;
   if (cfg->n_nearing < 0 || cfg->n_nearing > SIGMAENV_MAX_NEARING || cfg->n_nearing > cfg->n_agents - 1) return SIGMAENV_EINVAL;
   if (cfg->distance_type != SIGMAENV_DIST_C2C && cfg->distance_type != SIGMAENV_DIST_MTV) return SIGMAENV_EINVAL;
@@ -955,6 +969,7 @@ int sigmaenv_oracle_observe(oracle_t* o) {
  * draws 2000 + 2t / 2001 + 2t, the speed draw 3000.  Then the single-agent reset of road_traffic.py:888-923 (derived state of the
  * agent, env-wide mutual distances, all collision flags of the env cleared, prev_pos := pos) and a fresh observation. */
 static void auto_reset_agents(oracle_t* o, int b, uint64_t seed, uint64_t counter, int path_first, int path_count) {
+  const int mixed = path_count == SIGMAENV_SCENARIO_LISTS;
   int N = o->N;
   const sigmaenv_config_t* c = &o->cfg;
   float min_d = sqrtf((float)((double)c->length * (double)c->length + (double)c->width * (double)c->width)) * 1.5f;
@@ -967,6 +982,11 @@ static void auto_reset_agents(oracle_t* o, int b, uint64_t seed, uint64_t counte
     if (!((req >> i) & 1)) continue;
     size_t bi = (size_t)b * N + i;
     float* s = o->state + bi * 8;
+    if (mixed) {                                                 /* the agent keeps its env's sub-scenario (:325-328) */
+      const int sid = o->path[bi * 4 + 1];
+      const int k = (sid >= 1 && sid <= o->n_lists) ? sid - 1 : 0;
+      path_first = o->list_first[k]; path_count = o->list_count[k];
+    }
     int path = path_first, pt = 3;
     float px = 0.f, py = 0.f;
     for (int t = 0; t < AUTO_RESET_MAX_TRIES; ++t) {
@@ -999,8 +1019,27 @@ static void auto_reset_agents(oracle_t* o, int b, uint64_t seed, uint64_t counte
   for (int i = 0; i < N; ++i) agent_observation(o, b, i);
 }
 
+int sigmaenv_oracle_set_scenario_lists(oracle_t* o, int32_t n_lists, const int32_t* first, const int32_t* count, const float* probabilities) {
+  if (!o || n_lists < 1 || n_lists > 4 || !first || !count || !probabilities) return SIGMAENV_EINVAL;
+  double tot = 0.0, acc = 0.0;
+  for (int k = 0; k < n_lists; ++k) {
+    if (first[k] < 0 || count[k] < 1 || first[k] + count[k] > o->n_paths || !(probabilities[k] >= 0.0f)) return SIGMAENV_EINVAL;
+    tot += (double)probabilities[k];
+  }
+  if (!(tot > 0.0)) return SIGMAENV_EINVAL;
+  for (int k = 0; k < 4; ++k) {
+    o->list_first[k] = k < n_lists ? first[k] : 0;
+    o->list_count[k] = k < n_lists ? count[k] : 1;
+    if (k < n_lists) acc += (double)probabilities[k] / tot;
+    o->list_cdf[k] = k + 1 >= n_lists ? 1.0f : (float)acc;
+  }
+  o->n_lists = n_lists;
+  return SIGMAENV_OK;
+}
+
 int sigmaenv_oracle_auto_reset(oracle_t* o, uint64_t seed, uint64_t counter, int32_t path_first, int32_t path_count) {
-  if (!o || path_first < 0 || path_count < 1 || path_first + path_count > o->n_paths) return SIGMAENV_EINVAL;
+  if (!o) return SIGMAENV_EINVAL;
+  if (path_count == SIGMAENV_SCENARIO_LISTS ? o->n_lists < 1 : (path_first < 0 || path_count < 1 || path_first + path_count > o->n_paths)) return SIGMAENV_EINVAL;
 #pragma omp parallel for schedule(static)
   for (int b = 0; b < o->B; ++b) {
     if (o->done[b]) auto_reset_env(o, b, seed, counter, path_first, path_count);

@@ -155,7 +155,7 @@ class Actor:
         ``log_prob [T,B,N]``, ``actions [T,B,N,2]`` (CUDA float32, contiguous).  ``precision`` (default: the actor's): "fp32" = the reference's
         arithmetic (``sigmaenv_rollout_f32``), "bf16" = the fast inference variant (``sigmaenv_rollout``)."""
         if path_first is None:
-            path_first, path_count = env.map.list_first[0], env.map.list_count[0]
+            path_first, path_count = env.default_paths()
         if not hasattr(self, "_scratch") or self._scratch.shape[0] != env.B or self._scratch.device != env.device:
             self._scratch = torch.zeros((env.B, env.N, 2), dtype=torch.float32, device=env.device)
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731

@@ -18,7 +18,8 @@ ABI_VERSION = 4
 DIST_C2C, DIST_MTV = 0, 1
 REW_DISTANCE, REW_TTC, REW_EXACT_SPARSE, REW_HAS_SPARSE, REW_CBF, REW_CBF_QP = 1, 2, 4, 8, 16, 32
 CBF_MAX_CIRCLES = 4
-N_SHORT_TERM = 3
+N_SHORT_TERM = 3  # the default build; MAX_SHORT_TERM: the largest n_points_short_term a build exists for (include/sigmaenv.h)
+MAX_SHORT_TERM = 8
 MAX_NEARING = 4
 N_REWARD_INFO = 12
 
@@ -51,7 +52,7 @@ class Config(C.Structure):
         ("penalty_deviate_from_cbf_vel", C.c_float), ("penalty_deviate_from_cbf_steer", C.c_float),
         ("is_apply_mask", C.c_int32), ("distance_mask_agents", C.c_float), ("obs_flags", C.c_int32), ("reset_agent_fixed_duration", C.c_float),
         ("env_index_base", C.c_int32), ("obs_noise_level", C.c_float), ("obs_noise_seed_lo", C.c_uint32), ("obs_noise_seed_hi", C.c_uint32),
-        ("reserved", C.c_int32 * 4),
+        ("n_points_short_term", C.c_int32), ("reserved", C.c_int32 * 3),
     ]
 
 
@@ -107,15 +108,16 @@ def rew_flags_from_method(rew_method: str, is_solve_qp: bool = True) -> int:
 
 KERNEL_STEP, KERNEL_CBF_QP, KERNEL_CBF_MARGIN, KERNEL_MLP32, KERNEL_ACTOR_BF16 = range(5)
 KERNEL_NAMES = ("sigmaenv_step_wave_kernel", "cbf::sigmaenv_cbf_qp_kernel", "cbf::sigmaenv_cbf_kernel", "sigmaenv_mlp32_kernel", "sigmaenv_actor_kernel")
+SCENARIO_LISTS = -1  # path_count of a device-side reset that draws from the handle's sub-scenario lists (cpm_mixed)
 OBS_STEERING, OBS_REF_OTHERS, OBS_NO_VERTICES, OBS_NO_DIST_AGENTS, OBS_NO_DIST_CENTER, OBS_BIRD_VIEW, OBS_BOUNDARY_POINTS, OBS_OPPONENT_PAD = 1, 2, 4, 8, 16, 32, 64, 128
 
 
-def obs_dim(n_nearing: int, obs_flags: int = 0) -> int:
+def obs_dim(n_nearing: int, obs_flags: int = 0, n_short_term: int = N_SHORT_TERM) -> int:
     """``sigmaenv_obs_dim_ex``: [own] speed, (steering), short-term path, (centre-line distance), two boundary distances; per observed
     neighbour vertices (or position / rotation / length / width), velocity, (steering), (distance), (its short-term path)."""
     s, r = int(bool(obs_flags & OBS_STEERING)), int(bool(obs_flags & OBS_REF_OTHERS))
-    own = 1 + s + 2 * N_SHORT_TERM + (0 if obs_flags & OBS_NO_DIST_CENTER else 1) + (20 if obs_flags & OBS_BOUNDARY_POINTS else 2) + (4 if obs_flags & OBS_BIRD_VIEW else 0)
-    other = (5 if obs_flags & OBS_NO_VERTICES else 8) + 2 + s + (0 if obs_flags & OBS_NO_DIST_AGENTS else 1) + r * 2 * N_SHORT_TERM
+    own = 1 + s + 2 * n_short_term + (0 if obs_flags & OBS_NO_DIST_CENTER else 1) + (20 if obs_flags & OBS_BOUNDARY_POINTS else 2) + (4 if obs_flags & OBS_BIRD_VIEW else 0)
+    other = (5 if obs_flags & OBS_NO_VERTICES else 8) + 2 + s + (0 if obs_flags & OBS_NO_DIST_AGENTS else 1) + r * 2 * n_short_term
     return own + n_nearing * other + (2 * n_nearing if obs_flags & OBS_OPPONENT_PAD else 0)
 
 
@@ -125,6 +127,7 @@ DEFAULT_LIB = os.path.join(_PKG_DIR, "csrc", "libsigmaenv.so")
 _SIGS = {
     "obs_dim": (C.c_int, [C.c_int32]),
     "obs_dim_ex": (C.c_int, [C.c_int32, C.c_int32]),
+    "n_short_term": (C.c_int, []),
     "create": (C.c_int, [C.POINTER(Config), C.POINTER(Map), C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "destroy": (None, [C.c_void_p]),
     "last_error": (C.c_char_p, [C.c_void_p]),
@@ -136,6 +139,7 @@ _SIGS = {
     "sync": (C.c_int, [C.c_void_p]),
     "set_lanelets": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "opponent_fill": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "set_scenario_lists": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cbf_attach": (C.c_int, [C.c_void_p, C.POINTER(CbfConfig), C.c_void_p, C.c_void_p, C.c_int32]),
     "cbf_rewards": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cbf_qp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -187,20 +191,33 @@ class Library:
             setattr(self, name, f)
 
 
-_product_lib = None
+_product_libs = {}
 
 
-def load_library(path: str | None = None) -> Library:
-    """Loads ``libsigmaenv.so``.  torch is imported first on purpose: PyTorch-ROCm ships its own ``libamdhip64``; loading ours
-    before torch's would put two HIP runtimes in the process (observed: hipGetDeviceCount fails in the second one)."""
-    global _product_lib
+def variant_path(n_short_term: int = N_SHORT_TERM) -> str:
+    """The HIP library built for ``n_points_short_term`` (a build constant, include/sigmaenv.h): libsigmaenv.so for 3, libsigmaenv_ns<k>.so otherwise."""
+    return DEFAULT_LIB if n_short_term == N_SHORT_TERM else os.path.join(_PKG_DIR, "csrc", f"libsigmaenv_ns{int(n_short_term)}.so")
+
+
+def load_library(path: str | None = None, n_short_term: int = N_SHORT_TERM) -> Library:
+    """Loads ``libsigmaenv.so`` (or the build for another ``n_points_short_term``).  torch is imported first on purpose: PyTorch-ROCm ships its own
+    ``libamdhip64``; loading ours before torch's would put two HIP runtimes in the process (observed: hipGetDeviceCount fails in the second one)."""
     import torch  # noqa: F401  (must precede the CDLL below)
 
+    n_short_term = int(n_short_term or N_SHORT_TERM)
     if path is None:
-        if _product_lib is None:
+        lib = _product_libs.get(n_short_term)
+        if lib is None:
             # SIGMAENV_LIB: alternative build of the same HIP library (A/B experiments); still the HIP path, never a fallback
-            _product_lib = Library(os.environ.get("SIGMAENV_LIB", DEFAULT_LIB), "sigmaenv_", _PRODUCT_ONLY)
-        return _product_lib
+            p = os.environ.get("SIGMAENV_LIB", DEFAULT_LIB) if n_short_term == N_SHORT_TERM else variant_path(n_short_term)
+            if not os.path.exists(p) and n_short_term != N_SHORT_TERM:
+                raise RuntimeError(f"{p} not found: n_points_short_term={n_short_term} needs its own build of the HIP library "
+                                   f"(`make -C sigmarl_amd/csrc NS={n_short_term}`; no fallback)")
+            lib = Library(p, "sigmaenv_", _PRODUCT_ONLY)
+            if lib.n_short_term() != n_short_term:
+                raise RuntimeError(f"{p} is built for n_points_short_term={lib.n_short_term()}, not {n_short_term}")
+            _product_libs[n_short_term] = lib
+        return lib
     return Library(path, "sigmaenv_", _PRODUCT_ONLY)
 
 

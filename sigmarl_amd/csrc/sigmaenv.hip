@@ -39,8 +39,10 @@ using namespace sigmadev;
 #define PROF_TS2(g, tid, k) do { } while (0)
 #endif
 
-// weighting_ref_directions = linspace(1, 0.2, 3) / sum (road_traffic.py:536-543); bit patterns of the reference's tensor
-__device__ __constant__ uint32_t W_REF_BITS[3] = {0x3F0E38E3u, 0x3EAAAAABu, 0x3DE38E39u};
+// weighting_ref_directions = linspace(1, 0.2, n_points_short_term) / sum (road_traffic.py:536-543); bit patterns of the reference's tensor (torch CPU)
+#include "../../include/sigmaenv_ref_weights.h"
+static_assert(NS >= 1 && NS <= SIGMAENV_MAX_SHORT_TERM, "SIGMAENV_N_SHORT_TERM out of range");
+__device__ __constant__ uint32_t W_REF_BITS[NS] = SIGMAENV_W_REF_BITS;
 
 #define AUTO_RESET_MAX_TRIES 64
 
@@ -792,6 +794,22 @@ __device__ __forceinline__ void reset_candidate(const DevMap& m, const ResetDraw
   px = xy.x;
   py = xy.y;
 }
+// cpm_mixed: the path list of sub-scenario `sid` (1-based; out-of-range ids fall back to the first list), and the sub-scenario a finished env draws
+// (torch.multinomial(cpm_scenario_probabilities), world_state_rt_sim.py:330-343 -- here the counter-based generator's draw 5000 of agent 0 against the
+// cumulative distribution; specification shared with the oracle)
+__device__ __forceinline__ void scenario_list(const DevMap& m, int sid, int& first, int& count) {
+  const int k = (sid >= 1 && sid <= m.n_lists) ? sid - 1 : 0;
+  first = (int)((m.list_first16 >> (16 * k)) & 0xFFFFull);
+  count = (int)((m.list_count16 >> (16 * k)) & 0xFFFFull);
+}
+__device__ __forceinline__ int draw_scenario(const DevMap& m, uint64_t seed, uint64_t counter, int env_global) {
+  const float u = (float)(rng_u32(seed, counter, (uint32_t)env_global, 0u, 5000u) >> 8) * (1.0f / 16777216.0f);
+  int sid = m.n_lists;
+  if (m.n_lists > 3 && u < m.cdf2) sid = 3;
+  if (m.n_lists > 2 && u < m.cdf1) sid = 2;
+  if (m.n_lists > 1 && u < m.cdf0) sid = 1;
+  return sid;
+}
 // the tries a wavefront evaluates up front for a finished env: lane -> (agent, try), 64/N tries per agent
 struct ResetPrefetch {
   int path, pt;
@@ -800,7 +818,7 @@ struct ResetPrefetch {
 };
 
 template <bool WAVE = false>
-__device__ inline void auto_reset_tile(const sigmaenv_config_t& c, const DevMap& m, const DevBufs& g, const Smem& s, const Tile& t,
+__device__ __forceinline__ void auto_reset_tile(const sigmaenv_config_t& c, const DevMap& m, const DevBufs& g, const Smem& s, const Tile& t,
                                        const unsigned long long* s_mask, const int* s_full, uint64_t seed, uint64_t counter, int path_first,
                                        int path_count, int obs_mode, const ResetPrefetch& pre, int g_cap = 64, int* lds_tim = nullptr);
 #define MAX_G 64
@@ -1103,7 +1121,7 @@ __global__ void __launch_bounds__(256) sigmaenv_start_table_kernel(sigmaenv_conf
 // come from the start table (LDS and HBM), as reset + reset_init_distances_and_short_term_ref_path leave them
 // (world_state_rt_sim.py:189-213, world_state_rt.py:422-529)
 __device__ __forceinline__ void place_from_start_table(const DevMap& m, const DevBufs& g, const Smem& s, const Tile& t, int sl, int path, int pt,
-                                                       float speed, int path_first, bool full_env) {
+                                                       float speed, int path_first, bool full_env, int scenario_id = 0) {
   const float4* row4 = reinterpret_cast<const float4*>(m.start_table + ((size_t)path * m.P + pt) * START_ROW);
   float r[START_ROW];
 #pragma unroll
@@ -1142,7 +1160,7 @@ __device__ __forceinline__ void place_from_start_table(const DevMap& m, const De
   s.path[sl] = path;
   if (g.fresh) g.fresh[gi] = 1;
   g.path[gi * 4 + 0] = path;
-  if (full_env) g.path[gi * 4 + 1] = 0;  // scenario_id is kept by a per-agent reset
+  if (full_env) g.path[gi * 4 + 1] = scenario_id;  // (kept by a per-agent reset; 0 unless cpm_mixed)
   g.path[gi * 4 + 2] = path - path_first;
   g.path[gi * 4 + 3] = pt;
 }
@@ -1154,12 +1172,13 @@ __device__ __forceinline__ void place_from_start_table(const DevMap& m, const De
 // 64 tries; the reference loops without bound).  Then the deterministic reset as in sigmaenv_reset and a fresh observation.
 // All threads of the block participate.
 template <bool WAVE>
-__device__ inline void auto_reset_tile(const sigmaenv_config_t& c, const DevMap& m, const DevBufs& g, const Smem& s, const Tile& t,
+__device__ __forceinline__ void auto_reset_tile(const sigmaenv_config_t& c, const DevMap& m, const DevBufs& g, const Smem& s, const Tile& t,
                                        const unsigned long long* s_mask, const int* s_full, uint64_t seed, uint64_t counter, int path_first,
                                        int path_count, int obs_mode, const ResetPrefetch& pre, int g_cap, int* lds_tim) {
   const int N = t.N;
   const int tid = Grp<WAVE>::tid(), lane = tid & 63, wave = tid >> 6, n_waves = Grp<WAVE>::size() >> 6;
-  const ResetDraw rd{seed, counter, path_first, path_count, c.is_testing_mode, c.env_index_base};
+  const bool mixed = path_count < 0;  // SIGMAENV_SCENARIO_LISTS: every env draws from the path list of ITS sub-scenario
+  ResetDraw rd{seed, counter, path_first, path_count, c.is_testing_mode, c.env_index_base};
 #define TS2(k) PROF_TS2(g, tid, k)
   TS2(1);
   const float min_d = sqrtf((float)((double)c.length * (double)c.length + (double)c.width * (double)c.width)) * 1.5f;  // road_traffic.py:679-684
@@ -1178,6 +1197,7 @@ __device__ inline void auto_reset_tile(const sigmaenv_config_t& c, const DevMap&
         const int sl = e * N + i;
         int p2, q2;
         float x2, y2;
+        if (mixed) scenario_list(m, g.path[(t.a0 + sl) * 4 + 1], rd.path_first, rd.path_count);  // the agent keeps its env's sub-scenario (:325-328)
         reset_candidate(m, rd, b, i, lane, p2, q2, x2, y2, 2000u);
         bool ok = true;
         for (int j = 0; j < N; ++j) {
@@ -1190,13 +1210,18 @@ __device__ inline void auto_reset_tile(const sigmaenv_config_t& c, const DevMap&
         const int wl = f2 ? (__ffsll((long long)f2) - 1) : (AUTO_RESET_MAX_TRIES - 1);
         if (lane == wl) {
           float u = (float)(rng_u32(seed, counter, (uint32_t)(c.env_index_base + b), (uint32_t)i, 3000u) >> 8) * (1.0f / 16777216.0f);
-          place_from_start_table(m, g, s, t, sl, p2, q2, u * c.max_speed, path_first, false);
+          place_from_start_table(m, g, s, t, sl, p2, q2, u * c.max_speed, rd.path_first, false);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
       continue;
+    }
+    int sid = 0;
+    if (mixed) {
+      sid = draw_scenario(m, seed, counter, c.env_index_base + b);
+      scenario_list(m, sid, rd.path_first, rd.path_count);
     }
     const int ca = lane / TR, ctr = lane - ca * TR;  // this lane's (agent, try)
     const bool has_c = ca < N;
@@ -1240,7 +1265,7 @@ __device__ inline void auto_reset_tile(const sigmaenv_config_t& c, const DevMap&
     if (lane < N) {  // finalise the accepted starts, one lane per agent (world_state_rt_sim.py:189-213)
       const int i = lane, sl = e * N + i;
       float u = (float)(rng_u32(seed, counter, (uint32_t)(c.env_index_base + b), (uint32_t)i, 1000u) >> 8) * (1.0f / 16777216.0f);
-      place_from_start_table(m, g, s, t, sl, my_path, my_pt, u * c.max_speed, path_first, true);
+      place_from_start_table(m, g, s, t, sl, my_path, my_pt, u * c.max_speed, rd.path_first, true, sid);
     }
   }
   __threadfence_block();
@@ -1368,6 +1393,7 @@ static void dev_free(sigmaenv* h, void* p) {
   (void)hipFree(p);
 }
 
+extern "C" int sigmaenv_n_short_term(void) { return NS; }
 extern "C" int sigmaenv_obs_dim(int32_t n_nearing) { return 1 + 2 * NS + 3 + n_nearing * 11; }
 extern "C" int sigmaenv_obs_dim_ex(int32_t n_nearing, int32_t f) {  // observation_provider_rt.py:803-925
   const int s = (f & SIGMAENV_OBS_STEERING) ? 1 : 0, r = (f & SIGMAENV_OBS_REF_OTHERS) ? 1 : 0;
@@ -1402,7 +1428,11 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
   if (!cfg || !map || !out) return SIGMAENV_EINVAL;
   *out = nullptr;
   if (cfg->abi_version != SIGMAENV_ABI_VERSION) return SIGMAENV_EINVAL;
-  for (int k = 0; k < 4; ++k) if (cfg->reserved[k] != 0) return SIGMAENV_EINVAL;
+  for (int k = 0; k < 3; ++k) if (cfg->reserved[k] != 0) return SIGMAENV_EINVAL;
+  if (cfg->n_points_short_term != 0 && cfg->n_points_short_term != NS) {
+    fprintf(stderr, "sigmaenv_create: n_points_short_term = %d, but this library is built for %d (make -C sigmarl_amd/csrc NS=%d)\n", cfg->n_points_short_term, NS, cfg->n_points_short_term);
+    return SIGMAENV_EINVAL;
+  }
   if (cfg->env_index_base < 0 || !(cfg->obs_noise_level >= 0.0f)) return SIGMAENV_EINVAL;
   if (cfg->n_envs < 1 || cfg->n_agents < 1 || cfg->n_agents > SIGMAENV_MAX_AGENTS) return SIGMAENV_EINVAL;
   if (cfg->n_nearing < 0 || cfg->n_nearing > SIGMAENV_MAX_NEARING || cfg->n_nearing > cfg->n_agents - 1) return SIGMAENV_EINVAL;
@@ -1733,6 +1763,40 @@ extern "C" int sigmaenv_opponent_fill(sigmaenv_t* h, const float* actions) {
   return SIGMAENV_OK;
 }
 
+// the path range of a device-side reset: [path_first, path_first + path_count) of the table, or the handle's sub-scenario lists
+static bool paths_ok(const sigmaenv* h, int32_t path_first, int32_t path_count) {
+  if (path_count == SIGMAENV_SCENARIO_LISTS) return h->map.n_lists > 0;
+  return path_first >= 0 && path_count >= 1 && path_first + path_count <= h->n_paths;
+}
+
+extern "C" int sigmaenv_set_scenario_lists(sigmaenv_t* h, int32_t n_lists, const int32_t* first, const int32_t* count, const float* probabilities) {
+  if (!h) return SIGMAENV_EINVAL;
+  if (n_lists < 1 || n_lists > 4 || !first || !count || !probabilities) { h->err = "set_scenario_lists: 1..4 lists with their first path, path count and probability"; return SIGMAENV_EINVAL; }
+  double tot = 0.0;
+  for (int k = 0; k < n_lists; ++k) {
+    if (first[k] < 0 || count[k] < 1 || first[k] + count[k] > h->n_paths || first[k] + count[k] > 65535 || !(probabilities[k] >= 0.0f)) { h->err = "set_scenario_lists: list outside the path table, or a negative probability"; return SIGMAENV_EINVAL; }
+    tot += (double)probabilities[k];
+  }
+  if (!(tot > 0.0)) { h->err = "set_scenario_lists: the probabilities sum to zero"; return SIGMAENV_EINVAL; }
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  int32_t lf[4], lc[4];
+  float cdf[4];
+  double acc = 0.0;
+  for (int k = 0; k < 4; ++k) {
+    lf[k] = k < n_lists ? first[k] : 0;
+    lc[k] = k < n_lists ? count[k] : 1;
+    if (k < n_lists) acc += (double)probabilities[k] / tot;
+    cdf[k] = k + 1 >= n_lists ? 1.0f : (float)acc;  // torch.multinomial normalises the weights as well
+  }
+  DevMap& m = h->map;
+  m.list_first16 = 0ull; m.list_count16 = 0ull;
+  for (int k = 0; k < 4; ++k) { m.list_first16 |= (unsigned long long)lf[k] << (16 * k); m.list_count16 |= (unsigned long long)lc[k] << (16 * k); }
+  m.cdf0 = cdf[0]; m.cdf1 = cdf[1]; m.cdf2 = cdf[2];
+  m.n_lists = n_lists;
+  return SIGMAENV_OK;
+}
+
 static int launch_derive(sigmaenv* h, int with_obs) {
   // resets touch few envs: one env per workgroup (G = 1) keeps the untouched ones out of the way
   hipLaunchKernelGGL(sigmaenv_reset_derive_kernel, dim3(h->B), dim3(h->reset_block), h->smem_bytes, h->stream, h->cfg, h->map, h->buf, with_obs, 1);
@@ -1834,7 +1898,7 @@ static int launch_step(sigmaenv* h, const float* actions, uint64_t seed, uint64_
 extern "C" int sigmaenv_step(sigmaenv_t* h, const float* actions) { return launch_step(h, actions, 0, 0, 0, 0); }
 
 extern "C" int sigmaenv_step_autoreset(sigmaenv_t* h, const float* actions, uint64_t seed, uint64_t counter, int32_t path_first, int32_t path_count) {
-  if (!h || path_first < 0 || path_count < 1 || path_first + path_count > h->n_paths) return SIGMAENV_EINVAL;
+  if (!h || !paths_ok(h, path_first, path_count)) return SIGMAENV_EINVAL;
   return launch_step(h, actions, seed, counter, path_first, path_count);
 }
 
@@ -1847,7 +1911,7 @@ extern "C" int sigmaenv_step_autoreset(sigmaenv_t* h, const float* actions, uint
 extern "C" int sigmaenv_step_autoreset_n(sigmaenv_t* h, const float* actions, int32_t n_steps, int64_t action_stride, float* slab, int64_t slab_stride,
                                          uint64_t seed, uint64_t counter0, int32_t path_first, int32_t path_count) {
   if (!h) return SIGMAENV_EINVAL;
-  if (!actions || n_steps < 1 || action_stride < 0 || slab_stride < 0 || path_first < 0 || path_count < 1 || path_first + path_count > h->n_paths) {
+  if (!actions || n_steps < 1 || action_stride < 0 || slab_stride < 0 || !paths_ok(h, path_first, path_count)) {
     h->err = "step_autoreset_n: bad argument";
     return SIGMAENV_EINVAL;
   }
@@ -1867,7 +1931,7 @@ extern "C" int sigmaenv_step_autoreset_many(sigmaenv_t** hs, int32_t n, const fl
   if (!hs || !actions || !seeds || n < 1) return SIGMAENV_EINVAL;
   for (int k = 0; k < n; ++k) {
     sigmaenv* h = hs[k];
-    if (!h || path_first < 0 || path_count < 1 || path_first + path_count > h->n_paths) return SIGMAENV_EINVAL;
+    if (!h || !paths_ok(h, path_first, path_count)) return SIGMAENV_EINVAL;
     if (slab_ptrs) h->buf.slab = slab_ptrs[k];
     const int rc = launch_step(h, actions[k], seeds[k], counter, path_first, path_count);
     if (rc) return rc;
@@ -1884,7 +1948,7 @@ extern "C" int sigmaenv_observe(sigmaenv_t* h) {
 }
 
 extern "C" int sigmaenv_auto_reset(sigmaenv_t* h, uint64_t seed, uint64_t counter, int32_t path_first, int32_t path_count) {
-  if (!h || path_first < 0 || path_count < 1 || path_first + path_count > h->n_paths) return SIGMAENV_EINVAL;
+  if (!h || !paths_ok(h, path_first, path_count)) return SIGMAENV_EINVAL;
   HIPCHK(h, hipSetDevice(h->device));
   hipLaunchKernelGGL(sigmaenv_auto_reset_kernel, dim3(h->B), dim3(h->reset_block), h->smem_bytes, h->stream, h->cfg, h->map, h->buf, seed, counter,
                      (int)path_first, (int)path_count, 1);

@@ -41,6 +41,12 @@ struct DevMap {
   int32_t fast_div;         // every real segment has 2^-60 <= |l|^2 <= 2^60: the shared-reciprocal division is exact (div_shared)
   float rect_radius;        // upper bound of |vertex - centre| of a vehicle rectangle (half diagonal + slack)
   int32_t poly_stride;      // floats between the centre / left / right tables (they share one allocation, as do the point counts)
+  // cpm_mixed (world_state_rt_sim.py:313-358): the path lists of the sub-scenarios 1..n_lists and the cumulative distribution a finished env draws its
+  // sub-scenario from (sigmaenv_set_scenario_lists); used by the device-side resets when the launch passes path_count = SIGMAENV_SCENARIO_LISTS
+  int32_t n_lists;
+  float cdf0, cdf1, cdf2;
+  unsigned long long list_first16, list_count16;  // first path / path count of list k in bits [16 k, 16 k + 16): selected by a shift (a select between
+                                                  // members becomes a select between their ADDRESSES and puts the whole struct on the stack)
 };
 #define SIGMAENV_CHUNK 4
 // row of the start table (floats): everything reset_init_distances_and_short_term_ref_path derives for an agent standing on a
@@ -54,9 +60,9 @@ struct DevMap {
 #define START_DLEFT 18   /* 5 */
 #define START_DRIGHT 23  /* 5 */
 #define START_DBOUND 28
-#define START_SHORT 29   /* 6 */
-#define START_CP 35      /* 3 ints */
-#define START_ROW 40
+#define START_SHORT 29   /* 2 * NS */
+#define START_CP (START_SHORT + 2 * NS)             /* 3 ints */
+#define START_ROW ((START_CP + 3 + 3) & ~3)         /* whole float4s */
 
 struct DevBufs {
   float *state, *prev_pos, *vertices, *short_term, *dist_ref, *dist_left, *dist_right, *dist_bound, *dist_agents;

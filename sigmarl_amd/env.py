@@ -18,10 +18,10 @@ from .params import Parameters, make_config
 _TORCH_DTYPES = {"f32": (torch.float32, "<f4", 4), "i32": (torch.int32, "<i4", 4), "u8": (torch.uint8, "|u1", 1)}
 
 
-def _buf_layout(B, N, K, D):
+def _buf_layout(B, N, K, D, NS=capi.N_SHORT_TERM):
     return {
         capi.BUF_STATE: ("f32", (B, N, 8)), capi.BUF_PREV_POS: ("f32", (B, N, 2)), capi.BUF_VERTICES: ("f32", (B, N, 5, 2)),
-        capi.BUF_PATH: ("i32", (B, N, 4)), capi.BUF_SHORT_TERM: ("f32", (B, N, 3, 2)), capi.BUF_DIST_REF: ("f32", (B, N)),
+        capi.BUF_PATH: ("i32", (B, N, 4)), capi.BUF_SHORT_TERM: ("f32", (B, N, NS, 2)), capi.BUF_DIST_REF: ("f32", (B, N)),
         capi.BUF_DIST_LEFT: ("f32", (B, N, 5)), capi.BUF_DIST_RIGHT: ("f32", (B, N, 5)), capi.BUF_DIST_BOUND: ("f32", (B, N)),
         capi.BUF_CLOSEST: ("i32", (B, N, 3)), capi.BUF_DIST_AGENTS: ("f32", (B, N, N)), capi.BUF_COL_AGENTS: ("u8", (B, N, N)),
         capi.BUF_COL_FLAGS: ("u8", (B, N, 4)), capi.BUF_REWARD: ("f32", (B, N)), capi.BUF_REWARD_INFO: ("f32", (12, B, N)),
@@ -105,12 +105,13 @@ class SigmaEnv:
                  envs_per_group: int = 0, env_index_base: int | None = None):
         if not torch.cuda.is_available():
             raise RuntimeError("sigmarl_amd.SigmaEnv needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
-        self.lib = capi.load_library(lib_path)
         if cfg is None:
             if parameters is None:
                 raise ValueError("pass `parameters` (+ n_envs) or a ready `cfg` + `map_table`")
             map_table = map_table or load_map(parameters.scenario_type)
             cfg = make_config(parameters, map_table, int(n_envs if n_envs is not None else parameters.num_vmas_envs), make_world_scenario_type)
+        self.n_short_term = int(getattr(cfg, "n_points_short_term", 0) or capi.N_SHORT_TERM)
+        self.lib = capi.load_library(lib_path, self.n_short_term)  # (n_points_short_term is a build constant: one library per value)
         if env_index_base is not None:  # this shard's first env in the whole batch (shard.shard_range): the random draws of env e do not depend on the sharding
             cfg.env_index_base = int(env_index_base)
         if envs_per_group:  # full tiles even for a small shard (several handles stepped concurrently on different streams)
@@ -122,7 +123,7 @@ class SigmaEnv:
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.B, self.N, self.K = cfg.n_envs, cfg.n_agents, cfg.n_nearing
-        self.D = capi.obs_dim(self.K, int(getattr(self.cfg, "obs_flags", 0)))
+        self.D = capi.obs_dim(self.K, int(getattr(self.cfg, "obs_flags", 0)), self.n_short_term)
         self._map_struct = map_table.as_struct()
         with torch.cuda.device(self.device):
             self.stream = torch.cuda.current_stream(self.device)
@@ -132,7 +133,7 @@ class SigmaEnv:
             raise RuntimeError(f"sigmaenv_create failed with code {rc}")
         self.h = h
         self._views = {}
-        layout = _buf_layout(self.B, self.N, self.K, self.D)
+        layout = _buf_layout(self.B, self.N, self.K, self.D, self.n_short_term)
         for which, (kind, shape) in layout.items():
             p = C.c_void_p()
             nb = C.c_size_t()
@@ -140,12 +141,33 @@ class SigmaEnv:
             assert int(np.prod(shape)) * _TORCH_DTYPES[kind][2] == nb.value, (which, shape, nb.value)
             self._views[which] = device_view(p.value, shape, kind, self.device.index, self)
         self._reset_counter = 0
+        self._scenario_lists = False
+        if getattr(map_table, "scenario_type", "") == "cpm_mixed":  # per-env sub-scenario path lists (world_state_rt_sim.py:313-358)
+            probs = list(getattr(parameters, "cpm_scenario_probabilities", None) or [1.0, 0.0, 0.0]) if parameters is not None else [1.0, 0.0, 0.0]
+            self.set_scenario_lists(probs)
         # bird view + is_apply_mask: the lanelet-relation mask needs the map's lanelet tables (none on the CPM map: the mask is empty there)
         if (int(getattr(cfg, "obs_flags", 0)) & capi.OBS_BIRD_VIEW) and cfg.is_apply_mask and map_table.lanelet_tables() is not None:
             centers, neigh = map_table.lanelet_tables()
             self._lanelets = (centers, neigh)
             self._chk(self.lib.set_lanelets(self.h, int(centers.shape[0]), int(centers.shape[1]), centers.ctypes.data_as(C.c_void_p), neigh.ctypes.data_as(C.c_void_p)),
                       "set_lanelets")
+
+    def set_scenario_lists(self, probabilities):
+        """``cpm_mixed``: the device-side resets draw every finished env's sub-scenario (intersection / merge-in / merge-out: the map's path lists 1..3)
+        with these probabilities and keep it for the env's per-agent resets (``sigmaenv_set_scenario_lists``)."""
+        n = len(probabilities)
+        first = np.asarray([self.map.list_first[k + 1] for k in range(n)], np.int32)
+        count = np.asarray([self.map.list_count[k + 1] for k in range(n)], np.int32)
+        pr = np.asarray(probabilities, np.float32)
+        self._chk(self.lib.set_scenario_lists(self.h, n, first.ctypes.data_as(C.c_void_p), count.ctypes.data_as(C.c_void_p), pr.ctypes.data_as(C.c_void_p)),
+                  "set_scenario_lists")
+        self._scenario_lists = True
+
+    def default_paths(self):
+        """(path_first, path_count) of a device-side reset when the caller names none: the map's whole path list, or the sub-scenario lists (cpm_mixed)."""
+        if self._scenario_lists:
+            return 0, capi.SCENARIO_LISTS
+        return self.map.list_first[0], self.map.list_count[0]
 
     # ---- plumbing ---------------------------------------------------------------------------------------------
     def _chk(self, rc, what):
@@ -282,7 +304,7 @@ class SigmaEnv:
             counter = self._reset_counter
             self._reset_counter += 1
         if path_first is None:
-            path_first, path_count = self.map.list_first[0], self.map.list_count[0]
+            path_first, path_count = self.default_paths()
         self._chk(self.lib.step_autoreset(self.h, C.c_void_p(actions.data_ptr()), int(seed), int(counter), int(path_first), int(path_count)),
                   "step_autoreset")
 
@@ -303,7 +325,7 @@ class SigmaEnv:
             counter0 = self._reset_counter
             self._reset_counter += T
         if path_first is None:
-            path_first, path_count = self.map.list_first[0], self.map.list_count[0]
+            path_first, path_count = self.default_paths()
         self.step_autoreset_n_ptr(actions.data_ptr(), T, self.B * self.N * 2, slab.data_ptr() if slab is not None else 0, self.B * W, seed, counter0,
                                   path_first, path_count)
 
@@ -318,7 +340,7 @@ class SigmaEnv:
             counter = self._reset_counter
             self._reset_counter += 1
         if path_first is None:
-            path_first, path_count = self.map.list_first[0], self.map.list_count[0]
+            path_first, path_count = self.default_paths()
         self._chk(self.lib.auto_reset(self.h, int(seed), int(counter), int(path_first), int(path_count)), "auto_reset")
 
     def _warn_cbf_noise(self):
@@ -420,6 +442,9 @@ class NumpyAdapter:
 
     def observe(self):
         self.env.observe()
+
+    def set_scenario_lists(self, probabilities):
+        self.env.set_scenario_lists(probabilities)
 
     def opponent_fill(self, actions):
         a = torch.as_tensor(np.ascontiguousarray(actions, np.float32).reshape(self.B, self.N, 2)).to(self.env.device)

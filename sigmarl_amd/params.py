@@ -114,8 +114,9 @@ def check_supported(p: Parameters) -> None:
     # so current_lanelet_idx stays empty and determine_masked_agents_by_lanelets masks nobody (map_manager.py:21,102-118) on every map
     # built through the separate observation kernel (capi.OBS_*): is_obs_steering, is_observe_ref_path_other_agents, is_observe_vertices=False,
     # is_observe_distance_to_agents=False, is_observe_distance_to_center_line=False
-    if p.n_points_short_term != capi.N_SHORT_TERM:
-        bad.append(f"n_points_short_term={p.n_points_short_term} (only {capi.N_SHORT_TERM})")
+    # n_points_short_term is a build constant of the library: every value in 1 .. 8 has its own build (capi.variant_path; `make NS=k`)
+    if not (1 <= int(p.n_points_short_term) <= capi.MAX_SHORT_TERM):
+        bad.append(f"n_points_short_term={p.n_points_short_term} (1 .. {capi.MAX_SHORT_TERM})")
     if p.is_challenging_initial_state_buffer:
         bad.append("is_challenging_initial_state_buffer=True")
     # is_using_opponent_modeling IS built: the placeholder columns (observation_provider_rt.py:606-611, capi.OBS_OPPONENT_PAD) and the gather of the
@@ -199,6 +200,7 @@ def make_config(p: Parameters, map_table, n_envs: int, make_world_scenario_type:
     c.distance_mask_agents = A["length"] * 5  # road_traffic.py:663
     c.reset_agent_fixed_duration = float(p.reset_agent_fixed_duration or 0.0)  # road_traffic.py:1388-1397
     c.obs_flags = obs_flags(p)
+    c.n_points_short_term = int(p.n_points_short_term)
     # observation noise (observation_provider_rt.py:613-618) is added on the device, from the counter-based generator seeded by Parameters.random_seed
     c.obs_noise_level = float(p.obs_noise_level) if p.is_obs_noise else 0.0
     c.obs_noise_seed_lo, c.obs_noise_seed_hi = int(p.random_seed or 0) & 0xFFFFFFFF, (int(p.random_seed or 0) >> 32) & 0xFFFFFFFF

@@ -392,15 +392,16 @@ class ScenarioRoadTraffic(BaseScenario):
             return  # device_side_resets: done() already reset every finished env of this step on the GPU
         if env_index is None:
             if p.predefined_ref_path_idx is None:
-                if p.scenario_type == "cpm_mixed":
-                    for e in range(env.B):
-                        self.reset_world_at(e)
-                    return
                 if self.device_side_resets:
-                    # vectorised initial reset by the device-side sampler (same rule, counter-based RNG instead of torch's generator)
+                    # vectorised initial reset by the device-side sampler (same rule, counter-based RNG instead of torch's generator; on cpm_mixed
+                    # every env draws its sub-scenario from cpm_scenario_probabilities, SigmaEnv.set_scenario_lists)
                     env.buffer(capi.BUF_DONE).fill_(1)
                     env.auto_reset(seed=int(getattr(p, "random_seed", 0)))
                     self._obs_dirty = False
+                    return
+                if p.scenario_type == "cpm_mixed":
+                    for e in range(env.B):
+                        self.reset_world_at(e)
                     return
                 # default: the reference's own loop over the envs (road_traffic.py:832-834) drawing from torch's global generator in the
                 # reference's order, so a caller that seeds torch gets the reference's initial states
@@ -454,13 +455,9 @@ class ScenarioRoadTraffic(BaseScenario):
         """[B] bool (road_traffic.py:1368-1487) + the per-agent resets the reference performs here (:1435-1447, :1456-1473)."""
         is_done = self.env.done.to(torch.bool)
         if self.device_side_resets:
-            if self.parameters.scenario_type == "cpm_mixed":
-                # the reference draws the sub-scenario (path list) of every reset env from cpm_scenario_probabilities and keeps it for the
-                # env's per-agent resets (world_state_rt_sim.py:313-358); the device sampler takes ONE path list per launch
-                raise NotImplementedError("device_side_resets is not available for scenario_type 'cpm_mixed' (per-env path lists)")
-            lid = 0
-            self.env.auto_reset(seed=int(getattr(self.parameters, "random_seed", 0)), path_first=self.map.list_first[lid],
-                                path_count=self.map.list_count[lid])
+            # cpm_mixed: every finished env draws its sub-scenario (path list) from cpm_scenario_probabilities and keeps it for its per-agent resets
+            # (world_state_rt_sim.py:313-358): SigmaEnv.default_paths() hands the device sampler the scenario lists instead of one path range
+            self.env.auto_reset(seed=int(getattr(self.parameters, "random_seed", 0)))
             self._auto_reset_done_this_step = True
             self._obs_dirty = False  # the reset kernel refreshed the observations of every touched env
             return is_done

@@ -694,6 +694,12 @@ TRAJS = {
     # opponent modelling: the observation row ends with n_nearing x n_actions zero placeholders (observation_provider_rt.py:606-611)
     "cpm8_opponent_pad": dict(T=24, B=3, seed=38, mode_pattern=[1, 0, 1], n_agents=8, scenario_type="cpm_entire", dt=0.05, is_use_mtv_distance=False,
                               rew_method="distance", is_using_opponent_modeling=True),
+    # n_points_short_term != 3 (road_traffic.py:316, :536-543; helper_scenario.py:892-957): longer / shorter short-term reference path, observation
+    # width 4 + 2 n + 11 k, progress-reward weights linspace(1, 0.2, n) / sum
+    "cpm8_ns5": dict(T=24, B=3, seed=39, mode_pattern=[1, 0, 1], n_agents=8, scenario_type="cpm_entire", dt=0.05, is_use_mtv_distance=False,
+                     rew_method="distance", n_points_short_term=5),
+    "intersection4_ns2": dict(T=40, B=3, seed=40, mode_pattern=[1, 1, 0], n_agents=4, scenario_type="intersection_1", dt=0.1, is_use_mtv_distance=True,
+                              rew_method="ttc", n_points_short_term=2),
     # BASELINE config 4: 32 agents on the on-ramp map.  The reference's rejection sampler cannot place them, so the
     # start is injected (Parameters.predefined_ref_path_idx / init_state); vehicles overlap from the first step on, every env is "done" at
     # every step and none is reset: non-reset steps only, as the survey prescribes for this configuration

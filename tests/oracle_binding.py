@@ -20,20 +20,27 @@ ORACLE_SO = os.path.join(ORACLE_DIR, "libsigmaenv_oracle.so")
 _f32p = C.POINTER(C.c_float)
 
 
-def build_oracle(force: bool = False) -> str:
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("sigmaenv_oracle.c", "sigmaenv_cbf_oracle.inc")] + [os.path.join(ROOT, "include", f) for f in ("sigmaenv.h", "sigma_trig_f32.h")]
-    if force or not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < max(os.path.getmtime(f) for f in srcs):
-        subprocess.check_call(["make", "-C", ORACLE_DIR, "-B", "libsigmaenv_oracle.so"], stdout=subprocess.DEVNULL)
-    return ORACLE_SO
+def oracle_path(n_short_term: int = capi.N_SHORT_TERM) -> str:
+    return ORACLE_SO if n_short_term == capi.N_SHORT_TERM else os.path.join(ORACLE_DIR, f"libsigmaenv_oracle_ns{int(n_short_term)}.so")
 
 
-_lib = None
+def build_oracle(force: bool = False, n_short_term: int = capi.N_SHORT_TERM) -> str:
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("sigmaenv_oracle.c", "sigmaenv_cbf_oracle.inc")] + [os.path.join(ROOT, "include", f) for f in ("sigmaenv.h", "sigma_trig_f32.h", "sigmaenv_ref_weights.h")]
+    so = oracle_path(n_short_term)
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-B", f"NS={int(n_short_term)}", os.path.basename(so)], stdout=subprocess.DEVNULL)
+    return so
 
 
-def load_oracle() -> capi.Library:
-    global _lib
+_libs = {}
+
+
+def load_oracle(n_short_term: int = capi.N_SHORT_TERM) -> capi.Library:
+    """The oracle built for ``n_points_short_term`` (a build constant of both libraries, include/sigmaenv.h)."""
+    n_short_term = int(n_short_term or capi.N_SHORT_TERM)
+    _lib = _libs.get(n_short_term)
     if _lib is None:
-        build_oracle()
+        build_oracle(n_short_term=n_short_term)
         extra = {
             "fn_bicycle": (None, [C.POINTER(capi.Config), C.c_int, C.c_void_p, C.c_void_p]),
             "fn_vertices": (None, [C.POINTER(capi.Config), C.c_int, C.c_void_p, C.c_void_p]),
@@ -49,7 +56,9 @@ def load_oracle() -> capi.Library:
             "env0_reset_side_effect": (C.c_int, [C.c_void_p, C.c_int32]),
             "path_table": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(_f32p), C.POINTER(_f32p), C.POINTER(_f32p)]),
         }
-        _lib = capi.Library(ORACLE_SO, "sigmaenv_oracle_", extra)
+        _lib = capi.Library(oracle_path(n_short_term), "sigmaenv_oracle_", extra)
+        assert _lib.n_short_term() == n_short_term
+        _libs[n_short_term] = _lib
     return _lib
 
 
@@ -83,8 +92,10 @@ _BUF_SPEC = {
 }
 
 
-def buf_spec(which, B, N, K, D):
+def buf_spec(which, B, N, K, D, n_short_term=capi.N_SHORT_TERM):
     dt, shp = _BUF_SPEC[which]
+    if which == capi.BUF_SHORT_TERM:
+        return dt, (B, N, n_short_term, 2)
     return dt, shp(B, N, K, D)
 
 
@@ -92,12 +103,13 @@ class OracleEnv:
     """Host-memory twin of ``sigmarl_amd.env.SigmaEnv`` backed by the C oracle."""
 
     def __init__(self, cfg: capi.Config, map_table):
-        self.lib = load_oracle()
+        self.n_short_term = int(getattr(cfg, "n_points_short_term", 0) or capi.N_SHORT_TERM)
+        self.lib = load_oracle(self.n_short_term)
         self.cfg = cfg
         self.map = map_table
         self._map_struct = map_table.as_struct()
         self.B, self.N, self.K = cfg.n_envs, cfg.n_agents, cfg.n_nearing
-        self.D = capi.obs_dim(self.K, int(getattr(self.cfg, "obs_flags", 0)))
+        self.D = capi.obs_dim(self.K, int(getattr(self.cfg, "obs_flags", 0)), self.n_short_term)
         h = C.c_void_p()
         rc = self.lib.create(C.byref(cfg), C.byref(self._map_struct), 0, None, C.byref(h))
         if rc != 0:
@@ -142,6 +154,13 @@ class OracleEnv:
 
     def observe(self):
         assert self.lib.observe(self.h) == 0
+
+    def set_scenario_lists(self, probabilities):
+        n = len(probabilities)
+        first = np.asarray([self.map.list_first[k + 1] for k in range(n)], np.int32)
+        count = np.asarray([self.map.list_count[k + 1] for k in range(n)], np.int32)
+        pr = np.asarray(probabilities, np.float32)
+        assert self.lib.set_scenario_lists(self.h, n, ptr(first), ptr(count), ptr(pr)) == 0
 
     def opponent_fill(self, actions):
         a = np.ascontiguousarray(actions, np.float32).reshape(self.B, self.N, 2)
@@ -203,7 +222,7 @@ class OracleEnv:
         rc = self.lib.get(self.h, int(which), C.byref(p), C.byref(nb))
         if rc != 0:
             raise RuntimeError(f"oracle get({which}) failed: {rc}")
-        dt, shp = buf_spec(which, self.B, self.N, self.K, self.D)
+        dt, shp = buf_spec(which, self.B, self.N, self.K, self.D, self.n_short_term)
         n = int(np.prod(shp))
         assert n * np.dtype(dt).itemsize == nb.value, (which, shp, nb.value)
         if n == 0:

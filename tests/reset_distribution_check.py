@@ -64,3 +64,54 @@ def compare(tag, got, p_min=1e-4):
     # both samplers reject starts closer than reset_agent_min_distance (the bounded device sampler falls back after 64 tries: never on this map)
     assert got["min_spacing"] >= float(z[f"{tag}_min_distance"]) - 1e-6, got["min_spacing"]
     return res
+
+
+# ---- cpm_mixed: sub-scenario lists (world_state_rt_sim.py:313-358) -----------------------------------------------------------------------
+def sample_mixed(env, mp, rounds, probabilities, seed=91):
+    """Full-env resets of every env of a cpm_mixed twin through the scenario lists: histograms of the drawn sub-scenario, of the
+    (sub-scenario, list-local path) pairs, of the point position and of the speed."""
+    env.set_scenario_lists(list(probabilities))
+    counts = [mp.list_count[k] for k in (1, 2, 3)]
+    offs = np.concatenate([[0], np.cumsum(counts)])
+    scen_c, pair_c = np.zeros(3, np.int64), np.zeros(int(offs[-1]), np.int64)
+    frac_c, speed_c = np.zeros(20, np.int64), np.zeros(20, np.int64)
+    min_distance = float(np.load(FIXTURE)["mixed_min_distance"])
+    n_fallback = 0
+    for r in range(rounds):
+        if hasattr(env, "env"):
+            env.env.buffer(capi.BUF_DONE).fill_(1)
+        else:
+            env.get(capi.BUF_DONE, copy=False)[:] = 1
+        env.auto_reset(seed, r, 0, capi.SCENARIO_LISTS)
+        st, pa = env.get(capi.BUF_STATE), env.get(capi.BUF_PATH)
+        gp, sid, pid, pt = (pa[..., k].astype(np.int64) for k in range(4))
+        assert (sid == sid[:, :1]).all() and sid.min() >= 1 and sid.max() <= 3           # one sub-scenario per env (:343)
+        first = np.asarray([mp.list_first[k] for k in range(4)])[sid]
+        assert np.array_equal(gp, first + pid) and (pid >= 0).all() and (pid < np.asarray([0] + counts)[sid]).all()  # the path belongs to that list
+        half = mp.n_center[gp] // 2
+        frac = (pt - 3) / np.maximum(1, half - 3)
+        # envs the bounded sampler could not place (64 tries, then the last try stands): the reference's unbounded loop never returns on those -- its
+        # generator abandons them (gen_reset_distribution.py) -- so both sides count the feasible resets only
+        pos = st[..., 0:2].astype(np.float64)
+        d = np.sqrt(((pos[:, :, None, :] - pos[:, None, :, :]) ** 2).sum(-1)) + np.eye(env.N)[None] * 1e9
+        ok = d.min(axis=(1, 2)) >= min_distance - 1e-6
+        n_fallback += int((~ok).sum())
+        np.add.at(scen_c, sid[ok, 0] - 1, 1)
+        np.add.at(pair_c, (offs[sid[ok] - 1] + pid[ok]).ravel(), 1)
+        np.add.at(frac_c, np.minimum(19, (frac[ok].ravel() * 20).astype(np.int64)), 1)
+        np.add.at(speed_c, np.minimum(19, (st[ok][..., 3].ravel() * 20).astype(np.int64)), 1)
+    return dict(scenario_counts=scen_c, pair_counts=pair_c, point_frac_counts=frac_c, speed_counts=speed_c, n_fallback=n_fallback, n_total=rounds * env.B)
+
+
+def compare_mixed(got, p_min=1e-4):
+    z = np.load(FIXTURE)
+    assert "mixed_scenario_counts" in z.files, "tests/golden/reset_distribution.npz has no cpm_mixed histograms (gen_reset_distribution.py --mixed-only)"
+    res = {}
+    for key in ("scenario_counts", "pair_counts", "point_frac_counts", "speed_counts"):
+        p, stat = chi2_two_sample(z[f"mixed_{key}"], got[key])
+        res[key] = p
+        assert p >= p_min, (key, p, stat, z[f"mixed_{key}"], got[key])
+    # the share of infeasible placements agrees as well (reference: resets its unbounded loop never finished; here: fallbacks of the bounded one)
+    ref_stuck = float(z["mixed_n_stuck"]) / float(z["mixed_n_stuck"] + z["mixed_n_env_resets"])
+    assert abs(got["n_fallback"] / got["n_total"] - ref_stuck) < 0.01, (got["n_fallback"], got["n_total"], ref_stuck)
+    return res

@@ -463,6 +463,116 @@ def test_device_side_agent_resets_on_exit(scen):
     ora.close()
 
 
+@pytest.mark.parametrize("ns,scen,N,B,mtv,rew", [(5, "cpm_entire", 16, 96, False, "distance"), (2, "cpm_entire", 16, 64, True, "ttc"), (5, "intersection_1", 4, 64, False, "distance"),
+                                                 (2, "cpm_entire", 5, 33, False, "sparse")])
+def test_short_term_path_length_variants_hip_vs_oracle(ns, scen, N, B, mtv, rew):
+    """n_points_short_term != 3 (road_traffic.py:316, :536-543; helper_scenario.py:892-957) is a build constant: libsigmaenv_ns<k>.so from the same
+    sources.  The variant reports its constant, refuses a configuration for another one, and equals the oracle built for the same constant (pinned to the
+    reference on traj_cpm8_ns5 / traj_intersection4_ns2) through fused step + reset launches, the in-kernel step loop and the rollout record."""
+    import torch
+    from sigmarl_amd.env import SigmaEnv
+
+    p = Parameters(n_agents=N, scenario_type=scen, is_use_mtv_distance=mtv, rew_method=rew, dt=0.05, is_apply_mask=False, is_obs_noise=False, max_steps=10,
+                   n_points_short_term=ns)
+    mp = load_map(scen)
+    cfg = make_config(p, mp, B)
+    dev, ora = _hip_env(cfg, mp), ob.OracleEnv(cfg, mp)
+    K = cfg.n_nearing
+    assert dev.env.lib.path.endswith(f"libsigmaenv_ns{ns}.so") and dev.env.lib.n_short_term() == ns and ora.lib.n_short_term() == ns
+    assert dev.D == ora.D == 4 + 2 * ns + 11 * K and dev.get(capi.BUF_SHORT_TERM).shape == (B, N, ns, 2)
+    with pytest.raises(RuntimeError):  # the default build refuses this configuration instead of running with 3 points
+        SigmaEnv(cfg=cfg, map_table=mp, device="cuda:0", lib_path=capi.DEFAULT_LIB)
+    pf, pc = mp.list_first[0], mp.list_count[0]
+    dev.env.buffer(capi.BUF_DONE).fill_(1)
+    ora.get(capi.BUF_DONE, copy=False)[:] = 1
+    dev.auto_reset(4, 0, pf, pc)
+    ora.auto_reset(4, 0, pf, pc)
+    _compare_all(dev, ora, "initial reset")
+    rng = np.random.default_rng(ns)
+    T = 16
+    acts = np.stack([rng.uniform(0.0, 1.2, (T, B, N)), rng.uniform(-0.5, 0.5, (T, B, N))], axis=-1).astype(np.float32)
+    W = N * (dev.D + 1) + 1
+    slab = torch.zeros((B, W), device="cuda")
+    dev.env.set_slab(slab)
+    for t in range(T // 2):
+        dev.step_autoreset(acts[t], 4, t + 1, pf, pc)
+        ora.step(acts[t])
+        rec_obs, rec_rew, rec_done = ora.get(capi.BUF_OBS).copy(), ora.get(capi.BUF_REWARD).copy(), ora.get(capi.BUF_DONE).copy()
+        ora.auto_reset(4, t + 1, pf, pc)
+        _compare_all(dev, ora, f"ns={ns} step {t}")
+        row = slab.cpu().numpy()
+        assert np.abs(row[:, :N * dev.D].reshape(B, N, dev.D) - rec_obs).max() <= FTOL
+        np.testing.assert_array_equal(row[:, N * dev.D:N * dev.D + N], rec_rew)
+        np.testing.assert_array_equal(row[:, -1] != 0, rec_done != 0)
+    dev.env.set_slab(None)
+    a = torch.as_tensor(acts[T // 2:]).to("cuda").contiguous()
+    dev.env.step_autoreset_n(a, seed=4, counter0=50, path_first=pf, path_count=pc)
+    dev.env.sync()
+    for t in range(T // 2, T):
+        ora.step(acts[t])
+        ora.auto_reset(4, 50 + t - T // 2, pf, pc)
+    _compare_all(dev, ora, f"ns={ns} after the step loop")
+    dev.close()
+    ora.close()
+
+
+@pytest.mark.parametrize("testing", [False, True])
+def test_mixed_scenario_lists_device_resets(testing):
+    """cpm_mixed with device-side resets (world_state_rt_sim.py:313-358): every finished env draws its sub-scenario from cpm_scenario_probabilities
+    and its agents' paths from that list; per-agent resets (exits; collisions in testing mode) keep the env's sub-scenario.  HIP == oracle on every
+    buffer through fused step + reset launches (one launch per step, and the in-kernel step loop), and the HIP sampler's draws match the
+    reference's (chi-square, tests/golden/reset_distribution.npz mixed_*)."""
+    import torch
+    import reset_distribution_check as rdc
+
+    N, B, T = 4, 512, 24
+    probs = [0.5, 0.3, 0.2]
+    p = Parameters(n_agents=N, scenario_type="cpm_mixed", is_use_mtv_distance=False, rew_method="distance", dt=0.1, is_apply_mask=False, is_obs_noise=False,
+                   max_steps=12, is_testing_mode=testing, cpm_scenario_probabilities=probs)
+    mp = load_map("cpm_mixed")
+    cfg = make_config(p, mp, B)
+    dev, ora = _hip_env(cfg, mp), ob.OracleEnv(cfg, mp)
+    dev.set_scenario_lists(probs)
+    ora.set_scenario_lists(probs)
+    dev.env.buffer(capi.BUF_DONE).fill_(1)
+    ora.get(capi.BUF_DONE, copy=False)[:] = 1
+    dev.auto_reset(9, 0, 0, capi.SCENARIO_LISTS)
+    ora.auto_reset(9, 0, 0, capi.SCENARIO_LISTS)
+    _compare_all(dev, ora, "initial reset")
+    rng = np.random.default_rng(12)
+    acts = np.stack([rng.uniform(0.3, 1.2, (T, B, N)), rng.uniform(-0.4, 0.4, (T, B, N))], axis=-1).astype(np.float32)
+    full = agent = 0
+    for t in range(T // 2):
+        dev.step_autoreset(acts[t], 9, t + 1, 0, capi.SCENARIO_LISTS)
+        sid_before = ora.get(capi.BUF_PATH)[..., 1].copy()
+        ora.step(acts[t])
+        done = ora.get(capi.BUF_DONE).astype(bool)
+        req = ora.get(capi.BUF_COL_FLAGS)[..., 3].astype(bool) & ~done[:, None]
+        ora.auto_reset(9, t + 1, 0, capi.SCENARIO_LISTS)
+        _compare_all(dev, ora, f"step {t}")
+        pa = ora.get(capi.BUF_PATH)
+        assert (pa[..., 1] == pa[:, :1, 1]).all() and pa[..., 1].min() >= 1
+        assert np.array_equal(pa[..., 1][~done], sid_before[~done])                # only a finished env redraws its sub-scenario
+        full += int(done.sum())
+        agent += int(req.sum())
+    assert full > 0 and agent > 0
+    # the in-kernel step loop takes the lists as well
+    a = torch.as_tensor(acts[T // 2:]).to(dev.env.device).contiguous()
+    dev.env.step_autoreset_n(a, seed=9, counter0=100, path_first=0, path_count=capi.SCENARIO_LISTS)
+    dev.env.sync()
+    for t in range(T // 2, T):
+        ora.step(acts[t])
+        ora.auto_reset(9, 100 + t - T // 2, 0, capi.SCENARIO_LISTS)
+    _compare_all(dev, ora, "after the step loop")
+    if not testing:
+        p2 = Parameters(n_agents=2, scenario_type="cpm_mixed", is_apply_mask=False, is_obs_noise=False, cpm_scenario_probabilities=probs)  # (the fixture's agent count)
+        dev2 = _hip_env(make_config(p2, mp, 2048), mp)
+        rdc.compare_mixed(rdc.sample_mixed(dev2, mp, rounds=2, probabilities=probs))
+        dev2.close()
+    dev.close()
+    ora.close()
+
+
 @pytest.mark.parametrize("scen,N,B,mtv,rew,dt,testing", [
     ("cpm_entire", 16, 200, False, "distance", 0.05, False),       # whole tiles of 4 envs with 0..4 finished envs each
     ("cpm_entire", 5, 33, True, "ttc_sparse", 0.1, False),         # ragged tile

@@ -43,9 +43,11 @@ def test_unsupported_configurations_fail_loudly():
     ok = Parameters(is_apply_mask=False)
     check_supported(ok)
     for kw in (dict(is_apply_mask=False, is_partial_observation=False), dict(is_apply_mask=False, is_using_cbf_training=True, is_grouping_agents=True, is_solve_qp=False),
-               dict(is_apply_mask=False, n_points_short_term=5)):
+               dict(is_apply_mask=False, n_points_short_term=9), dict(is_apply_mask=False, n_points_short_term=0)):
         with pytest.raises(NotImplementedError):
             check_supported(Parameters(**kw))
+    check_supported(Parameters(is_apply_mask=False, n_points_short_term=5))  # a build constant: its own library build (capi.variant_path)
+    check_supported(Parameters(is_apply_mask=False, is_using_opponent_modeling=True))  # placeholder columns + sigmaenv_opponent_fill
     check_supported(Parameters(is_apply_mask=False, is_ego_view=False))  # bird view without the lanelet-relation mask
     check_supported(Parameters(is_apply_mask=True, is_ego_view=False))  # ... and with it (sigmaenv_set_lanelets)
     check_supported(Parameters(is_apply_mask=False, is_obs_steering=True, is_observe_vertices=False))  # observation switches
@@ -307,6 +309,45 @@ def test_device_sampler_specification_matches_the_reference_distribution(tag, te
     got = rdc.sample_histograms(env, mp, rounds=4)
     env.close()
     rdc.compare(tag, got)
+
+
+def test_mixed_scenario_lists_match_the_reference_distribution():
+    """cpm_mixed (world_state_rt_sim.py:313-358): the device-side reset specification (oracle side) draws every env's sub-scenario with
+    cpm_scenario_probabilities and its agents' paths from that sub-scenario's list -- chi-square against the reference's own draws
+    (tests/golden/reset_distribution.npz, mixed_*) and against the stated probabilities; a per-agent reset keeps the env's sub-scenario."""
+    import oracle_binding as ob
+    import reset_distribution_check as rdc
+    from sigmarl_amd import capi
+    from sigmarl_amd.maps import load_map
+    from sigmarl_amd.params import Parameters, make_config
+
+    mp = load_map("cpm_mixed")
+    z = np.load(rdc.FIXTURE)
+    probs = [float(v) for v in z["mixed_probabilities"]]
+    assert [int(v) for v in z["mixed_list_counts"]] == [mp.list_count[k] for k in (1, 2, 3)]
+    p = Parameters(n_agents=2, scenario_type="cpm_mixed", is_apply_mask=False, is_obs_noise=False, cpm_scenario_probabilities=probs)
+    env = ob.OracleEnv(make_config(p, mp, 1024), mp)
+    got = rdc.sample_mixed(env, mp, rounds=4, probabilities=probs)
+    rdc.compare_mixed(got)
+    # per-agent requests in unfinished envs: the re-placed agent stays on its env's list (:325-328)
+    env.get(capi.BUF_DONE, copy=False)[:] = 0
+    fl = env.get(capi.BUF_COL_FLAGS, copy=False)
+    fl[..., 3] = 0
+    fl[::2, 1, 3] = 1
+    before = env.get(capi.BUF_PATH).copy()
+    env.auto_reset(5, 100, 0, capi.SCENARIO_LISTS)
+    after = env.get(capi.BUF_PATH)
+    assert np.array_equal(after[..., 1], before[..., 1])                           # sub-scenario ids untouched
+    first = np.asarray([mp.list_first[k] for k in range(4)])[after[..., 1]]
+    count = np.asarray([mp.list_count[k] for k in range(4)])[after[..., 1]]
+    assert ((after[..., 0] >= first) & (after[..., 0] < first + count)).all() and np.array_equal(after[..., 2], after[..., 0] - first)
+    moved = (after[..., [0, 3]] != before[..., [0, 3]]).any(-1)
+    assert moved[::2, 1].mean() > 0.9 and not moved[1::2].any() and not moved[::2, 0].any()
+    # without lists the scenario-list mode is refused
+    plain = ob.OracleEnv(make_config(Parameters(n_agents=4, scenario_type="cpm_entire", is_obs_noise=False), load_map("cpm_entire"), 4), load_map("cpm_entire"))
+    assert plain.lib.auto_reset(plain.h, 0, 0, 0, capi.SCENARIO_LISTS) != 0
+    plain.close()
+    env.close()
 
 
 def test_observation_noise_specification_matches_the_reference_scaling():
