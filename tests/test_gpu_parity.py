@@ -555,7 +555,7 @@ def test_mixed_scenario_lists_device_resets(testing):
         assert np.array_equal(pa[..., 1][~done], sid_before[~done])                # only a finished env redraws its sub-scenario
         full += int(done.sum())
         agent += int(req.sum())
-    assert full > 0 and agent > 0
+    assert full > 0 and (agent > 0 or not testing)  # (per-agent requests within 12 steps: the colliders of testing mode)
     # the in-kernel step loop takes the lists as well
     a = torch.as_tensor(acts[T // 2:]).to(dev.env.device).contiguous()
     dev.env.step_autoreset_n(a, seed=9, counter0=100, path_first=0, path_count=capi.SCENARIO_LISTS)
