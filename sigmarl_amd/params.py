@@ -121,11 +121,9 @@ def check_supported(p: Parameters) -> None:
         bad.append("is_challenging_initial_state_buffer=True")
     # is_using_opponent_modeling IS built: the placeholder columns (observation_provider_rt.py:606-611, capi.OBS_OPPONENT_PAD) and the gather of the
     # neighbours' tentative actions into them (SigmaEnv.opponent_fill; helper_training.py:1117-1137).
-    # flags that change the distance definition or the action flow elsewhere in the reference (prioritised MARL adds action propagation; pseudo
-    # distances replace the boundary distances): not built -- reject instead of silently running the default
-    for flag in ("is_using_prioritized_marl", "is_using_pseudo_distance"):
-        if getattr(p, flag, False):
-            bad.append(f"{flag}=True")
+    # is_using_prioritized_marl: the environment's share is two extra info() entries (road_traffic.py:1513-1520, :1616-1625), built in scenario.info();
+    # priority assignment and action propagation are the trainer's.  is_using_pseudo_distance is read nowhere in the reference outside Parameters
+    # (helper_common.py:117, :229): accepted, no effect -- as there.
     if p.is_using_cbf_training or p.is_using_cbf_testing or "cbf" in p.rew_method:
         # built: the centralized QP (is_solve_qp=True), the grouped QPs (is_grouping_agents) and the QP-free margin reward
         # (sigmarl/cbf_qp.py:2534-2560).  The reference's grouped update only runs with is_solve_qp=True (its coefficient builders receive

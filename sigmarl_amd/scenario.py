@@ -278,6 +278,8 @@ class ScenarioRoadTraffic(BaseScenario):
                 f"map table of {p.scenario_type!r} was parsed with lane_width={self.map.parser_lane_width}; Parameters.lane_width={p.lane_width} needs the map compiler (SURVEY.md 8f-2)")
         cfg = make_config(p, self.map, batch_dim, make_world_scenario_type)
         self.env = SigmaEnv(cfg=cfg, map_table=self.map, device=device)
+        if p.scenario_type == "cpm_mixed":  # the sub-scenario distribution of the device-side resets (world_state_rt_sim.py:330-343)
+            self.env.set_scenario_lists(list(p.cpm_scenario_probabilities))
         self.n_agents = p.n_agents
         self.agent_width, self.agent_length = AGENTS["width"], AGENTS["length"]
         self.max_speed = AGENTS["max_speed"]
@@ -470,7 +472,7 @@ class ScenarioRoadTraffic(BaseScenario):
         return is_done
 
     def info(self, agent) -> Dict[str, torch.Tensor]:
-        """The 27 + 12 entries of road_traffic.py:1489-1635."""
+        """The 27 + 12 entries of road_traffic.py:1489-1635 (+ 2 with is_using_prioritized_marl)."""
         i = self._index(agent)
         ws, nz, B = self.world_state, self.normalizers, self.env.B
         st = agent.state
@@ -500,6 +502,12 @@ class ScenarioRoadTraffic(BaseScenario):
             "applied_action_vel": ws.applied_action_vel[:, i], "applied_action_steer": ws.applied_action_steer[:, i],
             "nominal_action_vel": ws.nominal_action_vel[:, i], "nominal_action_steer": ws.nominal_action_steer[:, i],
         }
+        if getattr(self.parameters, "is_using_prioritized_marl", False):
+            # the two extra entries of prioritised MARL (road_traffic.py:1513-1520, :1616-1625): the observation padded with the placeholders of the
+            # neighbours' actions for the base policy, and the observation itself for the priority-assignment policy
+            obs = self.stored_observations[i] if self.stored_observations[i] is not None else self.env.obs[:, i]
+            info["base_observation"] = torch.nn.functional.pad(obs.clone(), (0, self.parameters.n_nearing_agents_observed * 2))
+            info["priority_observation"] = obs.clone()
         for name in capi.REWARD_INFO_FIELDS:
             info[name] = getattr(self.reward_info, name)[:, i]
         return info

@@ -259,6 +259,76 @@ def test_device_side_resets_through_the_surface():
     sc.env.close()
 
 
+def test_prioritized_marl_info_and_opponent_placeholders_through_the_surface():
+    """is_using_prioritized_marl: info() carries base_observation (the observation padded with the 2 K placeholder columns) and priority_observation
+    (road_traffic.py:1513-1520, :1616-1625).  is_using_opponent_modeling: observation() itself ends with the placeholders (observation_provider_rt.py:606-611)
+    and env.opponent_fill is the gather opponent_modeling performs between its two policy calls (helper_training.py:1117-1137).  is_using_pseudo_distance
+    is accepted and changes nothing (it is read nowhere in the reference)."""
+    import torch
+    from sigmarl_amd.scenario import make_scenario
+
+    B, N, K = 16, 8, 2
+    p = Parameters(n_agents=N, scenario_type="cpm_entire", is_use_mtv_distance=False, is_apply_mask=False, is_obs_noise=False, num_vmas_envs=B,
+                   is_using_prioritized_marl=True, is_using_pseudo_distance=True)
+    sc = make_scenario(p)
+    world = sc.env_make_world(B, "cuda:0", n_agents=N)
+    sc.env_reset_world_at(None)
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    act = torch.rand((B, N, 2), generator=gen, device="cuda") - torch.tensor([0.0, 0.5], device="cuda")
+    obs, rew, done, info = _vmas_step(sc, act)
+    assert list(info[2].keys())[:29] == INFO_KEYS[:27] + ["base_observation", "priority_observation"] and len(info[2]) == 41
+    assert info[2]["base_observation"].shape == (B, 32 + 2 * K) and torch.equal(info[2]["base_observation"][:, :32], obs[2])
+    assert (info[2]["base_observation"][:, 32:] == 0).all() and torch.equal(info[2]["priority_observation"], obs[2])
+    sc.env.close()
+
+    p2 = Parameters(n_agents=N, scenario_type="cpm_entire", is_use_mtv_distance=False, is_apply_mask=False, is_obs_noise=False, num_vmas_envs=B,
+                    is_using_opponent_modeling=True)
+    sc2 = make_scenario(p2)
+    world2 = sc2.env_make_world(B, "cuda:0", n_agents=N)
+    sc2.env_reset_world_at(None)
+    obs, rew, done, info = _vmas_step(sc2, act)
+    o = torch.stack(obs, 1)
+    assert o.shape == (B, N, 32 + 2 * K) and (o[..., 32:] == 0).all()
+    tentative = torch.randn((B, N, 2), device="cuda")
+    sc2.env.opponent_fill(tentative)
+    filled = torch.stack([sc2.observation(a) for a in world2.agents], 1)
+    near = sc2.env.buffer(capi.BUF_NEARING).long()
+    want = torch.gather(tentative[:, None].expand(B, N, N, 2), 2, near[..., None].expand(B, N, K, 2)).reshape(B, N, 2 * K)
+    assert torch.equal(filled[..., 32:], want) and torch.equal(filled[..., :32], o[..., :32])
+    sc2.env.close()
+
+
+def test_mixed_map_device_side_resets_through_the_surface():
+    """cpm_mixed with device_side_resets=True (raised NotImplementedError until round 3): the initial reset and done() draw every env's sub-scenario
+    from cpm_scenario_probabilities on the GPU; the agents of an env share it and their paths belong to its list."""
+    import torch
+    from sigmarl_amd.scenario import make_scenario
+
+    B, N = 128, 2
+    p = Parameters(n_agents=N, scenario_type="cpm_mixed", is_use_mtv_distance=False, is_apply_mask=False, is_obs_noise=False, dt=0.1, max_steps=6,
+                   cpm_scenario_probabilities=[0.4, 0.3, 0.3])
+    sc = make_scenario(p)
+    sc.device_side_resets = True
+    world = sc.env_make_world(B, "cuda:0", n_agents=N)
+    sc.env_reset_world_at(None)
+    mp = sc.map
+    seen = set()
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    for _ in range(10):
+        act = torch.rand((B, N, 2), generator=gen, device="cuda") - torch.tensor([0.0, 0.5], device="cuda")
+        obs, rew, done, info = _vmas_step(sc, act)
+        pa = sc.env.buffer(capi.BUF_PATH).cpu().numpy()
+        sid = pa[..., 1]
+        assert (sid == sid[:, :1]).all() and sid.min() >= 1 and sid.max() <= 3
+        first = np.asarray([mp.list_first[k] for k in range(4)])[sid]
+        count = np.asarray([mp.list_count[k] for k in range(4)])[sid]
+        assert ((pa[..., 0] >= first) & (pa[..., 0] < first + count)).all()
+        seen |= set(np.unique(sid).tolist())
+        assert not sc.env.done.any()
+    assert seen == {1, 2, 3}
+    sc.env.close()
+
+
 @pytest.mark.parametrize("name,kw", [("cpm16", dict(n_agents=16, scenario_type="cpm_entire")), ("intersection4", dict(n_agents=4, scenario_type="intersection_1")),
                                      ("cpm8_testing", dict(n_agents=8, scenario_type="cpm_entire", is_testing_mode=True))])
 def test_seeded_initial_reset_reproduces_the_reference(name, kw):
