@@ -92,6 +92,17 @@ def test_hip_library_exports_the_declared_abi():
     hdr = open(os.path.join(ROOT, "include", "sigmaenv.h")).read()
     for sym in capi.exported_symbols():
         assert sym + "(" in hdr, f"{sym} missing from include/sigmaenv.h"
+    import re
+
+    declared = set(re.findall(r"^(?:int|void|const char\*)\s+(sigmaenv_\w+)\(", hdr, flags=re.M))
+    assert declared == set(capi.exported_symbols()), declared ^ set(capi.exported_symbols())  # and the other way round: nothing declared is unbound
+    for ns in (2, 5):  # the n_points_short_term build variants export the same ABI and report their constant
+        vp = capi.variant_path(ns)
+        if os.path.exists(vp):
+            v = ctypes.CDLL(vp)
+            assert all(hasattr(v, sym) for sym in capi.exported_symbols())
+            v.sigmaenv_n_short_term.restype = ctypes.c_int
+            assert v.sigmaenv_n_short_term() == ns
     lib.sigmaenv_obs_dim.restype = ctypes.c_int
     assert lib.sigmaenv_obs_dim(2) == 32
     # create() without a device must fail cleanly, not crash
