@@ -834,6 +834,8 @@ OBS_VARIANTS = [
     dict(is_ego_view=False, is_obs_steering=True, is_observe_vertices=False, is_observe_ref_path_other_agents=True),
     dict(is_using_opponent_modeling=True),
     dict(is_using_opponent_modeling=True, is_ego_view=False, is_obs_steering=True),
+    dict(n_points_short_term=5, is_observe_ref_path_other_agents=True, is_obs_steering=True),        # the switches in another build variant (libsigmaenv_ns5.so)
+    dict(n_points_short_term=2, is_ego_view=False, is_observe_distance_to_boundaries=False, is_using_opponent_modeling=True),
 ]
 
 
@@ -853,7 +855,7 @@ def test_observation_variants_hip_vs_oracle(kw):
     cfg = make_config(p, mp, B)
     assert cfg.obs_flags != 0
     dev, ora = _hip_env(cfg, mp), ob.OracleEnv(cfg, mp)
-    D = capi.obs_dim(2, cfg.obs_flags)
+    D = capi.obs_dim(2, cfg.obs_flags, p.n_points_short_term)
     assert dev.D == D == ora.D and dev.env.lib.obs_dim_ex(2, cfg.obs_flags) == D and D != 32
     dev.env.buffer(capi.BUF_DONE).fill_(1)
     ora.get(capi.BUF_DONE, copy=False)[:] = 1
