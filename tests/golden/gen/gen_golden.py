@@ -700,6 +700,18 @@ TRAJS = {
                      rew_method="distance", n_points_short_term=5),
     "intersection4_ns2": dict(T=40, B=3, seed=40, mode_pattern=[1, 1, 0], n_agents=4, scenario_type="intersection_1", dt=0.1, is_use_mtv_distance=True,
                               rew_method="ttc", n_points_short_term=2),
+    # the remaining map families (the oracle is otherwise pinned on cpm / intersection_1 / on_ramp_1 / roundabout_2 trajectories): interchange, the larger
+    # intersections, the small roundabout, the multi-lane on-ramp -- training and testing mode, every distance / reward combination once more
+    "interchange6_mtv": dict(T=48, B=3, seed=41, mode_pattern=[1, 1, 0], n_agents=6, scenario_type="interchange_2", dt=0.1, is_use_mtv_distance=True,
+                             rew_method="ttc"),
+    "intersection5_6_testing": dict(T=48, B=3, seed=42, mode_pattern=[1, 0, 1], n_agents=6, scenario_type="intersection_5", dt=0.1, is_use_mtv_distance=False,
+                                    rew_method="distance_sparse", is_testing_mode=True),
+    "roundabout1_5_c2c": dict(T=48, B=3, seed=43, mode_pattern=[1, 1, 0], n_agents=5, scenario_type="roundabout_1", dt=0.1, is_use_mtv_distance=False,
+                              rew_method="ttc_sparse"),
+    "onramp2_6_mask": dict(T=48, B=3, seed=44, mode_pattern=[1, 0, 1], n_agents=6, scenario_type="on_ramp_2_multilane", dt=0.1, is_use_mtv_distance=True,
+                           rew_method="distance", is_apply_mask=True),
+    "interchange1_8_birdview": dict(T=32, B=3, seed=45, mode_pattern=[1, 1, 0], n_agents=8, scenario_type="interchange_1", dt=0.1, is_use_mtv_distance=False,
+                                    rew_method="distance", is_ego_view=False, is_apply_mask=True, is_obs_steering=True),
     # BASELINE config 4: 32 agents on the on-ramp map.  The reference's rejection sampler cannot place them, so the
     # start is injected (Parameters.predefined_ref_path_idx / init_state); vehicles overlap from the first step on, every env is "done" at
     # every step and none is reset: non-reset steps only, as the survey prescribes for this configuration
