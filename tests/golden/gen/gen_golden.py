@@ -712,6 +712,17 @@ TRAJS = {
                            rew_method="distance", is_apply_mask=True),
     "interchange1_8_birdview": dict(T=32, B=3, seed=45, mode_pattern=[1, 1, 0], n_agents=8, scenario_type="interchange_1", dt=0.1, is_use_mtv_distance=False,
                                     rew_method="distance", is_ego_view=False, is_apply_mask=True, is_obs_steering=True),
+    # second round of cross-combinations: testing mode with mtv / ttc on the multi-lane on-ramp, the CBF margin reward on an interchange, the merge
+    # sub-scenarios of cpm_mixed (two agents: more do not fit the merge lists, tests/golden/gen/gen_reset_distribution.py; seed 51: with 48 and 50 the
+    # reference's unbounded rejection loop never returns -- a first agent on the merge point leaves the second no feasible start), bird view without vertices
+    "onramp2_8_testing_mtv": dict(T=40, B=3, seed=46, mode_pattern=[1, 0, 1], n_agents=8, scenario_type="on_ramp_2_multilane", dt=0.1, is_use_mtv_distance=True,
+                                  rew_method="ttc", is_testing_mode=True),
+    "interchange2_6_cbf": dict(T=24, B=2, seed=47, mode_pattern=[1, 0], hook="cbf", n_agents=6, scenario_type="interchange_2", dt=0.1,
+                               is_use_mtv_distance=False, rew_method="cbf", is_using_cbf_training=True, is_solve_qp=False),
+    "cpmmixed2_merge": dict(T=48, B=6, seed=51, mode_pattern=[1, 1, 0], n_agents=2, scenario_type="cpm_mixed", dt=0.05, is_use_mtv_distance=False,
+                            rew_method="distance", cpm_scenario_probabilities=[0.2, 0.4, 0.4]),
+    "intersection8_6_bird_novert": dict(T=40, B=3, seed=49, mode_pattern=[1, 1, 0], n_agents=6, scenario_type="intersection_8", dt=0.1, is_use_mtv_distance=True,
+                                        rew_method="distance_sparse", is_ego_view=False, is_observe_vertices=False, is_apply_mask=True, is_observe_distance_to_agents=False),
     # BASELINE config 4: 32 agents on the on-ramp map.  The reference's rejection sampler cannot place them, so the
     # start is injected (Parameters.predefined_ref_path_idx / init_state); vehicles overlap from the first step on, every env is "done" at
     # every step and none is reset: non-reset steps only, as the survey prescribes for this configuration

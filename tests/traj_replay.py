@@ -21,7 +21,8 @@ TRAJ_NAMES = ["cpm16_c2c", "cpm16_mtv", "intersection4_c2c", "onramp6_mtv", "cpm
               "cpm8_fixed_reset", "intersection4_fixed_testing", "cpm8_obs_steer_ref", "intersection4_obs_novert", "cpm8_birdview",
               "intersection4_birdview_novert", "cpm8_boundary_points", "onramp4_boundary_points_bird", "intersection4_birdview_mask",
               "roundabout6_birdview_mask", "cpm8_birdview_mask", "cpm8_opponent_pad", "cpm8_ns5", "intersection4_ns2",
-              "interchange6_mtv", "intersection5_6_testing", "roundabout1_5_c2c", "onramp2_6_mask", "interchange1_8_birdview"]
+              "interchange6_mtv", "intersection5_6_testing", "roundabout1_5_c2c", "onramp2_6_mask", "interchange1_8_birdview",
+              "onramp2_8_testing_mtv", "interchange2_6_cbf", "cpmmixed2_merge", "intersection8_6_bird_novert"]
 # The reference rounds the pseudo distance to fp16 and differentiates it numerically (pseudo_distance.py:118, cbf_qp.py:624-644): a
 # one-ulp difference in a float32 circle centre (torch's cos / sin -- a closed vector math library, within 1 ulp of the correctly rounded
 # value the oracle and the HIP path compute and NOT restatable, see include/sigma_trig_f32.h -- ) can flip
