@@ -19,21 +19,22 @@ from sigmarl_amd import capi
 from sigmarl_amd.maps import load_map
 from sigmarl_amd.params import Parameters, make_config
 
-MAPS = ["cpm_entire", "cpm_entire", "cpm_entire", "intersection_1", "on_ramp_1", "roundabout_1", "interchange_2", "intersection_5", "on_ramp_2_multilane"]
+MAPS = ["cpm_entire", "cpm_entire", "cpm_entire", "intersection_1", "on_ramp_1", "roundabout_1", "interchange_2", "intersection_5", "on_ramp_2_multilane", "cpm_mixed"]
 REW = ["distance", "ttc", "sparse", "distance_sparse", "ttc_sparse"]
 
 
 def one_case(rng, k):
     scen = MAPS[rng.integers(len(MAPS))]
     mp = load_map(scen)
-    n_max = 20 if scen.startswith("cpm") else 6
+    n_max = 20 if scen == "cpm_entire" else 6
     N = int(rng.integers(1, n_max + 1))
-    if scen.startswith("cpm") and rng.integers(8) == 0:  # now and then a crowded map: up to 64 agents (one env per wavefront, no lane pairing)
+    if scen == "cpm_entire" and rng.integers(8) == 0:  # now and then a crowded map: up to 64 agents (one env per wavefront, no lane pairing)
         N = int(rng.integers(21, 65))
     B = int(rng.integers(3, 160))
     kw = dict(n_agents=N, scenario_type=scen, is_use_mtv_distance=bool(rng.integers(2)), rew_method=REW[rng.integers(len(REW))], dt=float(rng.choice([0.05, 0.1])),
-              is_testing_mode=bool(rng.integers(4) == 0), is_apply_mask=bool(rng.integers(3) == 0), is_obs_noise=False, max_steps=int(rng.integers(6, 40)),
-              reset_agent_fixed_duration=float(rng.choice([0, 0, 0.5])))
+              is_testing_mode=bool(rng.integers(4) == 0), is_apply_mask=bool(rng.integers(3) == 0), is_obs_noise=bool(rng.integers(4) == 0), max_steps=int(rng.integers(6, 40)),
+              reset_agent_fixed_duration=float(rng.choice([0, 0, 0.5])), n_points_short_term=int(rng.choice([3, 3, 3, 2, 5])),
+              is_using_opponent_modeling=bool(rng.integers(6) == 0))
     if rng.integers(3) == 0:  # observation switches
         kw.update(is_obs_steering=bool(rng.integers(2)), is_observe_ref_path_other_agents=bool(rng.integers(2)), is_observe_vertices=bool(rng.integers(2)),
                   is_observe_distance_to_agents=bool(rng.integers(2)), is_observe_distance_to_center_line=bool(rng.integers(2)),
@@ -49,6 +50,12 @@ def one_case(rng, k):
     if mp.list_count[lst] < 1:
         lst = 0
     pf, pc = int(mp.list_first[lst]), int(mp.list_count[lst])
+    mixed = scen == "cpm_mixed" and bool(rng.integers(2))  # the sub-scenario lists instead of one path range (sigmaenv_set_scenario_lists)
+    if mixed:
+        probs = [float(v) for v in rng.uniform(0.0, 1.0, 3)]
+        dev.set_scenario_lists(probs)
+        ora.set_scenario_lists(probs)
+        pf, pc = 0, capi.SCENARIO_LISTS
     seed = int(rng.integers(1 << 30))
     dev.auto_reset(seed, 0, pf, pc)
     ora.auto_reset(seed, 0, pf, pc)
@@ -61,6 +68,11 @@ def one_case(rng, k):
         act = np.stack([rng.uniform(lo, hi, (B, N)) if hi > lo else np.zeros((B, N)), rng.uniform(-s, s, (B, N)) if s > 0 else np.zeros((B, N))], axis=-1).astype(np.float32)
         if rng.integers(2):
             dev.step_autoreset(act, seed, t + 1, pf, pc)
+        elif rng.integers(3) == 0:  # the in-kernel step loop with a chunk of one step (longer chunks: tests/test_gpu_nstep.py)
+            import torch
+
+            dev.env.step_autoreset_n(torch.as_tensor(act[None]).to(dev.env.device).contiguous(), seed=seed, counter0=t + 1, path_first=pf, path_count=pc)
+            dev.env.sync()
         else:
             dev.step(act)
             n_diff += 0
@@ -68,7 +80,7 @@ def one_case(rng, k):
         ora.step(act)
         ora.auto_reset(seed, t + 1, pf, pc)
         n_diff += tp._compare_all(dev, ora, tag + f" | step {t}")
-        if rng.integers(4) == 0:  # host-driven resets (sigmaenv_reset): single agents of some envs, or whole envs, onto random centre-line points
+        if rng.integers(4) == 0 and not mixed:  # host-driven resets (sigmaenv_reset): single agents of some envs, or whole envs, onto random centre-line points
             full = bool(rng.integers(2))
             envs = rng.choice(B, size=int(rng.integers(1, min(B, 6) + 1)), replace=False)
             ei, ai, ids, st8 = [], [], [], []
