@@ -166,8 +166,12 @@ def shard_streams(torch, device, S):
 
 
 def pick_chunk(steps: int, cap: int = 32) -> int:
-    """Steps per launch: the largest divisor of `steps` that is at most `cap` (the timed region is then whole launches)."""
-    return max(d for d in range(1, max(1, min(cap, steps)) + 1) if steps % d == 0) if steps > 0 else 1
+    """Steps per launch: the largest divisor of `steps` that is at most `cap` (the timed region is then whole launches) -- unless `steps` has no divisor of at
+    least cap / 2 (a prime step count ...): then `cap`, and the last launch of the region is a shorter one."""
+    if steps <= 0:
+        return 1
+    best = max(d for d in range(1, min(cap, steps) + 1) if steps % d == 0)
+    return best if 2 * best >= min(cap, steps) else min(cap, steps)
 
 
 class GpuRun:
