@@ -437,8 +437,6 @@ def dry_run(args):
         os.environ.setdefault("MASTER_PORT", "29541")
         dist.init_process_group("gloo")
         assert dist.get_rank() == rank and dist.get_world_size() == world
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     B, N = args.envs_per_gpu, args.agents
     plain = not (args.policy or args.cbf or args.cbf_qp or args.no_reset or args.separate_reset)
     T = 1 if not plain else (args.chunk if args.chunk >= 1 else pick_chunk(args.steps))
@@ -495,6 +493,30 @@ def dry_run(args):
     os.dup2(2, 1)
 
 
+def ensure_world(args):
+    """`--gpus N` must mean N ranks.  Started without a rendezvous (no WORLD_SIZE: `python bench.py --gpus 8`) the script re-executes itself under
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` -- the driver's own command line -- instead of timing one
+    rank and printing an `n_gpus: 1` line; started under a launcher whose world size differs from --gpus it exits non-zero with the command to use."""
+    world = os.environ.get("WORLD_SIZE")
+    if world is None:
+        if args.gpus <= 1:
+            return
+        import socket
+
+        with socket.socket() as sk:  # a free rendezvous port on the loopback interface
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        print(f"[bench] --gpus {args.gpus} without a rendezvous: re-launching as `{' '.join(cmd)}`", file=sys.stderr)
+        sys.stderr.flush()
+        os.execv(sys.executable, cmd)
+    if int(world) != args.gpus:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: launch `python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
+              f"--master-port <port> bench.py --gpus {args.gpus} ...` (or plain `python bench.py --gpus {args.gpus}`, which does that itself)", file=sys.stderr)
+        sys.exit(2)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -540,6 +562,7 @@ def main():
                     "rendezvous, env ranges, the chunk exchange (gloo, host buffers tagged by rank and step, checked), barrier / MAX reduction, ONE JSON line from "
                     "rank 0 (`dry_run: true`, `value: 0`) -- so that `torch.distributed.run ... bench.py --gpus 8` can be rehearsed on a box without GPUs")
     args = ap.parse_args()
+    ensure_world(args)
     if args.dry_run:
         return dry_run(args)
 
@@ -566,8 +589,6 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 

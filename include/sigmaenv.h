@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define SIGMAENV_ABI_VERSION 4
+#define SIGMAENV_ABI_VERSION 5
 
 /* error codes */
 #define SIGMAENV_OK 0
@@ -196,7 +196,17 @@ int sigmaenv_obs_dim(int32_t n_nearing);
 #define SIGMAENV_OBS_OPPONENT_PAD 128  /* Parameters.is_using_opponent_modeling: the row ends with n_nearing x 2 placeholder columns for the tentative actions of
                                         * the observed neighbours (F.pad, observation_provider_rt.py:606-611), zero before the sensor noise is added;
                                         * sigmaenv_opponent_fill writes the actions into them */
+#define SIGMAENV_OBS_FULL 256          /* Parameters.is_partial_observation == False (observation_provider_rt.py:622-800, the `else` branch at :756): every agent observes
+                                        * ALL agents in index order instead of its n_nearing nearest -- only with SIGMAENV_OBS_BIRD_VIEW (the ego view raises in the
+                                        * reference: its reshape of the per-agent length / width scalars fails).  [own] as in bird view; then, for each of the
+                                        * K = n_nearing chunks the reference's reshape(B, n_nearing_agents, -1) cuts every feature tensor into (:790-816), chunk k of:
+                                        * vertices [N,4,2] (NO_VERTICES: positions [N,2], rotations [N], lengths [N], widths [N]) | velocities [N,2] | steering [N]
+                                        * (STEERING) | the mutual distances [N,N], ALL ZERO in this view (:776-778; unless NO_DIST_AGENTS) | short-term paths
+                                        * [N,NS,2] (REF_OTHERS); no mask; SIGMAENV_BUF_NEARING stays zero.  N x (feature width) must be a multiple of K for every
+                                        * feature (torch.reshape raises otherwise: SIGMAENV_EINVAL) */
 int sigmaenv_obs_dim_ex(int32_t n_nearing, int32_t obs_flags);
+/* Row width for ANY flags, SIGMAENV_OBS_FULL included (equals sigmaenv_obs_dim_ex without it); SIGMAENV_EINVAL for a combination the reference raises on. */
+int sigmaenv_obs_dim_full(int32_t n_agents, int32_t n_nearing, int32_t obs_flags);
 int sigmaenv_n_short_term(void);   /* SIGMAENV_N_SHORT_TERM of this build */
 
 /* device_id: HIP device ordinal.  hip_stream: hipStream_t to enqueue on (NULL = the device's default stream). */

@@ -512,7 +512,9 @@ static void agent_observation(oracle_t* o, int b, int i) {
   /* top-k smallest, ascending, lowest index on ties: observation_provider_rt.py:629-636 */
   int32_t* near = o->nearing + bi * K;
   uint64_t taken = 0;
-  for (int k = 0; k < K; ++k) {
+  const int full = (F & SIGMAENV_OBS_FULL) != 0;                 /* is_partial_observation == False: no top-k, nearing_agents_indices keeps its zeros (:627-636) */
+  for (int k = 0; full && k < K; ++k) near[k] = 0;
+  for (int k = 0; !full && k < K; ++k) {
     int bj = -1;
     float bd = INFINITY;
     for (int j = 0; j < N; ++j) {
@@ -578,7 +580,45 @@ static void agent_observation(oracle_t* o, int b, int i) {
   /* [others] per observed neighbour (:803-853): vertices (8) -- or position (2), relative rotation, length, width --, velocity (2), steering,
    * distance, its short-term reference path; masked by distance (:638-749): positions / vertices / reference path / distance := 1,
    * rotation / steering / velocity := 0 (lengths and widths are not masked) */
-  for (int k = 0; k < K; ++k) {
+  if (full) {
+    /* full observation (bird view; the ego view raises in the reference: :756-800 with indexing_tuple_2 = (env_idx,)): every feature tensor holds ALL N
+     * agents in index order -- vertices [B,N,4,2], velocities [B,N,2], ..., and the mutual distances the whole [B,N,N] matrix, which
+     * `obs_distance_other_agents[indexing_tuple_2] = 0` (:776-778) zeroes entirely in this view --, is reshaped to [B, n_nearing_agents, -1] (:790-816),
+     * i.e. cut into K = n_nearing equal chunks of its flat per-env array, and the chunks of the features are concatenated chunk by chunk (:819-851).
+     * No mask applies (:638-749 is the partial branch).  sigmaenv_obs_dim_full refuses the shapes torch.reshape refuses (N * width not divisible by K). */
+    enum { F_VERT, F_POS, F_ROT, F_LEN, F_WID, F_VEL, F_STEER, F_DIST, F_REF };
+    int kind[9], wid[9], nf = 0;
+    if (!(F & SIGMAENV_OBS_NO_VERTICES)) { kind[nf] = F_VERT; wid[nf++] = 8; }
+    else { kind[nf] = F_POS; wid[nf++] = 2; kind[nf] = F_ROT; wid[nf++] = 1; kind[nf] = F_LEN; wid[nf++] = 1; kind[nf] = F_WID; wid[nf++] = 1; }
+    kind[nf] = F_VEL; wid[nf++] = 2;
+    if (F & SIGMAENV_OBS_STEERING) { kind[nf] = F_STEER; wid[nf++] = 1; }
+    if (!(F & SIGMAENV_OBS_NO_DIST_AGENTS)) { kind[nf] = F_DIST; wid[nf++] = N; }
+    if (F & SIGMAENV_OBS_REF_OTHERS) { kind[nf] = F_REF; wid[nf++] = 2 * NS; }
+    for (int ck = 0; ck < K; ++ck) {
+      for (int f = 0; f < nf; ++f) {
+        const int w = wid[f], chunk = N * w / K;
+        for (int e = 0; e < chunk; ++e) {
+          const int flat = ck * chunk + e, j = flat / w, q = flat - j * w;
+          const size_t bj = (size_t)b * N + j;
+          const float* sj = o->state + bj * 8;
+          float v = 0.0f;
+          switch (kind[f]) {
+            case F_VERT: v = o->vertices[bj * 10 + q] / ((q & 1) ? nwy : nwx); break;              /* :555-563 */
+            case F_POS: v = sj[q] / (q ? nwy : nwx); break;                                          /* :539-546 */
+            case F_ROT: v = angle_eliminate_two_pi(sj[2]) / n_rot; break;                            /* :550-553 */
+            case F_LEN: v = c->length / n_da; break;                                                 /* :387-389 */
+            case F_WID: v = c->width / n_da; break;                                                  /* :390-391 */
+            case F_VEL: v = sj[5 + q] / n_v; break;                                                  /* :547-549 */
+            case F_STEER: v = angle_eliminate_two_pi(sj[4]) / n_rot; break;                          /* :356-360, :392 */
+            case F_DIST: v = 0.0f; break;                                                            /* :776-778 */
+            case F_REF: v = o->short_term[bj * NS * 2 + q] / ((q & 1) ? nwy : nwx); break;          /* :564-571 */
+          }
+          ob[p++] = v;
+        }
+      }
+    }
+  }
+  for (int k = 0; !full && k < K; ++k) {
     int j = near[k];
     size_t bj = (size_t)b * N + j;
     const float* sj = o->state + bj * 8;
@@ -846,6 +886,25 @@ int sigmaenv_oracle_obs_dim_ex(int32_t n_nearing, int32_t f) {   /* observation_
   return own + n_nearing * other + ((f & SIGMAENV_OBS_OPPONENT_PAD) ? 2 * n_nearing : 0);
 }
 
+int sigmaenv_oracle_obs_dim_full(int32_t n_agents, int32_t n_nearing, int32_t f) {   /* :622-800, see agent_observation */
+  if (!(f & SIGMAENV_OBS_FULL)) return sigmaenv_oracle_obs_dim_ex(n_nearing, f);
+  if (!(f & SIGMAENV_OBS_BIRD_VIEW) || n_nearing < 1 || n_agents < 1) return SIGMAENV_EINVAL;
+  const int N = n_agents, K = n_nearing;
+  int wid[9], nf = 0;
+  if (!(f & SIGMAENV_OBS_NO_VERTICES)) wid[nf++] = 8; else { wid[nf++] = 2; wid[nf++] = 1; wid[nf++] = 1; wid[nf++] = 1; }
+  wid[nf++] = 2;
+  if (f & SIGMAENV_OBS_STEERING) wid[nf++] = 1;
+  if (!(f & SIGMAENV_OBS_NO_DIST_AGENTS)) wid[nf++] = N;
+  if (f & SIGMAENV_OBS_REF_OTHERS) wid[nf++] = 2 * NS;
+  int others = 0;
+  for (int q = 0; q < nf; ++q) {
+    if ((N * wid[q]) % K != 0) return SIGMAENV_EINVAL;          /* torch.reshape(B, n_nearing_agents, -1) raises */
+    others += N * wid[q];
+  }
+  const int own = sigmaenv_oracle_obs_dim_ex(0, f & ~SIGMAENV_OBS_OPPONENT_PAD);
+  return own + others + ((f & SIGMAENV_OBS_OPPONENT_PAD) ? 2 * K : 0);
+}
+
 static void* xcalloc(size_t n, size_t sz) { return calloc(n ? n : 1, sz); }
 
 int sigmaenv_oracle_create(const sigmaenv_config_t* cfg, const sigmaenv_map_t* map, int device_id, void* stream, oracle_t** out) {
@@ -860,7 +919,8 @@ int sigmaenv_oracle_create(const sigmaenv_config_t* cfg, const sigmaenv_map_t* m
   if (!o) return SIGMAENV_ENOMEM;
   o->cfg = *cfg;
   int B = o->B = cfg->n_envs, N = o->N = cfg->n_agents, K = o->K = cfg->n_nearing;
-  o->D = sigmaenv_oracle_obs_dim_ex(K, cfg->obs_flags);
+  o->D = sigmaenv_oracle_obs_dim_full(N, K, cfg->obs_flags);
+  if (o->D < 0) { free(o); return SIGMAENV_EINVAL; }
   int np = o->n_paths = map->n_paths, S = map->stride_points;
   int maxc = 0;
   for (int p = 0; p < np; ++p) {
@@ -984,7 +1044,7 @@ static void auto_reset_agents(oracle_t* o, int b, uint64_t seed, uint64_t counte
     float* s = o->state + bi * 8;
     if (mixed) {                                                 /* the agent keeps its env's sub-scenario (:325-328) */
       const int sid = o->path[bi * 4 + 1];
-      const int k = (sid >= 1 && sid <= o->n_lists) ? sid - 1 : 0;
+      const int k = (sid >= 1 && sid <= o->n_lists) ? sid - 1 : (o->n_lists > 0 ? o->n_lists - 1 : 0);   /* else branch of world_state_rt_sim.py:345-356: the last list */
       path_first = o->list_first[k]; path_count = o->list_count[k];
     }
     int path = path_first, pt = 3;

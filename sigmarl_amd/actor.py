@@ -30,7 +30,10 @@ class Mlp32:
     """``sigmaenv_mlp32_*``: a Tanh MLP with hidden width 256 in exact fp32 (matrix cores); ``forward(env, x[rows, in_dim]) -> [rows, out_dim]``."""
 
     def __init__(self, mlp: torch.nn.Module, lib: capi.Library | None = None):
+        # A handle belongs to the library that made it, and an env handle to the build of ITS n_points_short_term (libsigmaenv_ns<k>.so): every call
+        # that takes ``env.h`` goes through ``env.lib`` with a network handle created by that same library (one per library, made on first use).
         self.lib = lib or capi.load_library()
+        self._handles = {}
         lin = [m for m in mlp.modules() if isinstance(m, torch.nn.Linear)]
         if not (2 <= len(lin) <= 4) or any(m.out_features != 256 for m in lin[:-1]) or lin[-1].out_features > 32:
             raise ValueError("expected 2-4 Linear layers with hidden width 256 and at most 32 outputs")
@@ -39,18 +42,27 @@ class Mlp32:
         ws = [np.ascontiguousarray(m.weight.detach().cpu().numpy(), np.float32) for m in lin]
         bs = [np.ascontiguousarray(m.bias.detach().cpu().numpy(), np.float32) for m in lin]
         self._keep = (dims, ws, bs)
-        PA = C.c_void_p * len(lin)
-        wp, bp = PA(*[w.ctypes.data for w in ws]), PA(*[b.ctypes.data for b in bs])
-        h = C.c_void_p()
-        rc = self.lib.mlp32_create(len(lin), dims.ctypes.data_as(C.c_void_p), wp, bp, C.byref(h))
-        if rc != 0:
-            raise RuntimeError(f"sigmaenv_mlp32_create failed with code {rc}")
-        self.h = h
+        self.h = self.handle(self.lib)
+
+    def handle(self, lib: capi.Library):
+        """The network's handle in ``lib`` (created on first use)."""
+        ent = self._handles.get(lib.path)
+        if ent is None:
+            dims, ws, bs = self._keep
+            PA = C.c_void_p * len(ws)
+            wp, bp = PA(*[w.ctypes.data for w in ws]), PA(*[b.ctypes.data for b in bs])
+            h = C.c_void_p()
+            rc = lib.mlp32_create(len(ws), dims.ctypes.data_as(C.c_void_p), wp, bp, C.byref(h))
+            if rc != 0:
+                raise RuntimeError(f"sigmaenv_mlp32_create failed with code {rc}")
+            ent = self._handles[lib.path] = (lib, h)
+        return ent[1]
 
     def close(self):
-        if getattr(self, "h", None):
-            self.lib.mlp32_destroy(self.h)
-            self.h = None
+        for lib, h in getattr(self, "_handles", {}).values():
+            lib.mlp32_destroy(h)
+        self._handles = {}
+        self.h = None
 
     def __del__(self):  # pragma: no cover
         try:
@@ -64,7 +76,7 @@ class Mlp32:
         rows = x.numel() // self.in_dim
         if out is None:
             out = torch.empty((*x.shape[:-1], self.out_dim), dtype=torch.float32, device=x.device)
-        rc = self.lib.mlp32_forward(env.h, self.h, C.c_void_p(x.data_ptr()), rows, C.c_void_p(out.data_ptr()))
+        rc = env.lib.mlp32_forward(env.h, self.handle(env.lib), C.c_void_p(x.data_ptr()), rows, C.c_void_p(out.data_ptr()))
         if rc != 0:
             raise RuntimeError(f"sigmaenv_mlp32_forward failed with code {rc}: {env.lib.last_error(env.h).decode()}")
         return out
@@ -102,25 +114,26 @@ class Actor:
         self._keep = arrs + [np.ascontiguousarray(low, np.float32), np.ascontiguousarray(high, np.float32)]
         # the bf16 kernel handle exists only for the widths its MFMA tiling takes (sigmaenv_actor_create: obs_dim in {8, 16, 24, 32}); other
         # observation switches (e.g. is_obs_steering: 35) run the exact-fp32 network, which takes any width
-        self.h = None
+        self._bf16 = {}  # library path -> (library, handle): see Mlp32
         if precision == "bf16":
-            self._bf16_handle()
+            self._bf16_handle(self.lib)
 
-    def _bf16_handle(self):
-        if self.h is None:
+    def _bf16_handle(self, lib: capi.Library):
+        ent = self._bf16.get(lib.path)
+        if ent is None:
             if self.obs_dim not in (8, 16, 24, 32):
                 raise ValueError(f"the bf16 actor kernel takes obs_dim 8, 16, 24 or 32, not {self.obs_dim}: use precision='fp32' for this observation layout")
             h = C.c_void_p()
-            rc = self.lib.actor_create(self.obs_dim, *[a.ctypes.data_as(C.c_void_p) for a in self._keep], C.byref(h))
+            rc = lib.actor_create(self.obs_dim, *[a.ctypes.data_as(C.c_void_p) for a in self._keep], C.byref(h))
             if rc != 0:
                 raise RuntimeError(f"sigmaenv_actor_create failed with code {rc}")
-            self.h = h
-        return self.h
+            ent = self._bf16[lib.path] = (lib, h)
+        return ent[1]
 
     def close(self):
-        if getattr(self, "h", None):
-            self.lib.actor_destroy(self.h)
-            self.h = None
+        for lib, h in getattr(self, "_bf16", {}).values():
+            lib.actor_destroy(h)
+        self._bf16 = {}
         if getattr(self, "_mlp32", None) is not None:
             self._mlp32.close()
 
@@ -138,12 +151,12 @@ class Actor:
             if self._scratch4 is None or self._scratch4.shape[0] != env.B * env.N or self._scratch4.device != env.device:
                 self._scratch4 = torch.empty((env.B * env.N, 4), dtype=torch.float32, device=env.device)
             lo, hi = self._keep[-2], self._keep[-1]
-            rc = self.lib.actor_forward_f32(env.h, self._mlp32.h, p(obs), p(self._scratch4), lo.ctypes.data_as(C.c_void_p), hi.ctypes.data_as(C.c_void_p),
+            rc = env.lib.actor_forward_f32(env.h, self._mlp32.handle(env.lib), p(obs), p(self._scratch4), lo.ctypes.data_as(C.c_void_p), hi.ctypes.data_as(C.c_void_p),
                                             p(actions), p(log_prob), p(loc_scale), int(seed), int(counter), int(bool(deterministic)))
             if rc != 0:
                 raise RuntimeError(f"sigmaenv_actor_forward_f32 failed with code {rc}: {env.lib.last_error(env.h).decode()}")
             return actions
-        rc = self.lib.actor_forward(env.h, self._bf16_handle(), p(obs), p(actions), p(log_prob), p(loc_scale), int(seed), int(counter), int(bool(deterministic)))
+        rc = env.lib.actor_forward(env.h, self._bf16_handle(env.lib), p(obs), p(actions), p(log_prob), p(loc_scale), int(seed), int(counter), int(bool(deterministic)))
         if rc != 0:
             raise RuntimeError(f"sigmaenv_actor_forward failed with code {rc}: {env.lib.last_error(env.h).decode()}")
         return actions
@@ -163,13 +176,13 @@ class Actor:
             if self._scratch4 is None or self._scratch4.shape[0] != env.B * env.N or self._scratch4.device != env.device:
                 self._scratch4 = torch.empty((env.B * env.N, 4), dtype=torch.float32, device=env.device)
             lo, hi = self._keep[-2], self._keep[-1]
-            rc = self.lib.rollout_f32(env.h, self._mlp32.h, lo.ctypes.data_as(C.c_void_p), hi.ctypes.data_as(C.c_void_p), p(self._scratch4), int(n_steps),
+            rc = env.lib.rollout_f32(env.h, self._mlp32.handle(env.lib), lo.ctypes.data_as(C.c_void_p), hi.ctypes.data_as(C.c_void_p), p(self._scratch4), int(n_steps),
                                       p(self._scratch), p(slab), p(log_prob), p(actions), int(seed), int(counter0), int(path_first), int(path_count),
                                       int(bool(deterministic)))
             if rc != 0:
                 raise RuntimeError(f"sigmaenv_rollout_f32 failed with code {rc}: {env.lib.last_error(env.h).decode()}")
             return
-        rc = self.lib.rollout(env.h, self._bf16_handle(), int(n_steps), p(self._scratch), p(slab), p(log_prob), p(actions), int(seed), int(counter0), int(path_first),
+        rc = env.lib.rollout(env.h, self._bf16_handle(env.lib), int(n_steps), p(self._scratch), p(slab), p(log_prob), p(actions), int(seed), int(counter0), int(path_first),
                               int(path_count), int(bool(deterministic)))
         if rc != 0:
             raise RuntimeError(f"sigmaenv_rollout failed with code {rc}: {env.lib.last_error(env.h).decode()}")

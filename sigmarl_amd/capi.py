@@ -14,7 +14,7 @@ import ctypes as C
 import math
 import os
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 DIST_C2C, DIST_MTV = 0, 1
 REW_DISTANCE, REW_TTC, REW_EXACT_SPARSE, REW_HAS_SPARSE, REW_CBF, REW_CBF_QP = 1, 2, 4, 8, 16, 32
 CBF_MAX_CIRCLES = 4
@@ -110,15 +110,29 @@ KERNEL_STEP, KERNEL_CBF_QP, KERNEL_CBF_MARGIN, KERNEL_MLP32, KERNEL_ACTOR_BF16 =
 KERNEL_NAMES = ("sigmaenv_step_wave_kernel", "cbf::sigmaenv_cbf_qp_kernel", "cbf::sigmaenv_cbf_kernel", "sigmaenv_mlp32_kernel", "sigmaenv_actor_kernel")
 SCENARIO_LISTS = -1  # path_count of a device-side reset that draws from the handle's sub-scenario lists (cpm_mixed)
 OBS_STEERING, OBS_REF_OTHERS, OBS_NO_VERTICES, OBS_NO_DIST_AGENTS, OBS_NO_DIST_CENTER, OBS_BIRD_VIEW, OBS_BOUNDARY_POINTS, OBS_OPPONENT_PAD = 1, 2, 4, 8, 16, 32, 64, 128
+OBS_FULL = 256  # Parameters.is_partial_observation == False (bird view only): every agent observes ALL agents (include/sigmaenv.h)
 
 
-def obs_dim(n_nearing: int, obs_flags: int = 0, n_short_term: int = N_SHORT_TERM) -> int:
-    """``sigmaenv_obs_dim_ex``: [own] speed, (steering), short-term path, (centre-line distance), two boundary distances; per observed
-    neighbour vertices (or position / rotation / length / width), velocity, (steering), (distance), (its short-term path)."""
+def obs_dim(n_nearing: int, obs_flags: int = 0, n_short_term: int = N_SHORT_TERM, n_agents: int | None = None) -> int:
+    """``sigmaenv_obs_dim_full``: [own] speed, (steering), short-term path, (centre-line distance), two boundary distances; per observed
+    neighbour vertices (or position / rotation / length / width), velocity, (steering), (distance), (its short-term path).  With ``OBS_FULL``
+    (needs ``n_agents``): the [others] part is every feature tensor of ALL agents, cut into ``n_nearing`` chunks (observation_provider_rt.py:756-851);
+    raises ``ValueError`` where the reference's reshape raises."""
     s, r = int(bool(obs_flags & OBS_STEERING)), int(bool(obs_flags & OBS_REF_OTHERS))
     own = 1 + s + 2 * n_short_term + (0 if obs_flags & OBS_NO_DIST_CENTER else 1) + (20 if obs_flags & OBS_BOUNDARY_POINTS else 2) + (4 if obs_flags & OBS_BIRD_VIEW else 0)
+    pad = 2 * n_nearing if obs_flags & OBS_OPPONENT_PAD else 0
+    if obs_flags & OBS_FULL:
+        if n_agents is None:
+            raise ValueError("obs_dim: OBS_FULL needs n_agents")
+        if not obs_flags & OBS_BIRD_VIEW or n_nearing < 1:
+            raise ValueError("full observation (is_partial_observation=False) exists in bird view only (is_ego_view=False), with n_nearing_agents_observed >= 1")
+        widths = ([2, 1, 1, 1] if obs_flags & OBS_NO_VERTICES else [8]) + [2] + [1] * s + ([] if obs_flags & OBS_NO_DIST_AGENTS else [n_agents]) + [2 * n_short_term] * r
+        if any((n_agents * w) % n_nearing for w in widths):
+            raise ValueError(f"full observation: {n_agents} agents x feature widths {widths} do not split into n_nearing_agents_observed = {n_nearing} chunks "
+                             "(the reference's reshape(batch, n_nearing_agents, -1) raises)")
+        return own + n_agents * sum(widths) + pad
     other = (5 if obs_flags & OBS_NO_VERTICES else 8) + 2 + s + (0 if obs_flags & OBS_NO_DIST_AGENTS else 1) + r * 2 * n_short_term
-    return own + n_nearing * other + (2 * n_nearing if obs_flags & OBS_OPPONENT_PAD else 0)
+    return own + n_nearing * other + pad
 
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
@@ -127,6 +141,7 @@ DEFAULT_LIB = os.path.join(_PKG_DIR, "csrc", "libsigmaenv.so")
 _SIGS = {
     "obs_dim": (C.c_int, [C.c_int32]),
     "obs_dim_ex": (C.c_int, [C.c_int32, C.c_int32]),
+    "obs_dim_full": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "n_short_term": (C.c_int, []),
     "create": (C.c_int, [C.POINTER(Config), C.POINTER(Map), C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "destroy": (None, [C.c_void_p]),

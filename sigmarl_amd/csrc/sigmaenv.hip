@@ -794,11 +794,12 @@ __device__ __forceinline__ void reset_candidate(const DevMap& m, const ResetDraw
   px = xy.x;
   py = xy.y;
 }
-// cpm_mixed: the path list of sub-scenario `sid` (1-based; out-of-range ids fall back to the first list), and the sub-scenario a finished env draws
+// cpm_mixed: the path list of sub-scenario `sid` (1-based; any other id -- 0 after a host-placed start -- takes the LAST list, the reference's
+// `if 1 / elif 2 / else` chain, world_state_rt_sim.py:345-356), and the sub-scenario a finished env draws
 // (torch.multinomial(cpm_scenario_probabilities), world_state_rt_sim.py:330-343 -- here the counter-based generator's draw 5000 of agent 0 against the
 // cumulative distribution; specification shared with the oracle)
 __device__ __forceinline__ void scenario_list(const DevMap& m, int sid, int& first, int& count) {
-  const int k = (sid >= 1 && sid <= m.n_lists) ? sid - 1 : 0;
+  const int k = (sid >= 1 && sid <= m.n_lists) ? sid - 1 : (m.n_lists > 0 ? m.n_lists - 1 : 0);
   first = (int)((m.list_first16 >> (16 * k)) & 0xFFFFull);
   count = (int)((m.list_count16 >> (16 * k)) & 0xFFFFull);
 }
@@ -1402,6 +1403,24 @@ extern "C" int sigmaenv_obs_dim_ex(int32_t n_nearing, int32_t f) {  // observati
   return own + n_nearing * other + ((f & SIGMAENV_OBS_OPPONENT_PAD) ? 2 * n_nearing : 0);
 }
 
+extern "C" int sigmaenv_obs_dim_full(int32_t n_agents, int32_t n_nearing, int32_t f) {  // observation_provider_rt.py:622-851 (SIGMAENV_OBS_FULL: the `else` at :756)
+  if (!(f & SIGMAENV_OBS_FULL)) return sigmaenv_obs_dim_ex(n_nearing, f);
+  if (!(f & SIGMAENV_OBS_BIRD_VIEW) || n_nearing < 1 || n_agents < 1) return SIGMAENV_EINVAL;
+  const int N = n_agents, K = n_nearing;
+  int wid[9], nf = 0;
+  if (!(f & SIGMAENV_OBS_NO_VERTICES)) wid[nf++] = 8; else { wid[nf++] = 2; wid[nf++] = 1; wid[nf++] = 1; wid[nf++] = 1; }
+  wid[nf++] = 2;
+  if (f & SIGMAENV_OBS_STEERING) wid[nf++] = 1;
+  if (!(f & SIGMAENV_OBS_NO_DIST_AGENTS)) wid[nf++] = N;
+  if (f & SIGMAENV_OBS_REF_OTHERS) wid[nf++] = 2 * NS;
+  int others = 0;
+  for (int q = 0; q < nf; ++q) {
+    if ((N * wid[q]) % K != 0) return SIGMAENV_EINVAL;  // torch.reshape(B, n_nearing_agents, -1) raises
+    others += N * wid[q];
+  }
+  return sigmaenv_obs_dim_ex(0, f & ~SIGMAENV_OBS_OPPONENT_PAD) + others + ((f & SIGMAENV_OBS_OPPONENT_PAD) ? 2 * K : 0);
+}
+
 extern "C" const char* sigmaenv_last_error(const sigmaenv_t* h) { return h ? h->err.c_str() : "null handle"; }
 
 extern "C" void sigmaenv_destroy(sigmaenv_t* h) {
@@ -1447,7 +1466,8 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
   h->stream = reinterpret_cast<hipStream_t>(hip_stream);
   const int B = h->B = cfg->n_envs, N = h->N = cfg->n_agents, K = h->K = cfg->n_nearing;
   h->D = sigmaenv_obs_dim(K);  // the fused kernels' own (default) row
-  h->D_pub = sigmaenv_obs_dim_ex(K, cfg->obs_flags);
+  h->D_pub = sigmaenv_obs_dim_full(N, K, cfg->obs_flags);
+  if (h->D_pub < 0) { delete h; return SIGMAENV_EINVAL; }
   const int np = h->n_paths = map->n_paths, S = map->stride_points;
   for (int p = 0; p < np; ++p) {
     if (map->n_center[p] < 2 || map->n_left[p] < 2 || map->n_right[p] < 2 || map->n_center[p] > S || map->n_left[p] > S || map->n_right[p] > S) {

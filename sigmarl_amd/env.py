@@ -123,7 +123,7 @@ class SigmaEnv:
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.B, self.N, self.K = cfg.n_envs, cfg.n_agents, cfg.n_nearing
-        self.D = capi.obs_dim(self.K, int(getattr(self.cfg, "obs_flags", 0)), self.n_short_term)
+        self.D = capi.obs_dim(self.K, int(getattr(self.cfg, "obs_flags", 0)), self.n_short_term, self.N)
         self._map_struct = map_table.as_struct()
         with torch.cuda.device(self.device):
             self.stream = torch.cuda.current_stream(self.device)

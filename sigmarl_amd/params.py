@@ -99,6 +99,8 @@ def obs_flags(p: Parameters) -> int:
         f |= capi.OBS_BOUNDARY_POINTS
     if getattr(p, "is_using_opponent_modeling", False):
         f |= capi.OBS_OPPONENT_PAD
+    if not p.is_partial_observation:
+        f |= capi.OBS_FULL
     return f
 
 
@@ -107,8 +109,16 @@ def check_supported(p: Parameters) -> None:
     bad = []
     # bird view with is_apply_mask (the lanelet-relation mask, observation_provider_rt.py:577-665 / map_manager.py:41-118) IS built: SigmaEnv hands the
     # map's lanelet tables to the library (sigmaenv_set_lanelets); maps without a neighbour table (the CPM map) mask by distance only, as in the reference
+    # is_partial_observation=False (every agent observes ALL agents, observation_provider_rt.py:756-800) IS built for the bird view (capi.OBS_FULL); in the
+    # ego view the reference itself raises (its reshape of the per-agent length / width scalars to [batch, n_nearing, -1] fails), and so does this mirror
     if not p.is_partial_observation:
-        bad.append("is_partial_observation=False")
+        if p.is_ego_view:
+            bad.append("is_partial_observation=False with is_ego_view=True (raises in the reference as well)")
+        else:
+            try:
+                capi.obs_dim(min(int(p.n_nearing_agents_observed), int(p.n_agents) - 1), obs_flags(p), int(p.n_points_short_term), int(p.n_agents))
+            except ValueError as exc:
+                bad.append(str(exc))
     # is_apply_mask: in ego view (the only view built) only the DISTANCE criterion is live in the reference -- the lanelet of every agent
     # (MapManager.determine_current_lanelet) is only computed in the bird-view branch of update_state (observation_provider_rt.py:537-588),
     # so current_lanelet_idx stays empty and determine_masked_agents_by_lanelets masks nobody (map_manager.py:21,102-118) on every map

@@ -3,10 +3,13 @@
 Environments are independent units (no cross-env read anywhere in the step), so the data path
 shards with NO collective: rank r owns a contiguous env range and its own ``SigmaEnv``.  The only exchange is the
 learner-boundary concat of the rollout buffer (observation, reward, done of every step): the fused step kernel writes each
-step's slab row-wise into a ``[T, B, W]`` chunk buffer (``sigmaenv_set_slab``), and once per chunk ONE asynchronous gather
-ships it to the learner rank (RCCL over xGMI when the backend is "nccl"; gloo in the CPU tests) while the next chunk is
-being stepped into the second buffer.  One large message per link instead of a small one per step: xGMI is point-to-point, the
-7 peers of the learner send over 7 distinct links.
+step's slab row-wise into a ``[T, B, W]`` chunk buffer (``sigmaenv_set_slab`` / ``sigmaenv_step_autoreset_n``), and once per chunk ONE
+asynchronous collective ships it while the next chunk is being stepped into the second buffer (RCCL over xGMI when the backend is
+"nccl"; gloo in the CPU tests).  One large message per link instead of a small one per step.  Two forms (``RolloutExchange(mode=...)``):
+  "alltoall" (the default, and ``bench.py``'s)  the concatenated buffer is spread over the ranks by TIME SLICES -- rank r receives steps
+             [r T/W, (r+1) T/W) of every rank's chunk, all envs of the node for 1/W of the steps: a data-parallel learner.  xGMI is
+             point-to-point, so the record crosses it once over all 56 directed links.
+  "gather"   everything to ONE learner rank (``dst``): the 7 links into that GPU carry the whole node's record and bound the rate.
 """
 from __future__ import annotations
 
@@ -57,7 +60,7 @@ class RolloutExchange:
                      bytes cross xGMI once, but over all 56 directed links instead of the 7 into one GPU."""
 
     def __init__(self, local_envs: int, n_agents: int, obs_dim: int, chunk_steps: int, device, dst: int = 0, group=None,
-                 force_collective: bool = False, mode: str = "gather"):
+                 force_collective: bool = False, mode: str = "alltoall"):
         if mode not in ("gather", "alltoall"):
             raise ValueError("mode must be 'gather' or 'alltoall'")
         self.mode = mode

@@ -723,6 +723,19 @@ TRAJS = {
                             rew_method="distance", cpm_scenario_probabilities=[0.2, 0.4, 0.4]),
     "intersection8_6_bird_novert": dict(T=40, B=3, seed=49, mode_pattern=[1, 1, 0], n_agents=6, scenario_type="intersection_8", dt=0.1, is_use_mtv_distance=True,
                                         rew_method="distance_sparse", is_ego_view=False, is_observe_vertices=False, is_apply_mask=True, is_observe_distance_to_agents=False),
+    # full observation (is_partial_observation=False, observation_provider_rt.py:756-851): bird view only (the ego view raises in the reference); every
+    # agent's row carries ALL agents' features, cut into n_nearing_agents_observed chunks by the reference's reshape; the mutual distances are all zero
+    "intersection4_full_bird": dict(T=32, B=3, seed=52, mode_pattern=[1, 1, 0], n_agents=4, scenario_type="intersection_1", dt=0.1, is_use_mtv_distance=False,
+                                    rew_method="distance", is_ego_view=False, is_partial_observation=False, is_apply_mask=False),
+    "intersection4_full_bird_novert": dict(T=32, B=3, seed=53, mode_pattern=[1, 0, 1], n_agents=4, scenario_type="intersection_1", dt=0.1, is_use_mtv_distance=True,
+                                           rew_method="ttc", is_ego_view=False, is_partial_observation=False, is_apply_mask=True, is_observe_vertices=False,
+                                           is_obs_steering=True),
+    "roundabout6_full_bird_k3": dict(T=32, B=3, seed=54, mode_pattern=[1, 1, 0], n_agents=6, scenario_type="roundabout_2", dt=0.1, is_use_mtv_distance=True,
+                                     rew_method="distance_sparse", is_ego_view=False, is_partial_observation=False, is_apply_mask=False, n_nearing_agents_observed=3,
+                                     is_observe_ref_path_other_agents=True, is_observe_distance_to_center_line=False),
+    "cpm8_full_bird_pad": dict(T=24, B=3, seed=55, mode_pattern=[1, 0, 1], n_agents=8, scenario_type="cpm_entire", dt=0.05, is_use_mtv_distance=False,
+                               rew_method="distance", is_ego_view=False, is_partial_observation=False, is_apply_mask=False, is_using_opponent_modeling=True,
+                               is_observe_distance_to_agents=False, is_observe_distance_to_boundaries=False),
     # BASELINE config 4: 32 agents on the on-ramp map.  The reference's rejection sampler cannot place them, so the
     # start is injected (Parameters.predefined_ref_path_idx / init_state); vehicles overlap from the first step on, every env is "done" at
     # every step and none is reset: non-reset steps only, as the survey prescribes for this configuration

@@ -109,7 +109,7 @@ class OracleEnv:
         self.map = map_table
         self._map_struct = map_table.as_struct()
         self.B, self.N, self.K = cfg.n_envs, cfg.n_agents, cfg.n_nearing
-        self.D = capi.obs_dim(self.K, int(getattr(self.cfg, "obs_flags", 0)), self.n_short_term)
+        self.D = capi.obs_dim(self.K, int(getattr(self.cfg, "obs_flags", 0)), self.n_short_term, self.N)
         h = C.c_void_p()
         rc = self.lib.create(C.byref(cfg), C.byref(self._map_struct), 0, None, C.byref(h))
         if rc != 0:

@@ -309,6 +309,53 @@ def test_fp32_rollout_equals_stepwise_fp32_calls_with_observation_noise():
         ac.close()
 
 
+def test_actor_rollout_on_a_short_term_build_variant_equals_stepwise_calls():
+    """An env with n_points_short_term = 5 lives in libsigmaenv_ns5.so; Actor / Critic must drive it through THAT library (they bound the
+    default NS = 3 build, whose step kernel then ran on buffers laid out for NS = 5).  rollout == actor forward + fused step, call by call, bit for bit,
+    and the critic reads the NS = 5 observation width."""
+    import torch
+    from sigmarl_amd import capi
+    from sigmarl_amd.actor import Actor, Critic, make_mlp
+    from sigmarl_amd.env import SigmaEnv
+    from sigmarl_amd.params import Parameters
+    from sigmarl_amd.shard import slab_width
+
+    setups = []
+    for _ in range(2):
+        torch.manual_seed(2)
+        env = SigmaEnv(Parameters(n_agents=8, scenario_type="cpm_entire", is_use_mtv_distance=False, is_apply_mask=False, is_obs_noise=False, n_points_short_term=5),
+                       n_envs=64, device="cuda:0")
+        env.reset_random(seed=4)
+        setups.append((env, Actor(make_mlp(env.D), low=[-1.0, -0.6], high=[1.0, 0.6])))
+    (env, actor), (env2, actor2) = setups
+    assert env.lib.n_short_term() == 5 and env.lib is not actor.lib and env.D == 4 + 2 * 5 + 11 * 2
+    T, W = 5, slab_width(env.N, env.D)
+    slab, slab2 = torch.zeros((T, env.B, W), device="cuda"), torch.zeros((T, env.B, W), device="cuda")
+    lp, lp2 = torch.zeros((T, env.B, env.N), device="cuda"), torch.zeros((T, env.B, env.N), device="cuda")
+    acts = torch.zeros((T, env.B, env.N, 2), device="cuda")
+    actor.rollout(env, T, slab=slab, log_prob=lp, actions=acts, seed=5, counter0=40)
+    env.sync()
+    a = torch.zeros((env2.B, env2.N, 2), device="cuda")
+    for t in range(T):
+        actor2.forward(env2, a, lp2[t], seed=5, counter=40 + t)
+        env2.set_slab(slab2[t])
+        env2.step_autoreset(a, seed=5, counter=40 + t)
+        env2.sync()
+        assert torch.equal(a, acts[t])
+    assert torch.equal(slab, slab2) and torch.equal(lp, lp2)
+    for w in (capi.BUF_OBS, capi.BUF_STATE, capi.BUF_TIMER, capi.BUF_REWARD, capi.BUF_SHORT_TERM):
+        assert torch.equal(env.buffer(w), env2.buffer(w))
+    assert torch.isfinite(env.buffer(capi.BUF_STATE)).all() and float(slab.abs().max()) < 1e3
+    torch.manual_seed(7)
+    ref = make_mlp(env.N * env.D, n_out=1).cuda()
+    v = Critic(ref).values(env)
+    want = ref(env.obs.reshape(env.B, -1)).reshape(env.B, 1, 1).expand(env.B, env.N, 1)
+    assert float((v - want).abs().max()) <= 1e-5
+    for e, ac in setups:
+        e.close()
+        ac.close()
+
+
 def test_actor_for_an_observation_width_the_bf16_kernel_does_not_take():
     """is_obs_steering gives obs_dim 35: the exact-fp32 network takes any width, the bf16 kernel only 8 / 16 / 24 / 32 -- an Actor can be built and run
     in fp32, and asking it for bf16 raises a clear error instead of failing at construction."""

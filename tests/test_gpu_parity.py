@@ -53,7 +53,7 @@ def test_hip_vs_reference_goldens(name):
         assert err <= tol, (key, err, str(rep))
 
 
-def _compare_all(dev, ora, tag):
+def _compare_all(dev, ora, tag, diff_by_buffer=None):
     n_float_diff = 0
     for which in INT_BUFS:
         a, b = dev.get(which), ora.get(which)
@@ -64,7 +64,10 @@ def _compare_all(dev, ora, tag):
         d = np.where(both_inf, 0.0, np.abs(a.astype(np.float64) - b.astype(np.float64)))
         assert d.max() <= FTOL, f"{tag}: float buffer {which}: max |err| {d.max()}"
         if which != capi.BUF_OBS:  # the HIP observation uses the rotation form of the ego transform (no atan2): ~1e-7 off, by design
-            n_float_diff += int((a != b).sum() - (np.isnan(a) & np.isnan(b)).sum())
+            nd = int((a != b).sum() - (np.isnan(a) & np.isnan(b)).sum())
+            n_float_diff += nd
+            if nd and diff_by_buffer is not None:
+                diff_by_buffer[which] = diff_by_buffer.get(which, 0) + nd
     return n_float_diff
 
 
@@ -97,6 +100,7 @@ def test_hip_vs_oracle_seeded(scen, N, B, mtv, rew, dt, testing, steps):
     _compare_all(dev, ora, "after initial reset")
     rng = np.random.default_rng(123)
     n_diff = 0
+    by_buf = {}
     seen_done = seen_req = 0
     for t in range(steps):
         act = np.stack([rng.uniform(-0.2, 1.3, (B, N)), rng.uniform(-0.7, 0.7, (B, N))], axis=-1).astype(np.float32)
@@ -104,19 +108,19 @@ def test_hip_vs_oracle_seeded(scen, N, B, mtv, rew, dt, testing, steps):
             act = np.stack([rng.uniform(0.0, 0.3, (B, N)), rng.uniform(-0.05, 0.05, (B, N))], axis=-1).astype(np.float32)
         dev.step(act)
         ora.step(act)
-        n_diff += _compare_all(dev, ora, f"step {t}")
+        n_diff += _compare_all(dev, ora, f"step {t}", by_buf)
         seen_done += int(ora.get(capi.BUF_DONE).sum())
         seen_req += int(ora.get(capi.BUF_COL_FLAGS)[..., 3].sum())
         dev.auto_reset(5, t + 1, pf, pc)
         ora.auto_reset(5, t + 1, pf, pc)
-        n_diff += _compare_all(dev, ora, f"reset after step {t}")
+        n_diff += _compare_all(dev, ora, f"reset after step {t}", by_buf)
     assert seen_done > 0
     if testing:
         assert seen_req > 0  # device-side per-agent resets (reset requests of unfinished envs) were exercised
-    # the two sides share the arithmetic contract: apart from the observation rows (see _compare_all) expect (almost) no
-    # differing fp32 word at all
+    # the two sides share the arithmetic contract ("HIP vs oracle agrees on every fp32 word"): apart from the observation rows
+    # (see _compare_all) NO fp32 word may differ -- the observed count is asserted, and a failure names the buffers that differ
     print(f"{scen} N={N} B={B}: differing non-observation fp32 words over the run: {n_diff}; per-agent reset requests served: {seen_req}")
-    assert n_diff <= 64
+    assert n_diff == 0, f"{n_diff} differing fp32 words, by buffer id: {by_buf}"
     dev.close()
     ora.close()
 
@@ -836,6 +840,11 @@ OBS_VARIANTS = [
     dict(is_using_opponent_modeling=True, is_ego_view=False, is_obs_steering=True),
     dict(n_points_short_term=5, is_observe_ref_path_other_agents=True, is_obs_steering=True),        # the switches in another build variant (libsigmaenv_ns5.so)
     dict(n_points_short_term=2, is_ego_view=False, is_observe_distance_to_boundaries=False, is_using_opponent_modeling=True),
+    # full observation (is_partial_observation=False; bird view only): ALL agents' features in every row, observation_provider_rt.py:756-851
+    dict(is_ego_view=False, is_partial_observation=False),
+    dict(is_ego_view=False, is_partial_observation=False, is_observe_vertices=False, is_obs_steering=True, is_observe_ref_path_other_agents=True, is_apply_mask=True),
+    dict(is_ego_view=False, is_partial_observation=False, is_observe_distance_to_agents=False, is_observe_distance_to_boundaries=False, is_using_opponent_modeling=True,
+         n_nearing_agents_observed=4),
 ]
 
 
@@ -855,8 +864,10 @@ def test_observation_variants_hip_vs_oracle(kw):
     cfg = make_config(p, mp, B)
     assert cfg.obs_flags != 0
     dev, ora = _hip_env(cfg, mp), ob.OracleEnv(cfg, mp)
-    D = capi.obs_dim(2, cfg.obs_flags, p.n_points_short_term)
-    assert dev.D == D == ora.D and dev.env.lib.obs_dim_ex(2, cfg.obs_flags) == D and D != 32
+    D = capi.obs_dim(cfg.n_nearing, cfg.obs_flags, p.n_points_short_term, N)
+    assert dev.D == D == ora.D and dev.env.lib.obs_dim_full(N, cfg.n_nearing, cfg.obs_flags) == D and D != 32
+    if not (cfg.obs_flags & capi.OBS_FULL):
+        assert dev.env.lib.obs_dim_ex(cfg.n_nearing, cfg.obs_flags) == D
     dev.env.buffer(capi.BUF_DONE).fill_(1)
     ora.get(capi.BUF_DONE, copy=False)[:] = 1
     pf, pc = mp.list_first[0], mp.list_count[0]
@@ -880,6 +891,48 @@ def test_observation_variants_hip_vs_oracle(kw):
         dev.env.set_slab(torch.zeros((B, N * (D + 1) + 1), device="cuda"))
     dev.close()
     ora.close()
+
+
+def test_full_observation_16_agents_hip_vs_oracle_and_refusals():
+    """SURVEY row a12, is_partial_observation=False at the metric's agent count (16 agents, sensor noise on): the row is 14 + 16 x (8 + 2 + 16) = 430 wide,
+    HIP == oracle on every buffer through steps and device-side resets (the oracle is pinned on four reference trajectories, tests/golden/traj_*full_bird*),
+    its distance block is zero before the noise, SIGMAENV_BUF_NEARING stays zero; the shapes the reference's reshape refuses are refused."""
+    N, B = 16, 48
+    p = Parameters(n_agents=N, scenario_type="cpm_entire", is_use_mtv_distance=True, rew_method="ttc", dt=0.05, is_apply_mask=True, is_obs_noise=True,
+                   obs_noise_level=0.05, random_seed=11, max_steps=9, is_ego_view=False, is_partial_observation=False)
+    mp = load_map("cpm_entire")
+    cfg = make_config(p, mp, B)
+    assert cfg.obs_flags & capi.OBS_FULL
+    dev, ora = _hip_env(cfg, mp), ob.OracleEnv(cfg, mp)
+    assert dev.D == ora.D == 5 + 6 + 3 + N * (8 + 2 + N) == 430
+    dev.env.buffer(capi.BUF_DONE).fill_(1)
+    ora.get(capi.BUF_DONE, copy=False)[:] = 1
+    pf, pc = mp.list_first[0], mp.list_count[0]
+    dev.auto_reset(4, 0, pf, pc)
+    ora.auto_reset(4, 0, pf, pc)
+    _compare_all(dev, ora, "after initial reset")
+    rng = np.random.default_rng(8)
+    for t in range(8):
+        act = np.stack([rng.uniform(-0.2, 1.3, (B, N)), rng.uniform(-0.7, 0.7, (B, N))], axis=-1).astype(np.float32)
+        dev.step(act)
+        ora.step(act)
+        _compare_all(dev, ora, f"step {t}")
+        dev.auto_reset(4, t + 1, pf, pc)
+        ora.auto_reset(4, t + 1, pf, pc)
+        _compare_all(dev, ora, f"reset after step {t}")
+    obs = dev.get(capi.BUF_OBS)
+    assert not dev.get(capi.BUF_NEARING).any()
+    others = obs[..., 14:].reshape(B, N, 2, -1)          # K = 2 chunks of [8 agents' vertices | their velocities | 8 rows of the zeroed distance matrix]
+    dist = others[..., 8 * 8 + 8 * 2:]
+    assert dist.shape[-1] == 8 * N and (dist >= 0).all() and (dist < cfg.obs_noise_level).all()   # zero + noise in [0, level)
+    dev.close()
+    ora.close()
+    for kw in (dict(is_ego_view=True), dict(is_ego_view=False, n_agents=5, n_nearing_agents_observed=2), dict(is_ego_view=False, n_agents=6, n_nearing_agents_observed=4, is_obs_steering=True)):
+        with pytest.raises(NotImplementedError):
+            make_config(Parameters(**dict(dict(n_agents=4, scenario_type="cpm_entire", is_partial_observation=False), **kw)), mp, 4)
+    lib = capi.load_library()
+    assert lib.obs_dim_full(5, 2, capi.OBS_FULL | capi.OBS_BIRD_VIEW) < 0 and lib.obs_dim_full(4, 2, capi.OBS_FULL) < 0
+    assert lib.obs_dim_full(4, 2, capi.OBS_FULL | capi.OBS_BIRD_VIEW) == 70
 
 
 @pytest.mark.parametrize("noise", [False, True])

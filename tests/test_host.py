@@ -191,7 +191,7 @@ def make(lo, hi):
 env = make(b0, b1)
 full = make(0, TOTAL) if rank == 0 else None
 CH = 2  # steps per chunk: T = 3 steps -> one full chunk + one partial chunk flushed at the end
-ex = RolloutExchange(b1 - b0, N, env.D, CH, "cpu", dst=0)
+ex = RolloutExchange(b1 - b0, N, env.D, CH, "cpu", dst=0, mode="gather")
 rng = np.random.default_rng(0)
 ref = []
 for t in range(T):
@@ -217,7 +217,8 @@ if rank == 0:
 # the same rollout through the all-to-all exchange: rank r ends up with steps [r T/W, (r+1) T/W) of the chunk for ALL envs
 env2 = make(b0, b1)
 full2 = make(0, TOTAL)
-ex2 = RolloutExchange(b1 - b0, N, env2.D, 2, "cpu", mode="alltoall")
+ex2 = RolloutExchange(b1 - b0, N, env2.D, 2, "cpu")  # (the default mode)
+assert ex2.mode == "alltoall"
 rng = np.random.default_rng(0)
 ref2 = []
 for t in range(2):
@@ -265,7 +266,7 @@ assert tuple(obs.shape[:2]) == (hi - lo, TOTAL)
 for q in range(lo, hi):
     assert np.array_equal(obs[q - lo].numpy(), ref3[q][0]) and np.array_equal(rew[q - lo].numpy(), ref3[q][1]) and np.array_equal(done[q - lo].numpy(), ref3[q][2])
 try:  # shards of different size cannot share one exchange (ADVICE r1): loud error, no hang
-    RolloutExchange(3 + rank, N, env.D, 2, "cpu", dst=0)
+    RolloutExchange(3 + rank, N, env.D, 2, "cpu", dst=0, mode="gather")
     raise SystemExit("unequal shards were accepted")
 except ValueError:
     pass
@@ -302,6 +303,28 @@ def test_bench_dry_run_eight_ranks_gloo():
     assert d["dry_run"] is True and d["n_gpus"] == 8 and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "weak"
     c = d["config"]
     assert c["envs_total"] == 32768 and c["steps_per_launch"] == 20 and c["exchange"] == "alltoall" and c["time_slices"] == [0, 2, 5, 7, 10, 12, 15, 17, 20]
+
+
+def test_bench_gpus_without_a_launcher_relaunches_itself_and_a_mismatch_is_an_error():
+    """`python bench.py --gpus 2` with no rendezvous in the environment must not time ONE rank and print `n_gpus: 1`: it re-executes
+    itself under torch.distributed.run with 2 ranks (checked through --dry-run: gloo, no GPU).  Under a launcher whose WORLD_SIZE differs from --gpus it
+    exits non-zero without a JSON line."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--dry-run"], env=env, capture_output=True,
+                         text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["envs_total"] == 2 * rec["config"]["envs_per_gpu"] and rec["config"]["exchange"] == "alltoall"
+    assert "re-launching" in out.stderr
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--dry-run"],
+                         env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert bad.returncode != 0 and not [l for l in bad.stdout.splitlines() if l.strip().startswith("{")], bad.stdout[-1000:]
+    assert "torch.distributed.run" in bad.stderr
 
 
 @pytest.mark.parametrize("tag,testing", [("train", False), ("test", True)])

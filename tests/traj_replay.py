@@ -22,7 +22,8 @@ TRAJ_NAMES = ["cpm16_c2c", "cpm16_mtv", "intersection4_c2c", "onramp6_mtv", "cpm
               "intersection4_birdview_novert", "cpm8_boundary_points", "onramp4_boundary_points_bird", "intersection4_birdview_mask",
               "roundabout6_birdview_mask", "cpm8_birdview_mask", "cpm8_opponent_pad", "cpm8_ns5", "intersection4_ns2",
               "interchange6_mtv", "intersection5_6_testing", "roundabout1_5_c2c", "onramp2_6_mask", "interchange1_8_birdview",
-              "onramp2_8_testing_mtv", "interchange2_6_cbf", "cpmmixed2_merge", "intersection8_6_bird_novert"]
+              "onramp2_8_testing_mtv", "interchange2_6_cbf", "cpmmixed2_merge", "intersection8_6_bird_novert",
+              "intersection4_full_bird", "intersection4_full_bird_novert", "roundabout6_full_bird_k3", "cpm8_full_bird_pad"]
 # The reference rounds the pseudo distance to fp16 and differentiates it numerically (pseudo_distance.py:118, cbf_qp.py:624-644): a
 # one-ulp difference in a float32 circle centre (torch's cos / sin -- a closed vector math library, within 1 ulp of the correctly rounded
 # value the oracle and the HIP path compute and NOT restatable, see include/sigma_trig_f32.h -- ) can flip
@@ -46,7 +47,7 @@ def load_fixture(name):
 def params_from_meta(meta) -> Parameters:
     keys = ["n_agents", "dt", "scenario_type", "is_use_mtv_distance", "rew_method", "is_testing_mode", "max_steps",
             "is_obs_noise", "is_apply_mask", "cpm_scenario_probabilities", "is_using_cbf_training", "is_solve_qp", "nom_controller_type", "reset_agent_fixed_duration", "is_obs_steering", "is_observe_ref_path_other_agents",
-            "is_observe_vertices", "is_observe_distance_to_agents", "is_observe_distance_to_center_line", "is_ego_view", "is_observe_distance_to_boundaries", "is_using_opponent_modeling", "n_points_short_term"]
+            "is_observe_vertices", "is_observe_distance_to_agents", "is_observe_distance_to_center_line", "is_ego_view", "is_observe_distance_to_boundaries", "is_using_opponent_modeling", "n_points_short_term", "is_partial_observation", "n_nearing_agents_observed"]
     kw = {k: meta[k] for k in keys if k in meta}
     return Parameters(**kw)
 
