@@ -70,6 +70,9 @@ struct Smem {
   uint32_t* acc32;            // per boundary task: bits of the four minimal SQUARED corner distances, [S * 2][4]
   int* nearn;                 // per boundary task: number of segments within the circumradius, [S * 2]
   uint8_t* nearl;             // indices of the boundary segments within the circumradius, [S * 2][NEAR_CAP]
+  uint8_t* fresh;             // [S] 1 = the agent was (re)placed and has not been stepped since (boundary points of the observation: another index shift,
+                              // world_state_rt.py:531-576 vs :686-724); the tile's copy of DevBufs::fresh, kept across the steps of one launch
+  unsigned long long* key64;  // [S] scratch of the observation's lanelet search (min over (squared distance bits << 32 | lanelet)); aliases acc64 / cmask
   // LEAN = the wave-per-tile layout of the step kernel: no escr / cmask / cand (its scan keeps them in registers), near-segment lists instead
   __device__ Smem(char* base, int S, int N, int K, int D, bool lean = false) {
     escr = reinterpret_cast<float4*>(base);  // first: the dynamic LDS base is 16-byte aligned
@@ -111,13 +114,15 @@ struct Smem {
     nearl = reinterpret_cast<uint8_t*>(i);
     if (lean) i += (S * 2 * NEAR_CAP + 3) / 4;
     col = reinterpret_cast<uint8_t*>(i);
+    fresh = col + (size_t)S * COL_STRIDE(N);
+    key64 = lean ? acc64 : cmask;
   }
   __host__ __device__ static size_t bytes(int S, int N, int K, int D, bool lean = false) {
     size_t f = (size_t)S * 8 + S * 10 * 2 + S * NS * 2 + S + S * 5 * 2 + S + (size_t)S * DIST_STRIDE(N) + (size_t)S * D + S * 3 + S * 2 + S * 2;
     size_t i = (size_t)S + S * 3 + S * (K > 0 ? K : 1) + S * 4 + S * 3 + 1;
     i += lean ? (1 + (size_t)S * 3 * 2 + (size_t)S * 2 * 4 + (size_t)S * 2 + (size_t)(ITEM_CAP(S) + 1) / 2 + (size_t)(S * 2 * NEAR_CAP + 3) / 4)
               : ((size_t)S * 3 * 2 + (size_t)S * 3 * (CAND_LIST / 4));
-    return (lean ? 0 : ESCR_BYTES) + (f + i + 3 + (size_t)(N * (N - 1) / 2 + 1) / 2) * 4 + (size_t)S * COL_STRIDE(N) + 16;
+    return (lean ? 0 : ESCR_BYTES) + (f + i + 3 + (size_t)(N * (N - 1) / 2 + 1) / 2) * 4 + (size_t)S * COL_STRIDE(N) + (((size_t)S + 3) & ~(size_t)3) + 16;
   }
 };
 
@@ -144,12 +149,72 @@ struct Grp {
   __device__ static __forceinline__ void sync() { if (WAVE) wave_sync(); else __syncthreads(); }
 };
 
+// Row layout of the observation for obs_flags != 0 (_observe_self / _observe_other_agents, observation_provider_rt.py:803-925; include/sigmaenv.h):
+//   [own]     bird: position 2, rotation 1, velocity 2 | ego: speed 1;  steering?;  short-term path 2 NS;  distance to the centre line?;  boundary distances 2 | points 20
+//   [other k] vertices 8 | position 2, rotation, length, width;  velocity 2;  steering?;  distance?;  its short-term path 2 NS?
+//   placeholders 2 K?
+// SIGMAENV_OBS_FULL (is_partial_observation == False, :756-851; bird view): [own] as above, then the features of ALL N agents, every feature's flat per-env array cut
+// into K chunks and the chunks interleaved (see observe_tile).  Plain integers: the same on the host (sizes) and in the kernels.
+struct ObsLayout {
+  int F, bird, full, p_steer, p_short, p_dcen, p_bnd, n_bnd_pts, own_w, oth_w, q_vel, q_steer, q_dist, q_ref, n_oth_pts, T1, pad, D, DL;
+  int W_oth;  // FULL: total width of the [others] part per env (N x the sum of the feature widths)
+  enum { F_VERT, F_POS, F_ROT, F_LEN, F_WID, F_VEL, F_STEER, F_DIST, F_REF };
+  // FULL: the idx-th feature of the [others] part in row order (no arrays: the struct lives in registers)
+  __host__ __device__ bool feature(int idx, int N, int& kind, int& wid) const {
+    int n = 0;
+#define SIGMA_FEAT(cond, k_, w_) if (cond) { if (idx == n) { kind = (k_); wid = (w_); return true; } ++n; }
+    const bool nv = (F & SIGMAENV_OBS_NO_VERTICES) != 0;
+    SIGMA_FEAT(!nv, F_VERT, 8)
+    SIGMA_FEAT(nv, F_POS, 2) SIGMA_FEAT(nv, F_ROT, 1) SIGMA_FEAT(nv, F_LEN, 1) SIGMA_FEAT(nv, F_WID, 1)
+    SIGMA_FEAT(true, F_VEL, 2)
+    SIGMA_FEAT((F & SIGMAENV_OBS_STEERING) != 0, F_STEER, 1)
+    SIGMA_FEAT(!(F & SIGMAENV_OBS_NO_DIST_AGENTS), F_DIST, N)
+    SIGMA_FEAT((F & SIGMAENV_OBS_REF_OTHERS) != 0, F_REF, 2 * NS)
+#undef SIGMA_FEAT
+    return false;
+  }
+  __host__ __device__ ObsLayout(int F_, int N, int K) {
+    F = F_;
+    bird = (F & SIGMAENV_OBS_BIRD_VIEW) != 0;
+    full = (F & SIGMAENV_OBS_FULL) != 0;
+    int p = bird ? 5 : 1;
+    p_steer = (F & SIGMAENV_OBS_STEERING) ? p++ : -1;
+    p_short = p; p += 2 * NS;
+    p_dcen = (F & SIGMAENV_OBS_NO_DIST_CENTER) ? -1 : p++;
+    p_bnd = p; n_bnd_pts = (F & SIGMAENV_OBS_BOUNDARY_POINTS) ? 10 : 0; p += n_bnd_pts ? 20 : 2;
+    own_w = p;
+    int q = (F & SIGMAENV_OBS_NO_VERTICES) ? 5 : 8;
+    q_vel = q; q += 2;
+    q_steer = (F & SIGMAENV_OBS_STEERING) ? q++ : -1;
+    q_dist = (F & SIGMAENV_OBS_NO_DIST_AGENTS) ? -1 : q++;
+    q_ref = (F & SIGMAENV_OBS_REF_OTHERS) ? q : -1;
+    if (q_ref >= 0) q += 2 * NS;
+    oth_w = q;
+    n_oth_pts = ((F & SIGMAENV_OBS_NO_VERTICES) ? 1 : 4) + ((F & SIGMAENV_OBS_REF_OTHERS) ? NS : 0);
+    pad = (F & SIGMAENV_OBS_OPPONENT_PAD) ? 2 * K : 0;
+    W_oth = 0;
+    if (full) {
+      const int wsum = ((F & SIGMAENV_OBS_NO_VERTICES) ? 5 : 8) + 2 + ((F & SIGMAENV_OBS_STEERING) ? 1 : 0) + ((F & SIGMAENV_OBS_NO_DIST_AGENTS) ? 0 : N) +
+                       ((F & SIGMAENV_OBS_REF_OTHERS) ? 2 * NS : 0);
+      W_oth = N * wsum;
+      T1 = NS + n_bnd_pts;                    // only the [own] points are transformed per agent
+      D = own_w + W_oth + pad;
+      DL = own_w + (W_oth + N - 1) / N;       // LDS staging: the [own] blocks per agent + ONE copy of the [others] part per env
+    } else {
+      T1 = NS + n_bnd_pts + K * n_oth_pts;
+      D = own_w + K * oth_w + pad;
+      DL = D;
+    }
+  }
+};
+
 // what a workgroup (or, in the step kernel, a wavefront) covers
 struct Tile {
-  int env0, nenv, slots, N, K, D;
+  int env0, nenv, slots, N, K, D, DL;  // D: width of the observation row; DL: floats per agent slot of its LDS staging area (= D unless SIGMAENV_OBS_FULL)
   size_t a0;  // global agent index of slot 0 (= env0 * N)
   __device__ Tile(const sigmaenv_config_t& c, int G, int tile_index = -1) {
-    N = c.n_agents; K = c.n_nearing; D = 4 + 2 * NS + 11 * K;
+    N = c.n_agents; K = c.n_nearing; D = 4 + 2 * NS + 11 * K; DL = D;
+    if (c.obs_flags != 0) { const ObsLayout L(c.obs_flags, N, K); D = L.D; DL = L.DL; }
     env0 = (tile_index < 0 ? (int)blockIdx.x : tile_index) * G;
     nenv = min(G, c.n_envs - env0);
     slots = nenv * N;
@@ -599,9 +664,9 @@ __device__ inline void topk_nearest(const float* Drow, int N, int K, int* out) {
 // Rows are assembled in LDS and written out coalesced.  All threads of the block participate.
 // env_sel / n_sel: restrict the work to these envs of the tile (the reset tail only refreshes the envs it touched); the loops then run
 // over "virtual" slots v = (position in env_sel) * N + agent, so that the lanes stay densely used.
-template <bool WAVE = false>
-__device__ inline void observe_tile(const sigmaenv_config_t& c, const Smem& s, const DevBufs& g, const Tile& t, int ts_base = -1,
-                                    const int* env_sel = nullptr, int n_sel = 0, bool write_global = true, const int* tim = nullptr) {
+template <bool WAVE>
+__device__ __forceinline__ void observe_tile_default(const sigmaenv_config_t& c, const Smem& s, const DevBufs& g, const Tile& t,
+                                                     const int* env_sel, int n_sel, bool write_global, const int* tim) {
   // tim: the timer rows [nenv][4] of the tile's envs (LDS copy of the step kernel's step loop; default: SIGMAENV_BUF_TIMER) -- the observation
   // noise is keyed on an env's (episodes_reset, timer.step)
   const int N = t.N, K = t.K, D = t.D;
@@ -763,6 +828,265 @@ __device__ inline void observe_tile(const sigmaenv_config_t& c, const Smem& s, c
 #undef TSO
 }
 
+
+// ---- the observation for obs_flags != 0 --------------------------------------------------------------------------------------------------------------
+// _observe_self / _observe_other_agents of observation_provider_rt.py:594-925 with the quantities update_state prepares (:345-588), for every combination of
+// the SIGMAENV_OBS_* switches (include/sigmaenv.h; layout: ObsLayout), assembled from the tile in LDS exactly like the default row: lane per item, rows staged
+// in s.obs, noise, coalesced write-out -- so that every launch that refreshes observations (the fused step incl. its T-step loop and the rollout record, the
+// resets, sigmaenv_observe) produces the configured row itself.  Ego-view transforms use the rotation form of the default path.
+// Value k of agent slot sl's row in SIGMAENV_OBS_FULL mode, from the staging of observe_tile_variant: the [own] blocks of the `slots` agents, then ONE copy of the
+// [others] part per env (it does not depend on the observing agent in the bird view), placeholders zero; plus the sensor noise of element k.
+__device__ __forceinline__ float full_obs_value(const sigmaenv_config_t& c, const Smem& s, const Tile& t, const ObsLayout& L, int e, int i, int k, const int* tim) {
+  const int sl = e * t.N + i;
+  float v = k < L.own_w ? s.obs[sl * L.own_w + k] : (k < L.own_w + L.W_oth ? s.obs[t.slots * L.own_w + e * L.W_oth + (k - L.own_w)] : 0.0f);
+  if (c.obs_noise_level > 0.0f) v = v + obs_noise(c, c.env_index_base + t.env0 + e, i, k, tim[e * 4 + 3], tim[e * 4]);
+  return v;
+}
+
+template <bool WAVE>
+__device__ inline void observe_tile_variant(const sigmaenv_config_t& c, const Smem& s, const DevBufs& g, const Tile& t, const int* env_sel, int n_sel,
+                                            bool write_global, const int* tim) {
+  const int N = t.N, K = t.K, F = c.obs_flags;
+  const ObsLayout L(F, N, K);
+  const int D = L.full ? L.own_w : L.D;   // row stride of the staging area
+  const int Kv = L.full ? 0 : K;          // neighbours assembled per agent (FULL: none, the [others] part is assembled once per env below)
+  const int TID = Grp<WAVE>::tid(), NTHR = Grp<WAVE>::size();
+  const int n_env = env_sel ? n_sel : t.nenv;
+  const int n_slots = n_env * N;
+  auto real_slot = [&](int v) {
+    if (!env_sel) return v;
+    const int q = fdiv(v, g.mN);
+    return env_sel[q] * N + (v - q * N);
+  };
+  if (!tim) tim = g.timer + (size_t)t.env0 * 4;
+  const float n_pos = (float)((double)c.length * 10.0);      // normalizers.pos, road_traffic.py:588-592
+  const float n_v = c.max_speed;                              // :596
+  const float n_dl = (float)((double)c.lane_width * 3.0);    // :599-601
+  const float n_rot = (float)(2.0 * 3.141592653589793);      // normalizers.rot, :597
+  const float n_da = (float)((double)c.length * 10.0);       // normalizers.distance_agent, :605-607
+  const float nwx = c.world_x_dim, nwy = c.world_y_dim;      // normalizers.pos_world (bird view, :537-575)
+  const bool bird = L.bird != 0;
+  // ---- nearest neighbours (:629-636); the full observation has none and leaves nearing_agents_indices at zero
+  for (int w = TID; w < (L.full ? n_slots * K : n_slots); w += NTHR) {
+    if (L.full) {
+      const int v = w / (K > 0 ? K : 1), k = w - v * K;
+      s.near[real_slot(v) * K + k] = 0;
+    } else {
+      const int sl = real_slot(w);
+      topk_nearest(s.dist + sl * DIST_STRIDE(N), N, K, s.near + sl * K);
+    }
+  }
+  // ---- mask by lanelet relation (:638-665, map_manager.py:41-118): bird view only -- the agents' lanelets are computed in that branch of update_state only
+  // (:577-588) --, on maps whose parser lists neighbouring lanelets.  determine_current_lanelet: squared distance to every (zero-padded) centre-line point of
+  // every lanelet, minimum per lanelet, first lanelet with the smallest minimum == the minimum over (squared-distance bits, lanelet) of all (lanelet, point)
+  const bool lane_mask = bird && !L.full && c.is_apply_mask && g.n_lanelets > 0;
+  if (lane_mask) {
+    for (int v = TID; v < n_slots; v += NTHR) s.key64[real_slot(v)] = ~0ull;
+    Grp<WAVE>::sync();
+    const int LN = g.n_lanelets, LP = g.lanelet_pts;
+    for (int w = TID; w < n_slots * LN; w += NTHR) {
+      const int v = w / LN, l = w - v * LN;
+      const int sl = real_slot(v);
+      const float px = s.st[sl * 8], py = s.st[sl * 8 + 1];
+      const float2* c2 = reinterpret_cast<const float2*>(g.lanelet_centers) + (size_t)l * LP;
+      float md = INFINITY;
+      for (int q = 0; q < LP; ++q) {
+        const float2 cc = c2[q];
+        const float dx = px - cc.x, dy = py - cc.y;
+        md = fminf(md, dx * dx + dy * dy);
+      }
+      atomicMin(&s.key64[sl], ((unsigned long long)__float_as_uint(md) << 32) | (unsigned)l);
+    }
+  }
+  Grp<WAVE>::sync();
+  auto masked = [&](int sl, int ebase, int j) -> bool {  // observed neighbour j (agent index) of slot sl
+    if (!c.is_apply_mask) return false;
+    bool mk = s.dist[sl * DIST_STRIDE(N) + j] >= c.distance_mask_agents;
+    if (lane_mask) mk = mk || !((g.lanelet_neigh[(unsigned)s.key64[sl]] >> (unsigned)s.key64[ebase + j]) & 1ull);
+    return mk;
+  };
+  // ---- points: own short-term path, own boundary points, per neighbour its vertices (or position) and its short-term path
+  const int T1 = L.T1;
+  for (int w = TID; w < n_slots * T1; w += NTHR) {
+    const int v = fdiv(w, g.mVT1), q = w - v * T1;
+    const int sl = real_slot(v);
+    const int ebase = fdiv(sl, g.mN) * N;
+    const float* si = s.st + sl * 8;
+    float tx, ty;
+    int pos;
+    bool mk = false;
+    if (q < NS) {  // [own] short-term reference path (:451-460, :564-571, :893-897)
+      tx = s.shrt[sl * NS * 2 + 2 * q]; ty = s.shrt[sl * NS * 2 + 2 * q + 1];
+      pos = L.p_short + 2 * q;
+    } else if (q < NS + L.n_bnd_pts) {
+      // [own] the 5 points of each boundary around its closest point instead of the distances (:905-922; world_state_rt.py:686-724: get_short_term_reference_path
+      // with sample_interval 1 on the PADDED boundary polyline, the loop rule with the centre line's point count; index shift -2 after a step, +1 for an agent
+      // that was (re)placed and not stepped since (:531-576); a negative index counts from the end of the padded tensor)
+      const int r = q - NS, side = r >= 5 ? 1 : 0, kk = r - 5 * side;
+      const int path = s.path[sl];
+      const int n = g.bnd_n_center[path];
+      int id = kk + s.cp[sl * 3 + 1 + side] + (s.fresh[sl] ? 1 : -2);
+      if (g.bnd_is_loop[path] && id >= n - 1) id = (id + 1) % n;
+      if (id < 0) id += g.bnd_P;
+      const float2 pt = reinterpret_cast<const float2*>(g.bnd_left + (size_t)side * g.bnd_poly_stride + (size_t)path * g.bnd_P * 2)[id];
+      tx = pt.x; ty = pt.y;
+      pos = L.p_bnd + 2 * r;
+    } else {       // [others] (:803-853), masks (:638-749)
+      const int r = q - NS - L.n_bnd_pts, k = r / L.n_oth_pts, u = r - k * L.n_oth_pts;
+      const int j = s.near[sl * K + k], sj = ebase + j, base = L.own_w + k * L.oth_w;
+      mk = masked(sl, ebase, j);
+      const int nv = (F & SIGMAENV_OBS_NO_VERTICES) ? 1 : 4;
+      if (u < nv) {
+        if (F & SIGMAENV_OBS_NO_VERTICES) { tx = s.st[sj * 8]; ty = s.st[sj * 8 + 1]; }       // position (:429-434, :672-680)
+        else { tx = s.vnew[sj * 10 + 2 * u]; ty = s.vnew[sj * 10 + 2 * u + 1]; }              // vertices (:485-492, :731-737)
+        pos = base + 2 * u;
+      } else {                                                                                 // its short-term path (:451-460, :721-729)
+        tx = s.shrt[sj * NS * 2 + 2 * (u - nv)]; ty = s.shrt[sj * NS * 2 + 2 * (u - nv) + 1];
+        pos = base + L.q_ref + 2 * (u - nv);
+      }
+    }
+    float ox, oy;
+    if (bird) {
+      ox = tx / nwx; oy = ty / nwy;
+    } else {  // ego view: rel = R(-psi_i) (p - p_i), helper_scenario.py:1241-1273
+      const float dx = tx - si[0], dy = ty - si[1];
+      const float ci = s.cs[sl * 2], sn = s.cs[sl * 2 + 1];
+      ox = (dx * ci + dy * sn) / n_pos;
+      oy = (dy * ci - dx * sn) / n_pos;
+    }
+    s.obs[sl * D + pos] = mk ? 1.0f : ox;
+    s.obs[sl * D + pos + 1] = mk ? 1.0f : oy;
+  }
+  // ---- velocities: own (:547-549, :864-887) and the observed neighbours' (:439-449, :717-719)
+  const int T2 = Kv + 1;
+  for (int w = TID; w < n_slots * T2; w += NTHR) {
+    const int v = Kv ? fdiv(w, g.mT2) : w, q = w - v * T2;
+    const int sl = real_slot(v);
+    const int ebase = fdiv(sl, g.mN) * N;
+    const float* si = s.st + sl * 8;
+    if (q == 0) {
+      if (bird) { s.obs[sl * D + 3] = si[5] / n_v; s.obs[sl * D + 4] = si[6] / n_v; }
+      else s.obs[sl * D] = norm2(si[5], si[6]) / n_v;
+    } else {
+      const int k = q - 1, j = s.near[sl * K + k], sj = ebase + j, base = L.own_w + k * L.oth_w + L.q_vel;
+      const bool mk = masked(sl, ebase, j);
+      const float* sjp = s.st + sj * 8;
+      if (bird) {
+        s.obs[sl * D + base] = mk ? 0.0f : sjp[5] / n_v;
+        s.obs[sl * D + base + 1] = mk ? 0.0f : sjp[6] / n_v;
+      } else {
+        const float va = norm2(sjp[5], sjp[6]);
+        const float ci = s.cs[sl * 2], si_ = s.cs[sl * 2 + 1], cj = s.cs[sj * 2], sj_ = s.cs[sj * 2 + 1];
+        const float cr = cj * ci + sj_ * si_, sr = sj_ * ci - cj * si_;  // cos / sin of (psi_j - psi_i)
+        s.obs[sl * D + base] = mk ? 0.0f : (va * cr) / n_v;
+        s.obs[sl * D + base + 1] = mk ? 0.0f : (va * sr) / n_v;
+      }
+    }
+  }
+  // ---- scalars, one lane per agent
+  for (int v = TID; v < n_slots; v += NTHR) {
+    const int sl = real_slot(v);
+    const int ebase = fdiv(sl, g.mN) * N;
+    const float* si = s.st + sl * 8;
+    float* ob = s.obs + sl * D;
+    if (bird) {                                                                                   // [own] position, rotation (:862-877)
+      ob[0] = si[0] / nwx; ob[1] = si[1] / nwy;
+      ob[2] = angle_eliminate_two_pi(si[2]) / n_rot;
+    }
+    if (L.p_steer >= 0) ob[L.p_steer] = angle_eliminate_two_pi(si[4]) / n_rot;                    // :356-360, :392, :888-892
+    if (L.p_dcen >= 0) ob[L.p_dcen] = s.dref[sl] / n_dl;                                          // :376-378, :898-904
+    if (!L.n_bnd_pts) {
+      float ml = INFINITY, mr = INFINITY;
+#pragma unroll
+      for (int q = 0; q < 5; ++q) { ml = fminf(ml, s.dleft[sl * 5 + q]); mr = fminf(mr, s.dright[sl * 5 + q]); }
+      ob[L.p_bnd] = ml / n_dl;                                                                    // :379-386
+      ob[L.p_bnd + 1] = mr / n_dl;
+    }
+    for (int k = 0; k < Kv; ++k) {
+      const int j = s.near[sl * K + k], sj = ebase + j, base = L.own_w + k * L.oth_w;
+      const bool mk = masked(sl, ebase, j);
+      const float* sjp = s.st + sj * 8;
+      if (F & SIGMAENV_OBS_NO_VERTICES) {                                                         // rotation, length, width (:437, :551-553, :683-698)
+        ob[base + 2] = (mk ? 0.0f : (bird ? angle_eliminate_two_pi(sjp[2]) : angle_eliminate_two_pi(sjp[2] - si[2]))) / n_rot;
+        ob[base + 3] = c.length / n_da;
+        ob[base + 4] = c.width / n_da;
+      }
+      if (L.q_steer >= 0) ob[base + L.q_steer] = mk ? 0.0f : angle_eliminate_two_pi(sjp[4]) / n_rot;   // :699-706
+      if (L.q_dist >= 0) ob[base + L.q_dist] = mk ? 1.0f : s.dist[sl * DIST_STRIDE(N) + j] / n_dl;      // :373-375, :747-749
+    }
+    if (!L.full) for (int k = 0; k < L.pad; ++k) ob[L.own_w + K * L.oth_w + k] = 0.0f;             // placeholders, padded BEFORE the noise (:606-611)
+  }
+  // ---- full observation: the features of ALL agents, once per env (:756-851).  Every feature tensor ([B,N,4,2] vertices, [B,N,2] velocities, ..., and the whole
+  // [B,N,N] distance matrix, zeroed entirely by `obs_distance_other_agents[indexing_tuple_2] = 0` in this view, :776-778) is reshaped to [B, n_nearing_agents, -1],
+  // i.e. its flat per-env array is cut into K equal chunks, and the row takes chunk 0 of every feature, then chunk 1, ...
+  if (L.full) {
+    const int Wc = L.W_oth / K;  // elements per row chunk
+    float* oth = s.obs + t.slots * L.own_w;
+    for (int w = TID; w < n_env * L.W_oth; w += NTHR) {
+      const int qe = w / L.W_oth, r = w - qe * L.W_oth;
+      const int e = env_sel ? env_sel[qe] : qe;
+      const int ck = r / Wc;
+      int rem = r - ck * Wc, wf = 1, kind = ObsLayout::F_DIST;
+      bool found = false;
+#pragma unroll
+      for (int f = 0; f < 9; ++f) {
+        int fk, fw;
+        if (!found && L.feature(f, N, fk, fw)) {
+          const int cw = N * fw / K;
+          if (rem < cw) { wf = fw; kind = fk; found = true; }
+          else rem -= cw;
+        }
+      }
+      const int flat = ck * (N * wf / K) + rem, j = flat / wf, q = flat - j * wf;
+      const int sj = e * N + j;
+      const float* sjp = s.st + sj * 8;
+      float val = 0.0f;                                                                            // F_DIST: zero (:776-778)
+      if (kind == ObsLayout::F_VERT) val = s.vnew[sj * 10 + q] / ((q & 1) ? nwy : nwx);           // :555-563
+      else if (kind == ObsLayout::F_POS) val = sjp[q] / (q ? nwy : nwx);                          // :539-546
+      else if (kind == ObsLayout::F_ROT) val = angle_eliminate_two_pi(sjp[2]) / n_rot;            // :550-553
+      else if (kind == ObsLayout::F_LEN) val = c.length / n_da;                                   // :387-389
+      else if (kind == ObsLayout::F_WID) val = c.width / n_da;                                    // :390-391
+      else if (kind == ObsLayout::F_VEL) val = sjp[5 + q] / n_v;                                  // :547-549
+      else if (kind == ObsLayout::F_STEER) val = angle_eliminate_two_pi(sjp[4]) / n_rot;          // :356-360, :392
+      else if (kind == ObsLayout::F_REF) val = s.shrt[sj * NS * 2 + q] / ((q & 1) ? nwy : nwx);   // :564-571
+      oth[e * L.W_oth + r] = val;
+    }
+  }
+  Grp<WAVE>::sync();
+  const int DR = L.D;  // public row width
+  if (!L.full && c.obs_noise_level > 0.0f) {  // sensor noise on every element of the rows just assembled (observation_provider_rt.py:613-618)
+    for (int w = TID; w < n_slots * DR; w += NTHR) {
+      const int v = w / DR, k = w - v * DR;
+      const int sl = real_slot(v);
+      const int e = fdiv(sl, g.mN), i = sl - e * N;
+      s.obs[sl * DR + k] = s.obs[sl * DR + k] + obs_noise(c, c.env_index_base + t.env0 + e, i, k, tim[e * 4 + 3], tim[e * 4]);
+    }
+    Grp<WAVE>::sync();
+  }
+  if (env_sel || write_global) {  // (neither: an intermediate step of the in-kernel step loop -- the rows stay in LDS for the record)
+    const int ND = N * DR, NK = N * K;
+    for (int q = 0; q < n_env; ++q) {
+      const int e = env_sel ? env_sel[q] : q;
+      float* go = g.obs + (t.a0 + (size_t)e * N) * DR;
+      if (L.full) {
+        for (int k = TID; k < ND; k += NTHR) { const int i = k / DR; go[k] = full_obs_value(c, s, t, L, e, i, k - i * DR, tim); }
+      } else {
+        for (int k = TID; k < ND; k += NTHR) go[k] = s.obs[e * ND + k];
+      }
+      for (int k = TID; k < NK; k += NTHR) g.nearing[(t.a0 + e * N) * K + k] = s.near[e * NK + k];
+    }
+  }
+}
+
+// VARIANTS = false compiles the non-default rows out (the fixed-shape instantiations of the step kernel are only launched with obs_flags == 0)
+template <bool WAVE = false, bool VARIANTS = true>
+__device__ __forceinline__ void observe_tile(const sigmaenv_config_t& c, const Smem& s, const DevBufs& g, const Tile& t, int ts_base = -1,
+                                             const int* env_sel = nullptr, int n_sel = 0, bool write_global = true, const int* tim = nullptr) {
+  (void)ts_base;
+  if (VARIANTS && c.obs_flags != 0) observe_tile_variant<WAVE>(c, s, g, t, env_sel, n_sel, write_global, tim);
+  else observe_tile_default<WAVE>(c, s, g, t, env_sel, n_sel, write_global, tim);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // device-side resets (used by the step kernel's phase R and by sigmaenv_auto_reset)
 // VMAS >= 1.4 call order restated per env by the step: world.step(); reward(a) for all a; observation(a) for all a; done()
@@ -818,7 +1142,7 @@ struct ResetPrefetch {
   bool have;  // the first env of this wavefront (e == wave) has its candidates here already
 };
 
-template <bool WAVE = false>
+template <bool WAVE = false, bool VARIANTS = true>
 __device__ __forceinline__ void auto_reset_tile(const sigmaenv_config_t& c, const DevMap& m, const DevBufs& g, const Smem& s, const Tile& t,
                                        const unsigned long long* s_mask, const int* s_full, uint64_t seed, uint64_t counter, int path_first,
                                        int path_count, int obs_mode, const ResetPrefetch& pre, int g_cap = 64, int* lds_tim = nullptr);
@@ -839,6 +1163,10 @@ __device__ inline void load_tile_for_observation(const Smem& s, const DevBufs& g
     float psi = g.state[(t.a0 + k) * 8 + 2];
     s.cs[k * 2] = cr_cos(psi);
     s.cs[k * 2 + 1] = cr_sin(psi);
+    // (read by the non-default observation rows only: boundary points around the closest boundary point of the agent's path)
+    s.path[k] = g.path[(t.a0 + k) * 4];
+    s.cp[k * 3 + 0] = g.closest[(t.a0 + k) * 3 + 0]; s.cp[k * 3 + 1] = g.closest[(t.a0 + k) * 3 + 1]; s.cp[k * 3 + 2] = g.closest[(t.a0 + k) * 3 + 2];
+    s.fresh[k] = g.fresh ? g.fresh[t.a0 + k] : 0;
   }
   __syncthreads();
 }
@@ -846,7 +1174,7 @@ __device__ inline void load_tile_for_observation(const Smem& s, const DevBufs& g
 __global__ void __launch_bounds__(256) sigmaenv_observe_kernel(sigmaenv_config_t c, DevBufs g, int G) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const Tile t(c, G);
-  Smem s(smem_raw, G * t.N, t.N, t.K, t.D);
+  Smem s(smem_raw, G * t.N, t.N, t.K, t.DL);
   load_tile_for_observation(s, g, t);
   observe_tile(c, s, g, t);
 }
@@ -871,7 +1199,7 @@ __global__ void sigmaenv_reset_scatter_kernel(DevBufs g, int N, int n, const int
 // per-env tail (road_traffic.py:902-923) for the envs of the tile whose bit is set in env_bits; with_obs: also a fresh
 // observation of the whole tile.  Expects s.st / s.path / s.vnew / s.cp (scan guesses) of the tile in LDS; agent_mask[e] is the
 // per-env agent bit mask, full[e] the full-env flag.  All threads of the block participate.
-template <bool WAVE = false>
+template <bool WAVE = false, bool VARIANTS = true>
 __device__ inline void reset_finish_body(const sigmaenv_config_t& c, const DevBufs& g, const Smem& s, const Tile& t,
                                          const unsigned long long* agent_mask, const int* full, int with_obs, int g_cap = 64, int* lds_tim = nullptr);
 __device__ inline void reset_derive_body(const sigmaenv_config_t& c, const DevMap& m, const DevBufs& g, const Smem& s, const Tile& t,
@@ -947,7 +1275,7 @@ __device__ inline void reset_derive_body(const sigmaenv_config_t& c, const DevMa
 // tail of every touched env: mutual distances, collisions cleared, prev_pos := pos, timer (road_traffic.py:902-923); with_obs:
 // also a fresh observation of the whole tile (2: every input of it is already in LDS).  Expects the derived state of the marked
 // agents in LDS and HBM.
-template <bool WAVE>
+template <bool WAVE, bool VARIANTS>
 __device__ inline void reset_finish_body(const sigmaenv_config_t& c, const DevBufs& g, const Smem& s, const Tile& t,
                                          const unsigned long long* agent_mask, const int* full, int with_obs, int g_cap, int* lds_tim) {
   const int N = t.N;
@@ -994,10 +1322,10 @@ __device__ inline void reset_finish_body(const sigmaenv_config_t& c, const DevBu
         env_sel[0] = cnt;
       }
       Grp<WAVE>::sync();
-      observe_tile<WAVE>(c, s, g, t, -1, env_sel + 1, env_sel[0], true, lds_tim);
+      observe_tile<WAVE, VARIANTS>(c, s, g, t, -1, env_sel + 1, env_sel[0], true, lds_tim);
     } else {
       load_tile_for_observation(s, g, t);
-      observe_tile<WAVE>(c, s, g, t);
+      observe_tile<WAVE, VARIANTS>(c, s, g, t);
     }
     TS2(6);
   }
@@ -1010,7 +1338,7 @@ __global__ void __launch_bounds__(512) sigmaenv_reset_derive_kernel(sigmaenv_con
   const Tile t(c, G);
   const int N = t.N;
   // all LDS lives in the one dynamic region (keeps its base 16-byte aligned): [Smem | masks | full flags | any]
-  unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(smem_raw + ((Smem::bytes(G * N, N, t.K, t.D) + 15) & ~(size_t)15));
+  unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(smem_raw + ((Smem::bytes(G * N, N, t.K, t.DL) + 15) & ~(size_t)15));
   int* s_full = reinterpret_cast<int*>(s_mask + MAX_G);
   int* s_any = s_full + MAX_G;
   if (threadIdx.x == 0) *s_any = 0;
@@ -1023,11 +1351,12 @@ __global__ void __launch_bounds__(512) sigmaenv_reset_derive_kernel(sigmaenv_con
   }
   __syncthreads();
   if (!*s_any) return;
-  Smem s(smem_raw, G * N, N, t.K, t.D);
+  Smem s(smem_raw, G * N, N, t.K, t.DL);
   for (int k = threadIdx.x; k < t.slots * 8; k += blockDim.x) s.st[k] = g.state[t.a0 * 8 + k];
   for (int k = threadIdx.x; k < t.slots * 10; k += blockDim.x) s.vnew[k] = g.vertices[t.a0 * 10 + k];
   for (int k = threadIdx.x; k < t.slots; k += blockDim.x) {
     s.path[k] = g.path[(t.a0 + k) * 4];
+    s.fresh[k] = g.fresh ? g.fresh[t.a0 + k] : 0;
     int pt = g.path[(t.a0 + k) * 4 + 3];  // the agent was placed at (or near) this centre-line point: guess for the pruned scan
     s.cp[k * 3 + 0] = pt; s.cp[k * 3 + 1] = pt; s.cp[k * 3 + 2] = pt;
   }
@@ -1159,6 +1488,7 @@ __device__ __forceinline__ void place_from_start_table(const DevMap& m, const De
 #pragma unroll
   for (int k = 0; k < 3; ++k) { const int cpk = __float_as_int(r[START_CP + k]); s.cp[sl * 3 + k] = cpk; g.closest[gi * 3 + k] = cpk; }
   s.path[sl] = path;
+  s.fresh[sl] = 1;
   if (g.fresh) g.fresh[gi] = 1;
   g.path[gi * 4 + 0] = path;
   if (full_env) g.path[gi * 4 + 1] = scenario_id;  // (kept by a per-agent reset; 0 unless cpm_mixed)
@@ -1172,7 +1502,7 @@ __device__ __forceinline__ void place_from_start_table(const DevMap& m, const De
 // agent up front and the FIRST feasible try wins, which is exactly the sequential loop's result for the same draws (bounded to
 // 64 tries; the reference loops without bound).  Then the deterministic reset as in sigmaenv_reset and a fresh observation.
 // All threads of the block participate.
-template <bool WAVE>
+template <bool WAVE, bool VARIANTS>
 __device__ __forceinline__ void auto_reset_tile(const sigmaenv_config_t& c, const DevMap& m, const DevBufs& g, const Smem& s, const Tile& t,
                                        const unsigned long long* s_mask, const int* s_full, uint64_t seed, uint64_t counter, int path_first,
                                        int path_count, int obs_mode, const ResetPrefetch& pre, int g_cap, int* lds_tim) {
@@ -1272,7 +1602,7 @@ __device__ __forceinline__ void auto_reset_tile(const sigmaenv_config_t& c, cons
   __threadfence_block();
   Grp<WAVE>::sync();
   TS2(2);
-  reset_finish_body<WAVE>(c, g, s, t, s_mask, s_full, obs_mode, g_cap, lds_tim);
+  reset_finish_body<WAVE, VARIANTS>(c, g, s, t, s_mask, s_full, obs_mode, g_cap, lds_tim);
 #undef TS2
 }
 
@@ -1285,7 +1615,7 @@ __global__ void __launch_bounds__(512) sigmaenv_auto_reset_kernel(sigmaenv_confi
   const Tile t(c, G);
   const int N = t.N;
   const int tid = threadIdx.x;
-  unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(smem_raw + ((Smem::bytes(G * N, N, t.K, t.D) + 15) & ~(size_t)15));
+  unsigned long long* s_mask = reinterpret_cast<unsigned long long*>(smem_raw + ((Smem::bytes(G * N, N, t.K, t.DL) + 15) & ~(size_t)15));
   int* s_full = reinterpret_cast<int*>(s_mask + MAX_G);
   int* s_any = s_full + MAX_G;
 #define TS2(k) PROF_TS2(g, tid, k)
@@ -1308,11 +1638,11 @@ __global__ void __launch_bounds__(512) sigmaenv_auto_reset_kernel(sigmaenv_confi
   }
   __syncthreads();
   if (!*s_any) return;
-  Smem s(smem_raw, G * N, N, t.K, t.D);
+  Smem s(smem_raw, G * N, N, t.K, t.DL);
   // untouched envs of the tile keep their state (needed for the tile-wide observation)
   for (int k = tid; k < t.slots * 8; k += blockDim.x) s.st[k] = g.state[t.a0 * 8 + k];
   for (int k = tid; k < t.slots * 10; k += blockDim.x) s.vnew[k] = g.vertices[t.a0 * 10 + k];
-  for (int k = tid; k < t.slots; k += blockDim.x) s.path[k] = g.path[(t.a0 + k) * 4];
+  for (int k = tid; k < t.slots; k += blockDim.x) { s.path[k] = g.path[(t.a0 + k) * 4]; s.fresh[k] = g.fresh ? g.fresh[t.a0 + k] : 0; }
   __syncthreads();
   ResetPrefetch none;
   none.have = false;
@@ -1361,8 +1691,7 @@ struct sigmaenv {
   float* lanelet_centers = nullptr;           // [n_lanelets, lanelet_pts, 2] zero-padded centre lines (sigmaenv_set_lanelets)
   unsigned long long* lanelet_neigh = nullptr;  // [n_lanelets] neighbour bit masks
   int n_lanelets = 0, lanelet_pts = 0;
-  float* obs_var = nullptr;       // [B,N,D_pub]: the public observation buffer when cfg.obs_flags != 0 (sigmaenv_obs_variant.inc)
-  int D_pub = 0;                  // its row width (= D for the default flags)
+  int DL = 0;                     // floats per agent slot of the kernels' LDS staging of the observation rows (= D unless SIGMAENV_OBS_FULL, see ObsLayout)
   int32_t* cbf_groups = nullptr;  // [B,N] group index of every vehicle (grouped CBF-QPs), formed by the first sigmaenv_cbf_qp call
   bool cbf_groups_valid = false;
   std::string err;
@@ -1465,9 +1794,14 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
   h->device = device_id;
   h->stream = reinterpret_cast<hipStream_t>(hip_stream);
   const int B = h->B = cfg->n_envs, N = h->N = cfg->n_agents, K = h->K = cfg->n_nearing;
-  h->D = sigmaenv_obs_dim(K);  // the fused kernels' own (default) row
-  h->D_pub = sigmaenv_obs_dim_full(N, K, cfg->obs_flags);
-  if (h->D_pub < 0) { delete h; return SIGMAENV_EINVAL; }
+  h->D = sigmaenv_obs_dim_full(N, K, cfg->obs_flags);  // the configured observation row: assembled by every kernel that refreshes observations (observe_tile)
+  if (h->D < 0) { delete h; return SIGMAENV_EINVAL; }
+  h->DL = h->D;
+  if (cfg->obs_flags != 0) {
+    const ObsLayout L(cfg->obs_flags, N, K);
+    if (L.D != h->D) { delete h; return SIGMAENV_EINVAL; }  // (the two statements of the layout agree by construction)
+    h->DL = L.DL;
+  }
   const int np = h->n_paths = map->n_paths, S = map->stride_points;
   for (int p = 0; p < np; ++p) {
     if (map->n_center[p] < 2 || map->n_left[p] < 2 || map->n_right[p] < 2 || map->n_center[p] > S || map->n_left[p] > S || map->n_right[p] > S) {
@@ -1643,11 +1977,6 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
     h->bufs[sp.id] = *sp.p;
     h->buf_bytes[sp.id] = sp.bytes;
   }
-  if (cfg->obs_flags != 0) {  // non-default observation switches: the public buffer is written by the variant kernel
-    ALLOC(h->obs_var, BN * h->D_pub * 4);
-    h->bufs[SIGMAENV_BUF_OBS] = h->obs_var;
-    h->buf_bytes[SIGMAENV_BUF_OBS] = BN * h->D_pub * 4;
-  }
   ALLOC(g.reset_mask, (size_t)B * 8);
   ALLOC(g.reset_full, (size_t)B);
   g.slab = nullptr;
@@ -1663,7 +1992,10 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
     g.mT2 = magic((unsigned)(K + 1));
     g.mTP = magic((unsigned)(N * (N - 1) / 2));
     g.mW = magic((unsigned)(N * (h->D + 1) + 1));
+    g.mVT1 = cfg->obs_flags != 0 ? magic((unsigned)ObsLayout(cfg->obs_flags, N, K).T1) : 0u;
   }
+  g.lanelet_centers = nullptr; g.lanelet_neigh = nullptr; g.n_lanelets = 0; g.lanelet_pts = 0;
+  g.bnd_left = h->map.left; g.bnd_n_center = h->map.n_center; g.bnd_is_loop = h->map.is_loop; g.bnd_poly_stride = h->map.poly_stride; g.bnd_P = h->map.P;
   g.dbg_ts = nullptr;
   g.dbg_ts2 = nullptr;
   g.dbg_skip = 0;
@@ -1699,7 +2031,7 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
     int v = atoi(e);
     if (v >= 64 && v <= 512 && v % 64 == 0) h->reset_block = v;
   }
-  h->smem_bytes = ((Smem::bytes(h->G * N, N, K, h->D) + 15) & ~(size_t)15) + MAX_G * 8 + MAX_G * 4 + 16 + (MAX_G + 1) * 4;  // masks, flags, counters, env list
+  h->smem_bytes = ((Smem::bytes(h->G * N, N, K, h->DL) + 15) & ~(size_t)15) + MAX_G * 8 + MAX_G * 4 + 16 + (MAX_G + 1) * 4;  // masks, flags, counters, env list
   if (h->smem_bytes > 64 * 1024) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_observe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem_bytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_reset_derive_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem_bytes);
@@ -1719,11 +2051,11 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
       return SIGMAENV_EHIP;
     }
     { const unsigned d = (unsigned)(wg * N); h->buf.mSG = d <= 1u ? 0u : (uint32_t)(((1ull << 32) + d - 1ull) / d); }
-    h->wave_spec = (K == 2 && ((N == 16 && wg == 1) || (N == 32 && wg == 1) || (N == 8 && wg == 2) || (N == 4 && wg == 4))) ? N * 256 + wg : 0;
+    h->wave_spec = (cfg->obs_flags == 0 && K == 2 && ((N == 16 && wg == 1) || (N == 32 && wg == 1) || (N == 8 && wg == 2) || (N == 4 && wg == 4))) ? N * 256 + wg : 0;
     if (const char* e = getenv("SIGMAENV_WAVE_SPEC")) { if (atoi(e) == 0) h->wave_spec = 0; }  // A/B: the generic instantiation
     h->wave_wpb = 1;
     if (const char* e = getenv("SIGMAENV_WPB")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) h->wave_wpb = v; }
-    h->wave_tile_lds = (((Smem::bytes(wg * N, N, K, h->D, true) + 15) & ~(size_t)15) + 16 * (size_t)wg + 16 + 16 * (size_t)wg + 15) & ~(size_t)15;  // tile | masks, flags, env list | timers
+    h->wave_tile_lds = (((Smem::bytes(wg * N, N, K, h->DL, true) + 15) & ~(size_t)15) + 16 * (size_t)wg + 16 + 16 * (size_t)wg + 15) & ~(size_t)15;  // tile | masks, flags, env list | timers
     const int tiles = (B + wg - 1) / wg;
     h->wave_grid = (tiles + h->wave_wpb - 1) / h->wave_wpb;
     if (h->wave_tile_lds * h->wave_wpb > 64 * 1024) {
@@ -1732,6 +2064,10 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_wave_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_wave_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_wave_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_wave_kernel<true, true, 0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_wave_kernel<true, false, 0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_wave_kernel<false, true, 0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_wave_kernel<false, false, 0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_wave_kernel<true, true, 16, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_wave_kernel<true, true, 32, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_wave_kernel<true, true, 8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1744,22 +2080,17 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
 }
 
 #include "sigmaenv_obs_variant.inc"
-// after every launch that refreshed the observations: the public row of the non-default observation switches
-static int launch_obs_variant(sigmaenv* h) {
-  if (!h->obs_var) return SIGMAENV_OK;
-  const size_t BN = (size_t)h->B * h->N;
-  hipLaunchKernelGGL(obsvar::sigmaenv_observe_variant_kernel, dim3((unsigned)((BN + 255) / 256)), dim3(256), 0, h->stream, h->cfg, h->map, h->buf, h->obs_var, h->D_pub,
-                     (const float*)h->lanelet_centers, (const unsigned long long*)h->lanelet_neigh, h->n_lanelets, h->lanelet_pts);
-  HIPCHK(h, hipGetLastError());
-  return SIGMAENV_OK;
-}
 
 extern "C" int sigmaenv_set_lanelets(sigmaenv_t* h, int32_t n_lanelets, int32_t max_points, const float* centers, const uint64_t* neighbors) {
   if (!h) return SIGMAENV_EINVAL;
   if (n_lanelets < 1 || n_lanelets > 64 || max_points < 1 || !centers || !neighbors) { h->err = "set_lanelets: 1..64 lanelets with their centre lines and neighbour masks"; return SIGMAENV_EINVAL; }
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  if (h->lanelet_centers) { dev_free(h, h->lanelet_centers); dev_free(h, h->lanelet_neigh); h->lanelet_centers = nullptr; h->lanelet_neigh = nullptr; h->n_lanelets = 0; }
+  if (h->lanelet_centers) {
+    dev_free(h, h->lanelet_centers); dev_free(h, h->lanelet_neigh);
+    h->lanelet_centers = nullptr; h->lanelet_neigh = nullptr; h->n_lanelets = 0;
+    h->buf.lanelet_centers = nullptr; h->buf.lanelet_neigh = nullptr; h->buf.n_lanelets = 0;
+  }
   int rc;
   if ((rc = dev_alloc(h, (void**)&h->lanelet_centers, (size_t)n_lanelets * max_points * 2 * sizeof(float))) != SIGMAENV_OK) return rc;
   if ((rc = dev_alloc(h, (void**)&h->lanelet_neigh, (size_t)n_lanelets * sizeof(uint64_t))) != SIGMAENV_OK) return rc;
@@ -1768,16 +2099,17 @@ extern "C" int sigmaenv_set_lanelets(sigmaenv_t* h, int32_t n_lanelets, int32_t 
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->n_lanelets = n_lanelets;
   h->lanelet_pts = max_points;
+  h->buf.lanelet_centers = h->lanelet_centers; h->buf.lanelet_neigh = h->lanelet_neigh; h->buf.n_lanelets = n_lanelets; h->buf.lanelet_pts = max_points;
   return SIGMAENV_OK;
 }
 
 extern "C" int sigmaenv_opponent_fill(sigmaenv_t* h, const float* actions) {
   if (!h || !actions) return SIGMAENV_EINVAL;
-  if (!(h->cfg.obs_flags & SIGMAENV_OBS_OPPONENT_PAD) || !h->obs_var) { h->err = "opponent_fill: the configuration has no placeholder columns (SIGMAENV_OBS_OPPONENT_PAD)"; return SIGMAENV_EINVAL; }
+  if (!(h->cfg.obs_flags & SIGMAENV_OBS_OPPONENT_PAD)) { h->err = "opponent_fill: the configuration has no placeholder columns (SIGMAENV_OBS_OPPONENT_PAD)"; return SIGMAENV_EINVAL; }
   HIPCHK(h, hipSetDevice(h->device));
   const size_t n = (size_t)h->B * h->N * h->cfg.n_nearing;
   if (n == 0) return SIGMAENV_OK;
-  hipLaunchKernelGGL(obsvar::sigmaenv_opponent_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->obs_var, h->D_pub, h->buf.nearing, actions, h->B, h->N,
+  hipLaunchKernelGGL(obsvar::sigmaenv_opponent_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->buf.obs, h->D, h->buf.nearing, actions, h->B, h->N,
                      h->cfg.n_nearing);
   HIPCHK(h, hipGetLastError());
   return SIGMAENV_OK;
@@ -1821,7 +2153,7 @@ static int launch_derive(sigmaenv* h, int with_obs) {
   // resets touch few envs: one env per workgroup (G = 1) keeps the untouched ones out of the way
   hipLaunchKernelGGL(sigmaenv_reset_derive_kernel, dim3(h->B), dim3(h->reset_block), h->smem_bytes, h->stream, h->cfg, h->map, h->buf, with_obs, 1);
   HIPCHK(h, hipGetLastError());
-  return with_obs ? launch_obs_variant(h) : SIGMAENV_OK;
+  return SIGMAENV_OK;
 }
 
 extern "C" int sigmaenv_reset(sigmaenv_t* h, int32_t n, const int32_t* env_idx, const int32_t* agent_idx, const int32_t* path_ids,
@@ -1898,6 +2230,9 @@ static int launch_step(sigmaenv* h, const float* actions, uint64_t seed, uint64_
     const bool par = 2 * h->wave_G * h->N <= 64;
     auto kern = h->map.fast_div ? (par ? sigmaenv_step_wave_kernel<true, true> : sigmaenv_step_wave_kernel<true, false>)
                                 : (par ? sigmaenv_step_wave_kernel<false, true> : sigmaenv_step_wave_kernel<false, false>);
+    if (h->cfg.obs_flags != 0)  // the instantiations that carry the non-default observation rows
+      kern = h->map.fast_div ? (par ? sigmaenv_step_wave_kernel<true, true, 0, 0, true> : sigmaenv_step_wave_kernel<true, false, 0, 0, true>)
+                             : (par ? sigmaenv_step_wave_kernel<false, true, 0, 0, true> : sigmaenv_step_wave_kernel<false, false, 0, 0, true>);
     if (h->map.fast_div) {  // fixed-shape instantiations (the plain-division variant of a map with degenerate segments stays generic)
       switch (h->wave_spec) {
         case 16 * 256 + 1: kern = sigmaenv_step_wave_kernel<true, true, 16, 1>; break;
@@ -1912,7 +2247,7 @@ static int launch_step(sigmaenv* h, const float* actions, uint64_t seed, uint64_
   }
   HIPCHK(h, hipGetLastError());
   timer_end(h, SIGMAENV_KERNEL_STEP, slot);
-  return launch_obs_variant(h);
+  return SIGMAENV_OK;
 }
 
 extern "C" int sigmaenv_step(sigmaenv_t* h, const float* actions) { return launch_step(h, actions, 0, 0, 0, 0); }
@@ -1935,7 +2270,6 @@ extern "C" int sigmaenv_step_autoreset_n(sigmaenv_t* h, const float* actions, in
     h->err = "step_autoreset_n: bad argument";
     return SIGMAENV_EINVAL;
   }
-  if (slab && h->obs_var) { h->err = "step_autoreset_n: the rollout record holds the default observation row; not available with obs_flags != 0"; return SIGMAENV_EINVAL; }
   if (n_steps > 1 && (h->cfg.rew_flags & (SIGMAENV_REW_CBF | SIGMAENV_REW_CBF_QP))) {
     // the CBF reward channels / the safe action of step t come from a separate launch between the policy and step t (sigmaenv_cbf_rewards / _qp)
     h->err = "step_autoreset_n: rew_method with \"cbf\" needs the CBF launch before every step; use sigmaenv_step_autoreset (or sigmaenv_rollout)";
@@ -1964,7 +2298,7 @@ extern "C" int sigmaenv_observe(sigmaenv_t* h) {
   HIPCHK(h, hipSetDevice(h->device));
   hipLaunchKernelGGL(sigmaenv_observe_kernel, dim3(h->grid), dim3(h->block), h->smem_bytes, h->stream, h->cfg, h->buf, h->G);
   HIPCHK(h, hipGetLastError());
-  return launch_obs_variant(h);
+  return SIGMAENV_OK;
 }
 
 extern "C" int sigmaenv_auto_reset(sigmaenv_t* h, uint64_t seed, uint64_t counter, int32_t path_first, int32_t path_count) {
@@ -1973,7 +2307,7 @@ extern "C" int sigmaenv_auto_reset(sigmaenv_t* h, uint64_t seed, uint64_t counte
   hipLaunchKernelGGL(sigmaenv_auto_reset_kernel, dim3(h->B), dim3(h->reset_block), h->smem_bytes, h->stream, h->cfg, h->map, h->buf, seed, counter,
                      (int)path_first, (int)path_count, 1);
   HIPCHK(h, hipGetLastError());
-  return launch_obs_variant(h);
+  return SIGMAENV_OK;
 }
 
 extern "C" int sigmaenv_get(sigmaenv_t* h, sigmaenv_buf_t which, void** dev_ptr, size_t* bytes) {
@@ -1994,7 +2328,6 @@ extern "C" int sigmaenv_sync(sigmaenv_t* h) {
 // to dev_ptr ([B, N*(D+1)+1]); the caller rotates the pointer through its rollout buffer.  NULL disables it.
 extern "C" int sigmaenv_set_slab(sigmaenv_t* h, void* dev_ptr) {
   if (!h) return SIGMAENV_EINVAL;
-  if (dev_ptr && h->obs_var) { h->err = "set_slab: the rollout record holds the default observation row; not available with obs_flags != 0"; return SIGMAENV_EINVAL; }
   h->buf.slab = reinterpret_cast<float*>(dev_ptr);
   return SIGMAENV_OK;
 }

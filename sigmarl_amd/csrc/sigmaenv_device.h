@@ -74,6 +74,15 @@ struct DevBufs {
   uint8_t* fresh;                  // optional [B,N] (SIGMAENV_OBS_BOUNDARY_POINTS only): 1 = (re)placed and not stepped since -- the observation's boundary
                                    // points use another index shift then (world_state_rt.py:531-576 vs :686-724); nullptr otherwise
   float* slab;                     // optional rollout record of this step: [B][N*D obs | N reward | 1 done] fp32 (sigmaenv_set_slab)
+  // non-default observation switches (sigmaenv_config_t.obs_flags != 0; observe_tile): what the row assembly reads beyond the tile itself
+  const float* lanelet_centers;           // [n_lanelets][lanelet_pts][2] zero-padded lanelet centre lines (sigmaenv_set_lanelets), or nullptr
+  const unsigned long long* lanelet_neigh;  // [n_lanelets] neighbour bit masks
+  int32_t n_lanelets, lanelet_pts;
+  const float* bnd_left;                  // the padded boundary tables (DevMap::left; the right table follows at + bnd_poly_stride floats), [n_paths][bnd_P][2]
+  const int32_t* bnd_n_center;            // point count of every path's centre line (the loop rule of the boundary points, world_state_rt.py:686-724)
+  const uint8_t* bnd_is_loop;
+  int32_t bnd_poly_stride, bnd_P;
+  uint32_t mVT1;                          // magic multiplier of the variant rows' points per agent (observe_tile)
   // magic multipliers ceil(2^32 / d) for the divisors the kernels' index arithmetic divides by (fdiv below): agents per env, items per
   // agent of the two observation passes, unordered pairs per env, floats per rollout record row
   uint32_t mN, mT1, mT2, mTP, mW, mSG;  // mSG: slots of a full tile of the step kernel (G * N)

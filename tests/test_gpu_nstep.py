@@ -161,6 +161,78 @@ def test_observation_noise_on_the_device(scen, N, B, testing):
         e.close()
 
 
+NSTEP_OBS_VARIANTS = [
+    # (scenario, N, B, Parameters switches): every family of the non-default observation rows, in the T-step launch with the rollout record
+    ("cpm_entire", 16, 160, dict(is_ego_view=False)),                                                              # bird view
+    ("roundabout_2", 6, 64, dict(is_ego_view=False, is_apply_mask=True, is_observe_vertices=False)),               # bird view + the lanelet-relation mask
+    ("cpm_entire", 8, 96, dict(is_apply_mask=True, is_obs_steering=True, is_observe_ref_path_other_agents=True)),  # steering + neighbours' reference paths + distance mask
+    ("on_ramp_1", 4, 48, dict(is_observe_distance_to_boundaries=False, is_using_opponent_modeling=True, is_testing_mode=True)),  # boundary points (fresh / stepped shifts, per-agent re-placement) + placeholders
+    ("cpm_entire", 8, 64, dict(is_observe_vertices=False, is_observe_distance_to_agents=False, is_observe_distance_to_center_line=False, is_obs_noise=True)),
+    ("intersection_1", 4, 40, dict(is_ego_view=False, is_partial_observation=False, is_obs_noise=True)),           # full observation (+ sensor noise)
+    ("cpm_entire", 16, 64, dict(is_ego_view=False, is_partial_observation=False, is_observe_vertices=False, is_obs_steering=True, is_observe_ref_path_other_agents=True)),
+    ("cpm_entire", 8, 48, dict(n_points_short_term=5, is_ego_view=False, is_observe_distance_to_boundaries=False)),  # another build variant (libsigmaenv_ns5.so)
+]
+
+
+@pytest.mark.parametrize("scen,N,B,kw", NSTEP_OBS_VARIANTS)
+def test_nstep_launch_with_observation_variants(scen, N, B, kw):
+    """Every obs_flags combination is assembled INSIDE the fused step (observe_tile_variant): the T-step launch records the configured row, == T single
+    launches bit for bit (every buffer, every record row), == the oracle (pinned on the reference's trajectories) within 1e-5, masks / indices exact."""
+    import torch
+    from sigmarl_amd.shard import slab_width, unpack_slab
+
+    T = 10
+    base = dict(n_agents=N, scenario_type=scen, is_use_mtv_distance=False, rew_method="distance", dt=0.1, is_apply_mask=False, is_obs_noise=False, max_steps=9,
+                random_seed=5)
+    base.update(kw)
+    p = Parameters(**base)
+    mp = load_map(scen)
+    cfg = make_config(p, mp, B)
+    assert cfg.obs_flags != 0
+    pf, pc = mp.list_first[0], mp.list_count[0]
+    one, many, ora = _hip_env(cfg, mp), _hip_env(cfg, mp), ob.OracleEnv(cfg, mp)
+    D = one.env.D
+    assert D == ora.D == capi.obs_dim(cfg.n_nearing, cfg.obs_flags, p.n_points_short_term, N)
+    for d in (one, many):
+        d.env.buffer(capi.BUF_DONE).fill_(1)
+        d.auto_reset(5, 0, pf, pc)
+    ora.get(capi.BUF_DONE, copy=False)[:] = 1
+    ora.auto_reset(5, 0, pf, pc)
+    _compare_all(one, ora, "initial observation")
+    W = slab_width(N, D)
+    acts = _actions(np.random.default_rng(21), T, B, N, True)
+    ta = torch.as_tensor(acts).cuda()
+    rec_one = torch.full((T, B, W), float("nan"), device="cuda")
+    rec_many = torch.full((T, B, W), float("nan"), device="cuda")
+    n_done = n_req = 0
+    for t in range(T):
+        one.env.set_slab(rec_one[t])
+        one.env.step_autoreset(ta[t], 5, 100 + t, pf, pc)
+        ora.step(acts[t])
+        obs_t, rew_t, dn_t = unpack_slab(rec_one[t], N, D)
+        assert np.abs(obs_t.cpu().numpy() - ora.get(capi.BUF_OBS)).max() <= 1e-5, f"record row, step {t}"
+        assert np.abs(rew_t.cpu().numpy() - ora.get(capi.BUF_REWARD)).max() <= 1e-5
+        assert np.array_equal(dn_t.cpu().numpy(), ora.get(capi.BUF_DONE).astype(bool))
+        n_done += int(ora.get(capi.BUF_DONE).sum())
+        n_req += int(ora.get(capi.BUF_COL_FLAGS)[..., 3].sum())
+        ora.auto_reset(5, 100 + t, pf, pc)
+        _compare_all(one, ora, f"step {t}")
+    one.env.set_slab(None)
+    many.env.step_autoreset_n(ta, rec_many, 5, 100, pf, pc)
+    many.env.sync()
+    assert torch.equal(rec_one.view(torch.int32), rec_many.view(torch.int32)), "record rows differ"
+    for w in INT_BUFS + FLT_BUFS:
+        assert one.get(w).tobytes() == many.get(w).tobytes(), f"buffer {w} differs between {T} launches and the one {T}-step launch"
+    assert n_done > 0
+    if scen == "on_ramp_1":
+        assert n_req > 0  # per-agent re-placements inside the loop: re-placed agents' boundary points use the 'fresh' index shift, the others' the stepped one
+    one.env.observe()
+    ora.observe()
+    _compare_all(one, ora, "sigmaenv_observe")
+    for e in (one, many, ora):
+        e.close()
+
+
 def test_nstep_rejects_what_it_cannot_do():
     import torch
 

@@ -851,8 +851,8 @@ OBS_VARIANTS = [
 @pytest.mark.parametrize("kw", OBS_VARIANTS)
 def test_observation_variants_hip_vs_oracle(kw):
     """Non-default observation switches (capi.OBS_*, observation_provider_rt.py:803-925): the public observation buffer has
-    sigmaenv_obs_dim_ex columns and equals the oracle's row (pinned on two reference trajectories, tests/golden) through steps, device-side
-    resets and sigmaenv_observe; every other buffer is unaffected; the rollout record is refused."""
+    sigmaenv_obs_dim_full columns and equals the oracle's row (pinned on the reference's trajectories, tests/golden) through steps, device-side
+    resets and sigmaenv_observe; every other buffer is unaffected; the rollout record carries the same row."""
     import torch
 
     N, B = 8, 40
@@ -887,8 +887,13 @@ def test_observation_variants_hip_vs_oracle(kw):
     dev.env.observe()
     ora.observe() if hasattr(ora, "observe") else None
     _compare_all(dev, ora, "observe")
-    with pytest.raises(RuntimeError):
-        dev.env.set_slab(torch.zeros((B, N * (D + 1) + 1), device="cuda"))
+    slab = torch.full((B, N * (D + 1) + 1), float("nan"), device="cuda")
+    dev.env.set_slab(slab)
+    act = np.stack([rng.uniform(0, 1, (B, N)), rng.uniform(-0.3, 0.3, (B, N))], axis=-1).astype(np.float32)
+    dev.step(act)
+    ora.step(act)
+    got = slab[:, : N * D].reshape(B, N, D).cpu().numpy()
+    assert np.array_equal(got, dev.get(capi.BUF_OBS)) and np.abs(got - ora.get(capi.BUF_OBS)).max() <= 1e-5
     dev.close()
     ora.close()
 
