@@ -42,9 +42,10 @@ HBM_PEAK_GBPS = 8000.0
 FP32_PEAK_TFLOPS = 157.3
 
 
-def algorithmic_bytes_per_agent_step(n_agents: int) -> int:
-    """44 B read + (251 + 5 N) B written per agent-env-step at obs_dim = 32 (375 B at N = 16)."""
-    return ALGO_BYTES_READ + 251 + 5 * n_agents
+def algorithmic_bytes_per_agent_step(n_agents: int, obs_dim: int = 32) -> int:
+    """44 B read + (251 + 5 N) B written per agent-env-step at obs_dim = 32 (375 B at N = 16); another observation layout changes
+    the observation's 4 x obs_dim bytes of that sum."""
+    return ALGO_BYTES_READ + 251 + 4 * (obs_dim - 32) + 5 * n_agents
 
 
 def make_params_kw(args, n_envs):
@@ -56,7 +57,18 @@ def make_params_kw(args, n_envs):
             kw.update(is_grouping_agents=True, max_group_size=args.cbf_group_size, adaptive_lambda=True)
     elif args.cbf:
         kw.update(rew_method="cbf", is_solve_qp=False, is_using_cbf_training=True)
+    if getattr(args, "defaults", False):  # the reference's own Parameters defaults for this path (helper_common.py:66-79): mtv distance, mask, sensor noise
+        kw.update(is_use_mtv_distance=True, is_apply_mask=True, is_obs_noise=True, obs_noise_level=0.05)
+    for item in getattr(args, "param", None) or []:  # --param key=value: any other Parameters field (observation switches ...)
+        k, _, v = item.partition("=")
+        kw[k.strip()] = json.loads(v) if v.strip().lower() not in ("true", "false") else (v.strip().lower() == "true")
     return kw
+
+
+def params_note(args):
+    kw = make_params_kw(args, 1)
+    extra = {k: v for k, v in kw.items() if k in ("is_apply_mask", "is_obs_noise") and v} | {k: kw[k] for k in ((it.partition("=")[0].strip()) for it in (args.param or []))}
+    return (", " + ", ".join(f"{k}={v}" for k, v in sorted(extra.items()))) if extra else ""
 
 
 def needs_injected_start(mp, n_agents):
@@ -400,6 +412,48 @@ class GpuRun:
             e.close()
 
 
+class SurfaceRun:
+    """The drop-in surface: ``ScenarioRoadTraffic`` (the mirror of sigmarl/scenarios/road_traffic.py) under an ``Environment``-shaped driver that calls it in
+    vmas' order -- per step: N action tensors set, ``world.step()`` (ONE fused launch), ``reward(a)`` / ``observation(a)`` / ``info(a)`` for every agent with
+    every returned tensor cloned (39 info entries per agent), ``done()`` incl. the resets (on the device: ``device_side_resets``).  Same interface as GpuRun."""
+
+    def __init__(self, args, device, B):
+        import torch
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from vmas_env_shim import EnvironmentShim
+        from sigmarl_amd.params import Parameters
+        from sigmarl_amd.scenario import ScenarioRoadTraffic
+
+        self.torch, self.args, self.B, self.N, self.S, self.Bs, self.T = torch, args, B, args.agents, 1, B, 1
+        sc = ScenarioRoadTraffic()
+        sc.parameters = Parameters(**make_params_kw(args, B))
+        sc.device_side_resets = True
+        self.shim = EnvironmentShim(sc, num_envs=B, device=device, seed=0, n_agents=args.agents)
+        self.env = sc.env
+        self.envs = [sc.env]
+        self.D = sc.env.D
+        self.start = "device-side sampler (device_side_resets=True)"
+        gen = torch.Generator(device=device).manual_seed(1000)
+        self.acts = [[torch.stack([torch.rand(B, generator=gen, device=device), torch.rand(B, generator=gen, device=device) * 0.5 - 0.25], dim=-1)
+                      for _ in range(self.N)] for _ in range(8)]
+        self.gather, self.gather_note, self.gather_fail, self.fused = None, "none (the consumer collects the callbacks' tensors itself)", None, False
+        self.n_tensors = 0
+
+    def run_steps(self, t0, n):
+        for t in range(n):
+            obs, rews, dones, infos = self.shim.step(self.acts[(t0 + t) % 8])
+            self.n_tensors = len(obs) + len(rews) + 1 + sum(len(i) for i in infos)
+
+    def finish_chunk(self):
+        pass
+
+    arm_timing = GpuRun.arm_timing
+    kernel_timing = GpuRun.kernel_timing
+    episodes_reset = GpuRun.episodes_reset
+    agent_requests = GpuRun.agent_requests
+    close = GpuRun.close
+
+
 def timed(run, steps, start_t, use_dist, dist, torch, device):
     if use_dist:
         dist.barrier()
@@ -527,6 +581,12 @@ def main():
     ap.add_argument("--scenario", default="cpm_entire", help="map (sigmarl_amd/assets/maps); maps that cannot hold --agents through the "
                     "reference's own reset start from the injected state (BASELINE config 4: --scenario on_ramp_1 --agents 32 --envs-per-gpu 8192)")
     ap.add_argument("--distance", choices=["c2c", "mtv"], default="c2c")
+    ap.add_argument("--defaults", action="store_true", help="the reference's own defaults for this path (helper_common.py:66-79): mtv distance, is_apply_mask, is_obs_noise")
+    ap.add_argument("--param", action="append", default=[], metavar="KEY=VALUE", help="override a Parameters field (JSON value), e.g. --param is_ego_view=false "
+                    "--param is_obs_steering=true: the non-default observation rows run inside the same fused launch")
+    ap.add_argument("--surface", action="store_true", help="time the DROP-IN SURFACE instead of the C-ABI: ScenarioRoadTraffic driven the way vmas' Environment drives "
+                    "a scenario (tests/vmas_env_shim.py: set actions per agent, world.step(), reward / observation / info per agent -- every returned tensor cloned --, "
+                    "done(), device-side resets) -- what sigmarl/mappo_cavs.py:166-184 sees per env.step()")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 disables it)")
     ap.add_argument("--sweep", action="store_true", help="also time the metric's batch sweep (envs per GPU in --sweep-envs, same agents / map) and "
                     "report it in `sweep`; the headline stays --envs-per-gpu")
@@ -593,7 +653,11 @@ def main():
     torch.cuda.set_device(device)
 
     B, N = args.envs_per_gpu, args.agents
-    run = GpuRun(args, device, B, world, rank, T=T)
+    if args.surface:
+        T = 1
+        args.no_compare = True
+    run = SurfaceRun(args, device, B) if args.surface else GpuRun(args, device, B, world, rank, T=T)
+    dist_label = "mtv" if make_params_kw(args, B)["is_use_mtv_distance"] else "c2c"
     # nothing but the warm-up steps runs on the GPU right before the timed region (no reduction kernel, no device-to-host copy: both would let the
     # queue run empty and the first timed launch pay for it)
     run.arm_timing()  # arms the HIP-event bracketing of the step launches (on the env's stream)
@@ -614,7 +678,7 @@ def main():
     total_agent_steps = N * B * world * args.steps
     value = total_agent_steps / elapsed
     value_per_gpu = value / world
-    bytes_per = algorithmic_bytes_per_agent_step(N)
+    bytes_per = algorithmic_bytes_per_agent_step(N, D)
     achieved = bytes_per * value_per_gpu / 1e9  # GB/s of ONE GPU: SURVEY.md section 8(d)'s per-unit figure x the units it processes per second
     # what the launch stores on top of section 8(d)'s list: the rollout record row of every env, and the whole record of every agent of a
     # re-placed env once more (320 + 5 N bytes)
@@ -628,7 +692,7 @@ def main():
     try:  # HBM bytes per launch from the separate rocprofv3 --pmc passes (tools/pmc_passes.sh), corrected as the MI355X guide says
         with open(os.path.join(ROOT, "profiles", "traffic_latest.json")) as f:
             tr = json.load(f)
-        if tr.get("n_agents") == N and tr.get("envs_per_launch") == Bs and tr.get("distance") == args.distance and tr.get("scenario", "cpm_entire") == args.scenario:
+        if tr.get("n_agents") == N and tr.get("envs_per_launch") == Bs and tr.get("distance") == dist_label and tr.get("obs_dim", 32) == D and tr.get("scenario", "cpm_entire") == args.scenario:
             # the profile's launches may hold another number of steps: scale by the steps of ONE launch of this run
             traffic = tr["hbm_bytes_per_launch"] / float(tr.get("steps_per_launch", 1)) * steps_per_launch
             traffic_source = "profiles/traffic_latest.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload (not this run), per launch"
@@ -655,11 +719,14 @@ def main():
         "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {
-            "workload": f"{args.scenario} map, {N} agents x {B} envs per GPU ({B * world} envs total), {args.distance} distance, "
-                        f"rew_method={make_params_kw(args, B)['rew_method']}, dt=0.05, obs_dim={D}, start: {run.start}, fused step + device-side reset of finished envs "
+            "workload": f"{args.scenario} map, {N} agents x {B} envs per GPU ({B * world} envs total), {dist_label} distance, "
+                        f"rew_method={make_params_kw(args, B)['rew_method']}{params_note(args)}, dt=0.05, obs_dim={D}, start: {run.start}, "
+                        + ("VMAS plugin surface: ScenarioRoadTraffic under the Environment-shaped driver (per step: world.step() = one fused launch, then reward / "
+                           f"observation / info of every agent cloned -- {run.n_tensors} tensors -- and done() with device-side resets) " if args.surface else
+                           "fused step + device-side reset of finished envs ")
                         + ((f"({T} steps per launch)" if T > 1 else "(one launch per step)") if run.fused else "(two launches)" if not args.no_reset else "(resets disabled)")
                         + ((" + rollout record" + ((" + " + run.gather.mode) if run.gather.collective else "")) if run.gather else ""),
-            "n_agents": N, "envs_per_gpu": B, "envs_total": B * world, "distance": args.distance, "scenario": args.scenario, "env_shards_per_gpu": S, "steps_per_launch": T,
+            "n_agents": N, "envs_per_gpu": B, "envs_total": B * world, "distance": dist_label, "scenario": args.scenario, "env_shards_per_gpu": S, "steps_per_launch": T,
             "policy": (f"actor MLP 32-256-256-256-4 ({args.policy_precision}) on device before every step" if args.policy
                        else "none in the timed region (precomputed actions resident in HBM)"),
             **({"cbf": ("centralized CBF-QP safety filter of every env (sigmaenv_cbf_qp: 2 N controls, lane + pair constraints, projected "
@@ -667,6 +734,9 @@ def main():
                         + (f"; grouped QPs, max_group_size {args.cbf_group_size}" if args.cbf_group_size > 0 else "") if args.cbf_qp else
                         "QP-free CBF margin reward (sigmaenv_cbf_rewards: 3 circles per vehicle, 9-point fp16 pseudo-distance stencils to both "
                         "boundaries, float64 margins) launched before every step")} if (args.cbf or args.cbf_qp) else {}),
+            "actions": ("one tensor per agent handed to env.step() (the surface's contract)" if args.surface else
+                        f"open loop: precomputed actions resident in HBM, {T} step(s) per launch -- a closed-loop rollout (policy or CBF filter between the steps) "
+                        "runs at the config.per_step_launch / --policy rates"),
             "resets_per_step_per_gpu": dones / max(1, args.steps),
             "agent_reset_requests_last_step": req_last, "entry_exit_crossings_last_step": entry_exit_last,
             "rollout_gather": run.gather_fail or run.gather_note,
@@ -679,6 +749,10 @@ def main():
             "algorithmic_bytes_per_agent_env_step": bytes_per, "algorithmic_bytes_per_launch": per_launch_bytes,
             "achieved_per_launch": (per_launch_bytes / (kernel_ms * 1e-3) / 1e9) if kernel_ms > 0 else None,
             "achieved_incl_record": achieved_incl,
+            # what the kernel actually moves: the PMC-measured HBM bytes of one launch / its duration.  A T-step launch keeps the tile in LDS between its steps and
+            # writes section 8(d)'s per-step outputs (distance rows, collision rows, closest indices ...) for the LAST step only, so this is BELOW `achieved`
+            "achieved_measured": (traffic / (kernel_ms * 1e-3) / 1e9) if (traffic and kernel_ms > 0) else None,
+            "traffic_over_algorithmic": (traffic / per_launch_bytes) if traffic else None,
             "achieved_basis": "algorithmic bytes per agent-env-step (SURVEY.md 8d: 44 + 251 + 5 N) x agent-env-steps/s of one GPU; achieved_per_launch = the same "
                               "bytes of ONE launch / its average duration by HIP events (launches of different shards overlap); achieved_incl_record adds the "
                               "rollout record rows and the rewrites of re-placed envs",

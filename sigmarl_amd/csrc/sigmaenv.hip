@@ -72,12 +72,32 @@ struct Smem {
   uint8_t* nearl;             // indices of the boundary segments within the circumradius, [S * 2][NEAR_CAP]
   uint8_t* fresh;             // [S] 1 = the agent was (re)placed and has not been stepped since (boundary points of the observation: another index shift,
                               // world_state_rt.py:531-576 vs :686-724); the tile's copy of DevBufs::fresh, kept across the steps of one launch
-  unsigned long long* key64;  // [S] scratch of the observation's lanelet search (min over (squared distance bits << 32 | lanelet)); aliases acc64 / cmask
+  unsigned long long* key64;  // [S] scratch of the observation's lanelet search (min over (squared distance bits << 32 | lanelet))
   // LEAN = the wave-per-tile layout of the step kernel: no escr / cmask / cand (its scan keeps them in registers), near-segment lists instead
-  __device__ Smem(char* base, int S, int N, int K, int D, bool lean = false) {
+  // floats of the staging region: the observation rows -- and, in the LEAN layout, the scan's work areas IN THE SAME BYTES: the work list and the per-task
+  // accumulators live from phase S to phase E of a step, the observation rows (and the reward phase's use of the region as scratch) from phase C to the end of the
+  // step, and the next step's scan initialises its areas again.  2 KB per 16-agent tile: the difference between 16 and 20 resident tiles per CU, i.e. room for the
+  // wider rows of the non-default observation switches without dropping below the 16 tiles per CU (one resident round at 4096 envs) the default row runs at.
+  __host__ __device__ static __forceinline__ size_t scan_scratch_ints(int S) {
+    return (size_t)S * 3 * 2 + (size_t)S * 2 * 4 + (size_t)S * 2 + (size_t)(ITEM_CAP(S) + 1) / 2 + (size_t)(S * 2 * NEAR_CAP + 3) / 4;
+  }
+  __host__ __device__ static __forceinline__ size_t stage_floats(int S, int D, bool lean) {
+    const size_t o = ((size_t)S * D + 3) & ~(size_t)3, q = (scan_scratch_ints(S) + 3) & ~(size_t)3;
+    return (lean && q > o) ? q : o;
+  }
+  __device__ __forceinline__ Smem(char* base, int S, int N, int K, int D, bool lean = false) {
     escr = reinterpret_cast<float4*>(base);  // first: the dynamic LDS base is 16-byte aligned
     float* f = reinterpret_cast<float*>(base + (lean ? 0 : ESCR_BYTES));
-    obs = f; f += (S * D + 3) & ~3;  // 16-byte aligned (vector copy to HBM), and so is everything up to vold
+    obs = f;  // 16-byte aligned (vector copy to HBM), and so is everything up to vold
+    {
+      int* q = reinterpret_cast<int*>(f);
+      acc64 = reinterpret_cast<unsigned long long*>(q); q += S * 3 * 2;
+      acc32 = reinterpret_cast<uint32_t*>(q); q += S * 2 * 4;
+      nearn = q; q += S * 2;
+      items = reinterpret_cast<uint16_t*>(q); q += (ITEM_CAP(S) + 1) / 2;
+      nearl = reinterpret_cast<uint8_t*>(q);  // (only meaningful in the LEAN layout)
+    }
+    f += stage_floats(S, D, lean);
     st = f; f += S * 8;
     vold = f; f += S * 10;
     vnew = f; f += S * 10;
@@ -96,33 +116,22 @@ struct Smem {
     near = i; i += S * (K > 0 ? K : 1);
     flags = i; i += S * 4;
     npts = i; i += S * 3;  // point counts of the agent's centre line / left / right boundary
-    i += (S * 3) & 1;      // keep the 64-bit masks 8-byte aligned
+    i += ((reinterpret_cast<uintptr_t>(i) >> 2) & 1);  // 8-byte alignment of the 64-bit words that follow (the base is 16-byte aligned)
     cmask = reinterpret_cast<unsigned long long*>(i);
     if (!lean) i += S * 3 * 2;
+    key64 = lean ? reinterpret_cast<unsigned long long*>(i) : cmask;  // LEAN: its own S words (the observation phase cannot borrow the scan's: they share its region)
+    if (lean) i += S * 2;
     cand = reinterpret_cast<uint8_t*>(i);
     if (!lean) i += S * 3 * (CAND_LIST / 4);
     pidx = reinterpret_cast<uint16_t*>(i); i += (N * (N - 1) / 2 + 1) / 2;
-    if (lean) i += ((reinterpret_cast<uintptr_t>(i) >> 2) & 1);  // 8-byte alignment of acc64 (the base is 16-byte aligned)
-    acc64 = reinterpret_cast<unsigned long long*>(i);
-    if (lean) i += S * 3 * 2;
-    acc32 = reinterpret_cast<uint32_t*>(i);
-    if (lean) i += S * 2 * 4;
-    nearn = i;
-    if (lean) i += S * 2;
-    items = reinterpret_cast<uint16_t*>(i);
-    if (lean) i += (ITEM_CAP(S) + 1) / 2;
-    nearl = reinterpret_cast<uint8_t*>(i);
-    if (lean) i += (S * 2 * NEAR_CAP + 3) / 4;
     col = reinterpret_cast<uint8_t*>(i);
     fresh = col + (size_t)S * COL_STRIDE(N);
-    key64 = lean ? acc64 : cmask;
   }
-  __host__ __device__ static size_t bytes(int S, int N, int K, int D, bool lean = false) {
-    size_t f = (size_t)S * 8 + S * 10 * 2 + S * NS * 2 + S + S * 5 * 2 + S + (size_t)S * DIST_STRIDE(N) + (size_t)S * D + S * 3 + S * 2 + S * 2;
-    size_t i = (size_t)S + S * 3 + S * (K > 0 ? K : 1) + S * 4 + S * 3 + 1;
-    i += lean ? (1 + (size_t)S * 3 * 2 + (size_t)S * 2 * 4 + (size_t)S * 2 + (size_t)(ITEM_CAP(S) + 1) / 2 + (size_t)(S * 2 * NEAR_CAP + 3) / 4)
-              : ((size_t)S * 3 * 2 + (size_t)S * 3 * (CAND_LIST / 4));
-    return (lean ? 0 : ESCR_BYTES) + (f + i + 3 + (size_t)(N * (N - 1) / 2 + 1) / 2) * 4 + (size_t)S * COL_STRIDE(N) + (((size_t)S + 3) & ~(size_t)3) + 16;
+  __host__ __device__ static __forceinline__ size_t bytes(int S, int N, int K, int D, bool lean = false) {
+    size_t f = stage_floats(S, D, lean) + (size_t)S * 8 + S * 10 * 2 + S * NS * 2 + S + S * 5 * 2 + S + (size_t)S * DIST_STRIDE(N) + S * 3 + S * 2 + S * 2;
+    size_t i = (size_t)S + S * 3 + S * (K > 0 ? K : 1) + S * 4 + S * 3 + 1;  // (+ 1: the alignment word)
+    i += lean ? (size_t)S * 2 : ((size_t)S * 3 * 2 + (size_t)S * 3 * (CAND_LIST / 4));
+    return (lean ? 0 : ESCR_BYTES) + (f + i + (size_t)(N * (N - 1) / 2 + 1) / 2) * 4 + (size_t)S * COL_STRIDE(N) + (((size_t)S + 3) & ~(size_t)3) + 16;
   }
 };
 
@@ -160,7 +169,7 @@ struct ObsLayout {
   int W_oth;  // FULL: total width of the [others] part per env (N x the sum of the feature widths)
   enum { F_VERT, F_POS, F_ROT, F_LEN, F_WID, F_VEL, F_STEER, F_DIST, F_REF };
   // FULL: the idx-th feature of the [others] part in row order (no arrays: the struct lives in registers)
-  __host__ __device__ bool feature(int idx, int N, int& kind, int& wid) const {
+  __host__ __device__ __forceinline__ bool feature(int idx, int N, int& kind, int& wid) const {
     int n = 0;
 #define SIGMA_FEAT(cond, k_, w_) if (cond) { if (idx == n) { kind = (k_); wid = (w_); return true; } ++n; }
     const bool nv = (F & SIGMAENV_OBS_NO_VERTICES) != 0;
@@ -173,7 +182,7 @@ struct ObsLayout {
 #undef SIGMA_FEAT
     return false;
   }
-  __host__ __device__ ObsLayout(int F_, int N, int K) {
+  __host__ __device__ __forceinline__ ObsLayout(int F_, int N, int K) {
     F = F_;
     bird = (F & SIGMAENV_OBS_BIRD_VIEW) != 0;
     full = (F & SIGMAENV_OBS_FULL) != 0;
@@ -212,7 +221,7 @@ struct ObsLayout {
 struct Tile {
   int env0, nenv, slots, N, K, D, DL;  // D: width of the observation row; DL: floats per agent slot of its LDS staging area (= D unless SIGMAENV_OBS_FULL)
   size_t a0;  // global agent index of slot 0 (= env0 * N)
-  __device__ Tile(const sigmaenv_config_t& c, int G, int tile_index = -1) {
+  __device__ __forceinline__ Tile(const sigmaenv_config_t& c, int G, int tile_index = -1) {
     N = c.n_agents; K = c.n_nearing; D = 4 + 2 * NS + 11 * K; DL = D;
     if (c.obs_flags != 0) { const ObsLayout L(c.obs_flags, N, K); D = L.D; DL = L.DL; }
     env0 = (tile_index < 0 ? (int)blockIdx.x : tile_index) * G;
@@ -656,31 +665,9 @@ __device__ inline void topk_nearest(const float* Drow, int N, int K, int* out) {
   }
 }
 
-// D: observations of all slots of the tile (observation_provider_rt.py:345-588 latest slot, :594-925 default flags).
-// Three branch-free passes so that every lane of a wavefront runs the same code:
-//   1. ego-view transforms (own short-term path points, observed neighbours' vertices): atan2 + cos + sin each
-//   2. relative velocities (self + observed neighbours): angle wrap + cos + sin each
-//   3. normalised distances
-// Rows are assembled in LDS and written out coalesced.  All threads of the block participate.
-// env_sel / n_sel: restrict the work to these envs of the tile (the reset tail only refreshes the envs it touched); the loops then run
-// over "virtual" slots v = (position in env_sel) * N + agent, so that the lanes stay densely used.
-template <bool WAVE>
-__device__ __forceinline__ void observe_tile_default(const sigmaenv_config_t& c, const Smem& s, const DevBufs& g, const Tile& t,
-                                                     const int* env_sel, int n_sel, bool write_global, const int* tim) {
-  // tim: the timer rows [nenv][4] of the tile's envs (LDS copy of the step kernel's step loop; default: SIGMAENV_BUF_TIMER) -- the observation
-  // noise is keyed on an env's (episodes_reset, timer.step)
-  const int N = t.N, K = t.K, D = t.D;
-  const int TID = Grp<WAVE>::tid(), NTHR = Grp<WAVE>::size();
-  const int n_slots = env_sel ? n_sel * N : t.slots;
-  auto real_slot = [&](int v) {
-    if (!env_sel) return v;
-    const int q = fdiv(v, g.mN);
-    return env_sel[q] * N + (v - q * N);
-  };
-#define TSO(k) do { } while (0)
-  const float n_pos = (float)((double)c.length * 10.0);   // normalizers.pos, road_traffic.py:588-592
-  const float n_v = c.max_speed;                            // :596
-  const float n_dl = (float)((double)c.lane_width * 3.0);   // :599-601 (distance_lanelet also normalises the agent distances)
+// top-k nearest agents of every (selected) slot of the tile into s.near (observation_provider_rt.py:629-636): ascending distance, lowest index on ties
+template <bool WAVE, class RealSlot>
+__device__ __forceinline__ void topk_tile(const Smem& s, int N, int K, int n_slots, int TID, int NTHR, RealSlot real_slot) {
   if (K == 2 && n_slots * 4 <= NTHR) {
     // Two nearest of every agent with FOUR lanes per agent (a quad): lane q scans the candidates q, q + 4, q + 8, ... in increasing
     // order, then the quads merge their (distance, index)-sorted pairs through DPP quad permutations.  Same result as the selection
@@ -723,6 +710,34 @@ __device__ __forceinline__ void observe_tile_default(const sigmaenv_config_t& c,
       topk_nearest(s.dist + sl * DIST_STRIDE(N), N, K, s.near + sl * K);
     }
   }
+}
+
+// D: observations of all slots of the tile (observation_provider_rt.py:345-588 latest slot, :594-925 default flags).
+// Three branch-free passes so that every lane of a wavefront runs the same code:
+//   1. ego-view transforms (own short-term path points, observed neighbours' vertices): atan2 + cos + sin each
+//   2. relative velocities (self + observed neighbours): angle wrap + cos + sin each
+//   3. normalised distances
+// Rows are assembled in LDS and written out coalesced.  All threads of the block participate.
+// env_sel / n_sel: restrict the work to these envs of the tile (the reset tail only refreshes the envs it touched); the loops then run
+// over "virtual" slots v = (position in env_sel) * N + agent, so that the lanes stay densely used.
+template <bool WAVE>
+__device__ __forceinline__ void observe_tile_default(const sigmaenv_config_t& c, const Smem& s, const DevBufs& g, const Tile& t,
+                                                     const int* env_sel, int n_sel, bool write_global, const int* tim) {
+  // tim: the timer rows [nenv][4] of the tile's envs (LDS copy of the step kernel's step loop; default: SIGMAENV_BUF_TIMER) -- the observation
+  // noise is keyed on an env's (episodes_reset, timer.step)
+  const int N = t.N, K = t.K, D = t.D;
+  const int TID = Grp<WAVE>::tid(), NTHR = Grp<WAVE>::size();
+  const int n_slots = env_sel ? n_sel * N : t.slots;
+  auto real_slot = [&](int v) {
+    if (!env_sel) return v;
+    const int q = fdiv(v, g.mN);
+    return env_sel[q] * N + (v - q * N);
+  };
+#define TSO(k) do { } while (0)
+  const float n_pos = (float)((double)c.length * 10.0);   // normalizers.pos, road_traffic.py:588-592
+  const float n_v = c.max_speed;                            // :596
+  const float n_dl = (float)((double)c.lane_width * 3.0);   // :599-601 (distance_lanelet also normalises the agent distances)
+  topk_tile<WAVE>(s, N, K, n_slots, TID, NTHR, real_slot);
   TSO(0);
   Grp<WAVE>::sync();
   TSO(1);
@@ -844,7 +859,7 @@ __device__ __forceinline__ float full_obs_value(const sigmaenv_config_t& c, cons
 }
 
 template <bool WAVE>
-__device__ inline void observe_tile_variant(const sigmaenv_config_t& c, const Smem& s, const DevBufs& g, const Tile& t, const int* env_sel, int n_sel,
+__device__ __forceinline__ void observe_tile_variant(const sigmaenv_config_t& c, const Smem& s, const DevBufs& g, const Tile& t, const int* env_sel, int n_sel,
                                             bool write_global, const int* tim) {
   const int N = t.N, K = t.K, F = c.obs_flags;
   const ObsLayout L(F, N, K);
@@ -867,14 +882,13 @@ __device__ inline void observe_tile_variant(const sigmaenv_config_t& c, const Sm
   const float nwx = c.world_x_dim, nwy = c.world_y_dim;      // normalizers.pos_world (bird view, :537-575)
   const bool bird = L.bird != 0;
   // ---- nearest neighbours (:629-636); the full observation has none and leaves nearing_agents_indices at zero
-  for (int w = TID; w < (L.full ? n_slots * K : n_slots); w += NTHR) {
-    if (L.full) {
+  if (L.full) {
+    for (int w = TID; w < n_slots * K; w += NTHR) {
       const int v = w / (K > 0 ? K : 1), k = w - v * K;
       s.near[real_slot(v) * K + k] = 0;
-    } else {
-      const int sl = real_slot(w);
-      topk_nearest(s.dist + sl * DIST_STRIDE(N), N, K, s.near + sl * K);
     }
+  } else {
+    topk_tile<WAVE>(s, N, K, n_slots, TID, NTHR, real_slot);
   }
   // ---- mask by lanelet relation (:638-665, map_manager.py:41-118): bird view only -- the agents' lanelets are computed in that branch of update_state only
   // (:577-588) --, on maps whose parser lists neighbouring lanelets.  determine_current_lanelet: squared distance to every (zero-padded) centre-line point of
@@ -932,7 +946,8 @@ __device__ inline void observe_tile_variant(const sigmaenv_config_t& c, const Sm
       tx = pt.x; ty = pt.y;
       pos = L.p_bnd + 2 * r;
     } else {       // [others] (:803-853), masks (:638-749)
-      const int r = q - NS - L.n_bnd_pts, k = r / L.n_oth_pts, u = r - k * L.n_oth_pts;
+      const int r = q - NS - L.n_bnd_pts;
+      const int k = (r >= L.n_oth_pts) + (r >= 2 * L.n_oth_pts) + (r >= 3 * L.n_oth_pts), u = r - k * L.n_oth_pts;  // (K <= SIGMAENV_MAX_NEARING = 4)
       const int j = s.near[sl * K + k], sj = ebase + j, base = L.own_w + k * L.oth_w;
       mk = masked(sl, ebase, j);
       const int nv = (F & SIGMAENV_OBS_NO_VERTICES) ? 1 : 4;
@@ -1063,7 +1078,13 @@ __device__ inline void observe_tile_variant(const sigmaenv_config_t& c, const Sm
     }
     Grp<WAVE>::sync();
   }
-  if (env_sel || write_global) {  // (neither: an intermediate step of the in-kernel step loop -- the rows stay in LDS for the record)
+  if (!L.full && !env_sel && write_global && ((N * DR) & 3) == 0) {
+    // the whole tile's rows are one contiguous, 16-byte aligned block of whole float4s in the staging area and in SIGMAENV_BUF_OBS
+    const float4* so4 = reinterpret_cast<const float4*>(s.obs);
+    float4* go4 = reinterpret_cast<float4*>(g.obs + t.a0 * DR);
+    for (int k = TID; k < t.slots * DR / 4; k += NTHR) go4[k] = so4[k];
+    for (int k = TID; k < t.slots * K; k += NTHR) g.nearing[t.a0 * K + k] = s.near[k];
+  } else if (env_sel || write_global) {  // (neither: an intermediate step of the in-kernel step loop -- the rows stay in LDS for the record)
     const int ND = N * DR, NK = N * K;
     for (int q = 0; q < n_env; ++q) {
       const int e = env_sel ? env_sel[q] : q;
@@ -2051,7 +2072,7 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
       return SIGMAENV_EHIP;
     }
     { const unsigned d = (unsigned)(wg * N); h->buf.mSG = d <= 1u ? 0u : (uint32_t)(((1ull << 32) + d - 1ull) / d); }
-    h->wave_spec = (cfg->obs_flags == 0 && K == 2 && ((N == 16 && wg == 1) || (N == 32 && wg == 1) || (N == 8 && wg == 2) || (N == 4 && wg == 4))) ? N * 256 + wg : 0;
+    h->wave_spec = ((cfg->obs_flags == 0 || (N == 16 && wg == 1)) && K == 2 && ((N == 16 && wg == 1) || (N == 32 && wg == 1) || (N == 8 && wg == 2) || (N == 4 && wg == 4))) ? N * 256 + wg : 0;
     if (const char* e = getenv("SIGMAENV_WAVE_SPEC")) { if (atoi(e) == 0) h->wave_spec = 0; }  // A/B: the generic instantiation
     h->wave_wpb = 1;
     if (const char* e = getenv("SIGMAENV_WPB")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) h->wave_wpb = v; }
@@ -2064,6 +2085,7 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_wave_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_wave_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_wave_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_wave_kernel<true, true, 16, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_wave_kernel<true, true, 0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_wave_kernel<true, false, 0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_wave_kernel<false, true, 0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -2230,10 +2252,11 @@ static int launch_step(sigmaenv* h, const float* actions, uint64_t seed, uint64_
     const bool par = 2 * h->wave_G * h->N <= 64;
     auto kern = h->map.fast_div ? (par ? sigmaenv_step_wave_kernel<true, true> : sigmaenv_step_wave_kernel<true, false>)
                                 : (par ? sigmaenv_step_wave_kernel<false, true> : sigmaenv_step_wave_kernel<false, false>);
-    if (h->cfg.obs_flags != 0)  // the instantiations that carry the non-default observation rows
+    if (h->cfg.obs_flags != 0 && h->map.fast_div && h->wave_spec == 16 * 256 + 1) kern = sigmaenv_step_wave_kernel<true, true, 16, 1, true>;
+    else if (h->cfg.obs_flags != 0)  // the instantiations that carry the non-default observation rows
       kern = h->map.fast_div ? (par ? sigmaenv_step_wave_kernel<true, true, 0, 0, true> : sigmaenv_step_wave_kernel<true, false, 0, 0, true>)
                              : (par ? sigmaenv_step_wave_kernel<false, true, 0, 0, true> : sigmaenv_step_wave_kernel<false, false, 0, 0, true>);
-    if (h->map.fast_div) {  // fixed-shape instantiations (the plain-division variant of a map with degenerate segments stays generic)
+    if (h->map.fast_div && h->cfg.obs_flags == 0) {  // fixed-shape instantiations (the plain-division variant of a map with degenerate segments stays generic)
       switch (h->wave_spec) {
         case 16 * 256 + 1: kern = sigmaenv_step_wave_kernel<true, true, 16, 1>; break;
         case 32 * 256 + 1: kern = sigmaenv_step_wave_kernel<true, true, 32, 1>; break;

@@ -11,7 +11,9 @@ from sigmarl_amd.env import SigmaEnv
 from sigmarl_amd.params import Parameters
 B, N = int(os.environ.get("B", 4096)), int(os.environ.get("N", 16))
 scen = os.environ.get("SCENARIO", "cpm_entire")
-env = SigmaEnv(Parameters(n_agents=N, scenario_type=scen, is_use_mtv_distance=False, is_apply_mask=False, is_obs_noise=False), n_envs=B, device="cuda:0")
+import json
+extra = json.loads(os.environ.get("PARAMS", "{}"))  # e.g. PARAMS='{"is_ego_view": false}': the non-default observation rows
+env = SigmaEnv(Parameters(**dict(dict(n_agents=N, scenario_type=scen, is_use_mtv_distance=False, is_apply_mask=False, is_obs_noise=False), **extra)), n_envs=B, device="cuda:0")
 env.reset_random(seed=1)
 acts = torch.rand((B, N, 2), device="cuda") * torch.tensor([1.0, 0.5], device="cuda") - torch.tensor([0.0, 0.25], device="cuda")
 pf, pc = env.map.list_first[0], env.map.list_count[0]
