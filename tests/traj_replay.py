@@ -206,18 +206,58 @@ def apply_events(env, z, mp, t):
     return touched
 
 
-def replay(env, z, meta, mp, steps=None, check_next=True) -> Report:
+class _NoQuirk:
+    """An oracle twin WITHOUT the reference's env-0 reset side effect (hides ``env0_reset_side_effect``): what the product is specified to do."""
+
+    def __init__(self, env):
+        self._env = env
+
+    def __getattr__(self, name):
+        if name == "env0_reset_side_effect":
+            raise AttributeError(name)
+        return getattr(self._env, name)
+
+
+_TWIN_INT = [capi.BUF_PATH, capi.BUF_CLOSEST, capi.BUF_COL_AGENTS, capi.BUF_COL_FLAGS, capi.BUF_NEARING, capi.BUF_DONE, capi.BUF_TIMER]
+_TWIN_FLT = [capi.BUF_STATE, capi.BUF_PREV_POS, capi.BUF_VERTICES, capi.BUF_SHORT_TERM, capi.BUF_DIST_REF, capi.BUF_DIST_LEFT, capi.BUF_DIST_RIGHT, capi.BUF_DIST_BOUND,
+             capi.BUF_DIST_AGENTS, capi.BUF_OBS]
+
+
+def compare_with_twin(rep: Report, env, twin, envs):
+    """The envs a snapshot comparison against the reference had to leave out (the env-0 reset quirk) are held to the quirk-free oracle instead: every buffer."""
+    sel = np.asarray(envs)
+    for w in _TWIN_INT:
+        rep.i(f"twin_buf{w}", env.get(w)[sel], twin.get(w)[sel])
+    for w in _TWIN_FLT:
+        rep.f(f"twin_buf{w}", env.get(w)[sel], twin.get(w)[sel])
+    rep.twin_checked = getattr(rep, "twin_checked", 0) + len(sel)
+
+
+def replay(env, z, meta, mp, steps=None, check_next=True, twin=None) -> Report:
+    """``twin``: an ``OracleEnv`` of the same configuration, driven through the same calls WITHOUT the reference's env-0 reset quirk; the envs the product cannot be
+    compared on against the reference's post-reset snapshot (see below) are compared against it, so no touched env goes unchecked."""
     rep = Report()
     T = int(meta["T"]) if steps is None else min(int(steps), int(meta["T"]))
     apply_initial_reset(env, z, mp, meta)
     compare_snapshot(rep, env, z, "init_", None)
+    if twin is not None:
+        twin = _NoQuirk(twin)
+        apply_initial_reset(twin, z, mp, meta)
     with_cbf = "cbf_in_state" in z.files
     if with_cbf:
         from sigmarl_amd import cbf
 
         seg_l, seg_r = cbf.load_segment_tables(mp)
         env.cbf_attach(cbf.make_cbf_config(params_from_meta(meta)), seg_l, seg_r)
+        if twin is not None:
+            twin.cbf_attach(cbf.make_cbf_config(params_from_meta(meta)), seg_l, seg_r)
     for t in range(T):
+        if twin is not None:  # the same calls, in the same order
+            if with_cbf:
+                twin.cbf_rewards(z["act"][t])
+            twin.step(z["act"][t])
+            if apply_events(twin, z, mp, t):
+                twin.observe()
         if with_cbf:  # CBFQP.update_qp runs after the policy, before the env step (helper_training.py:1620-1627)
             lane_l, lane_r, pair = env.cbf_rewards(z["act"][t])
             rep.cbf("cbf_lane_left", lane_l, z["cbf_lane_left"][t])
@@ -242,6 +282,11 @@ def replay(env, z, meta, mp, steps=None, check_next=True) -> Report:
                     if any(int(z["ev_env"][k]) == 0 for k in ev):
                         full = {int(z["ev_env"][k]) for k in ev if int(z["ev_kind"][k]) == 1}
                         cmp_envs = [e for e in touched if e == 0 or e in full]
+                        dropped = [e for e in touched if e not in cmp_envs]
+                        if dropped and twin is not None:  # ... and the others against the oracle replay WITHOUT the side effect (the product's specification)
+                            compare_with_twin(rep, env, twin, dropped)
+                        elif dropped:
+                            rep.unchecked = getattr(rep, "unchecked", 0) + len(dropped)
                 if cmp_envs:
                     compare_snapshot(rep, env, z, "next_", t, envs=np.asarray(cmp_envs))
     return rep
