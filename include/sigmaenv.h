@@ -415,6 +415,12 @@ int sigmaenv_cbf_attach(sigmaenv_t* h, const sigmaenv_cbf_config_t* cfg, const f
  * lane_left [B,N,C], lane_right [B,N,C], pair [B,N,N,C,C] (entries with i < j), back to back; NULL to skip. */
 int sigmaenv_cbf_rewards(sigmaenv_t* h, const float* actions, double* margins);
 
+/* Test hook.  centers: DEVICE f32 [B,N,C,2] (C = n_circles) or NULL.  While set, sigmaenv_cbf_rewards / sigmaenv_cbf_qp take the covering-circle centres from it
+ * instead of computing them (get_circle_centers, sigmarl/cbf_qp.py:527-573).  The reference rounds the pseudo distance to fp16 and differentiates it numerically, so a
+ * 1-ulp difference of a float32 centre (torch's closed cos / sin against this library's correctly rounded ones) can flip an fp16 rounding; the parity tests inject the
+ * centres the reference itself computed (recorded in the CBF goldens) and then hold every CBF quantity to 2e-6 without exceptions. */
+int sigmaenv_cbf_inject_centers(sigmaenv_t* h, const float* centers);
+
 /* The centralized CBF-QP safety filter of every env (CBFQP.update_centralized_cbf_qp with Parameters.is_solve_qp,
  * sigmarl/cbf_qp.py:733-1019 problem, :1019-1400 data + solve): per env
  *     min  sum_i |(u_i - u_nom_i) W|^2 + w_lane |s_lane|^2 + w_pair |s_pair|^2 + w_clf (|s_head|^2 + |s_speed|^2) [+ w_lambda |lambda|^2]

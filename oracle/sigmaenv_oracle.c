@@ -57,6 +57,7 @@ typedef struct sigmaenv_oracle {
   float* lanelet_centers;       /* [n_lanelets][lanelet_pts][2] zero-padded centre lines of parser.lanelets_all (sigmaenv_oracle_set_lanelets) */
   uint64_t* lanelet_neigh;      /* [n_lanelets] bit j: lanelet j is in parser.neighboring_lanelets_idx[i] */
   int n_lanelets, lanelet_pts;
+  const float* cbf_centers_inject;   /* test hook (sigmaenv_oracle_cbf_inject_centers): [B,N,C,2] circle centres that replace the computed ones, or NULL */
   int n_lists, list_first[4], list_count[4];   /* cpm_mixed sub-scenario path lists (sigmaenv_oracle_set_scenario_lists) */
   float list_cdf[4];
   char err[256];

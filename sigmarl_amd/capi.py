@@ -157,6 +157,7 @@ _SIGS = {
     "set_scenario_lists": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cbf_attach": (C.c_int, [C.c_void_p, C.POINTER(CbfConfig), C.c_void_p, C.c_void_p, C.c_int32]),
     "cbf_rewards": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cbf_inject_centers": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cbf_qp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cbf_regroup": (C.c_int, [C.c_void_p]),
     "cbf_get_groups": (C.c_int, [C.c_void_p, C.c_void_p]),

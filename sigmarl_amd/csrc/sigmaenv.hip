@@ -1709,6 +1709,7 @@ struct sigmaenv {
   sigmaenv_cbf_config_t cbf_cfg{};
   void *cbf_seg4 = nullptr, *cbf_segl = nullptr, *cbf_cxy = nullptr, *cbf_u = nullptr, *cbf_kin = nullptr, *cbf_clf = nullptr, *cbf_safe = nullptr;
   int cbf_seg_stride = 0;
+  const float* cbf_centers_inject = nullptr;  // test hook (sigmaenv_cbf_inject_centers): device [B,N,C,2] circle centres that replace the computed ones
   float* lanelet_centers = nullptr;           // [n_lanelets, lanelet_pts, 2] zero-padded centre lines (sigmaenv_set_lanelets)
   unsigned long long* lanelet_neigh = nullptr;  // [n_lanelets] neighbour bit masks
   int n_lanelets = 0, lanelet_pts = 0;

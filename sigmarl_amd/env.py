@@ -454,6 +454,11 @@ class NumpyAdapter:
     def cbf_attach(self, cbf_cfg, seg_left, seg_right):
         self.env.cbf_attach(cbf_cfg, seg_left, seg_right)
 
+    def cbf_inject_centers(self, centers):
+        """Test hook (sigmaenv_cbf_inject_centers): circle centres [B,N,C,2] float32 replace the computed ones; None clears."""
+        self._centers = None if centers is None else torch.as_tensor(np.ascontiguousarray(centers, np.float32)).to(self.env.device).contiguous()
+        self.env._chk(self.env.lib.cbf_inject_centers(self.env.h, C.c_void_p(self._centers.data_ptr()) if self._centers is not None else None), "cbf_inject_centers")
+
     def cbf_rewards(self, actions, want_margins=True):
         a = torch.as_tensor(np.ascontiguousarray(actions, np.float32).reshape(self.B, self.N, 2)).to(self.env.device)
         m = torch.full((self.env.cbf_margin_count(),), float("nan"), dtype=torch.float64, device=self.env.device) if want_margins else None

@@ -138,6 +138,15 @@ class CbfHook:
             "cbf_in_path": np_(td[("agents", "info", "path_id")]).astype(np.int32),
         }
         L = np.zeros((B, N, C)); R = np.zeros((B, N, C)); P = np.full((B, N, N, C, C), np.nan)
+        # the float32 covering-circle centres exactly as the reference computes them (get_circle_centers, cbf_qp.py:527-573, on the state vector
+        # compute_nominal_cbf_constraint_margins builds, :2586-2600): torch's cos / sin are within 1 ulp of the correctly rounded ones the oracle and the HIP
+        # path use, and that ulp can flip an fp16 rounding of the pseudo distance downstream -- the parity tests can inject these instead
+        cen = np.zeros((B, N, C, 2), np.float32)
+        for e in range(B):
+            for i in range(N):
+                st_i = torch.cat([ag[i].state.pos[e], ag[i].state.rot[e], ag[i].state.speed[e], ag[i].state.steering[e]], dim=-1)
+                cen[e, i] = np_(self.ctl[e].get_circle_centers(st_i)[:, 0:2])
+        rec["cbf_centers"] = cen
         for e in range(B):
             c = self.ctl[e]
             c.time_pseudo_dis = 0
@@ -529,6 +538,13 @@ def gen_cbf_functions():
     ri = sc.reward_info
     out["p2_state"], out["p2_path"], out["p2_act"] = np_(state), np_(path_id).astype(np.int32), np_(act)
     out["p2_lane_left"], out["p2_lane_right"], out["p2_pair"] = L, R, P
+    cen = np.zeros((B, N, C, 2), np.float32)  # the reference's own float32 circle centres of these states (see CbfHook)
+    c0 = CBFQP(env=fake, env_idx=0)
+    for e in range(B):
+        for i in range(N):
+            st_i = torch.cat([ag[i].state.pos[e], ag[i].state.rot[e], ag[i].state.speed[e], ag[i].state.steering[e]], dim=-1)
+            cen[e, i] = np_(c0.get_circle_centers(st_i)[:, 0:2])
+    out["p2_centers"] = cen
     out["p2_rew"] = np.stack([np_(ri.rew_near_left_lane), np_(ri.rew_near_right_lane), np_(ri.rew_near_other_agents)], axis=0)
     out["meta_json"] = np.asarray(json.dumps(dict(B=B, N=N, dt=p.dt, h_nom=p.h_nom, n_circles=C, scenario_type="cpm_entire",
                                                   numpy_version=np.__version__, torch_version=torch.__version__)))

@@ -174,6 +174,11 @@ class OracleEnv:
         if rc != 0:
             raise RuntimeError(f"oracle cbf_attach failed: {rc}")
 
+    def cbf_inject_centers(self, centers):
+        """Test hook: the covering-circle centres ([B,N,C,2] float32, e.g. the reference's own from a CBF golden) replace the computed ones; None clears."""
+        self._centers = None if centers is None else np.ascontiguousarray(centers, np.float32)
+        assert self.lib.cbf_inject_centers(self.h, ptr(self._centers) if self._centers is not None else None) == 0
+
     def cbf_rewards(self, actions, want_margins=True):
         from sigmarl_amd.cbf import split_cbf_margins
 

@@ -349,7 +349,7 @@ def test_actor_rollout_on_a_short_term_build_variant_equals_stepwise_calls():
     torch.manual_seed(7)
     ref = make_mlp(env.N * env.D, n_out=1).cuda()
     v = Critic(ref).values(env)
-    want = ref(env.obs.reshape(env.B, -1)).reshape(env.B, 1, 1).expand(env.B, env.N, 1)
+    want = ref(env.obs.reshape(env.B, -1)).detach().reshape(env.B, 1, 1).expand(env.B, env.N, 1)
     assert float((v - want).abs().max()) <= 1e-5
     for e, ac in setups:
         e.close()

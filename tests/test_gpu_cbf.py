@@ -59,8 +59,18 @@ def test_cbf_set_states_vs_oracle_and_reference():
     rep.cbf("pair", md[2], z["p2_pair"])
     ri = dev.get(capi.BUF_REWARD_INFO)
     rep.cbf("rew", np.stack([ri[5], ri[6], ri[4]]), z["p2_rew"])
+    for e in (dev, ora):
+        e.cbf_inject_centers(z["p2_centers"])
+    md, mo = dev.cbf_rewards(z["p2_act"]), ora.cbf_rewards(z["p2_act"])
+    _cmp_margins(md, mo, "set states, injected centres")
+    rep.cbf("inj_lane_left", md[0], z["p2_lane_left"])
+    rep.cbf("inj_lane_right", md[1], z["p2_lane_right"])
+    rep.cbf("inj_pair", md[2], z["p2_pair"])
+    ri = dev.get(capi.BUF_REWARD_INFO)
+    rep.cbf("inj_rew", np.stack([ri[5], ri[6], ri[4]]), z["p2_rew"])
     print(f"cbf_functions (HIP): {rep}")
     assert rep.cbf_ok("cbf_functions"), str(rep)
+    assert all(rep.cbf_bad[k] == 0 for k in rep.cbf_bad if k.startswith("inj_")), str(rep)  # with the reference's own centres: no exception at all
     dev.close()
     ora.close()
 

@@ -206,9 +206,18 @@ def test_cbf_margins_on_set_states():
     rep.cbf("pair", pair, z["p2_pair"])
     ri = env.get(capi.BUF_REWARD_INFO)
     rep.cbf("rew", np.stack([ri[5], ri[6], ri[4]]), z["p2_rew"])
+    # with the reference's own float32 circle centres injected, no exception is needed: every margin and channel within CBF_TOL
+    env.cbf_inject_centers(z["p2_centers"])
+    lane_l, lane_r, pair = env.cbf_rewards(z["p2_act"])
+    rep.cbf("inj_lane_left", lane_l, z["p2_lane_left"])
+    rep.cbf("inj_lane_right", lane_r, z["p2_lane_right"])
+    rep.cbf("inj_pair", pair, z["p2_pair"])
+    ri = env.get(capi.BUF_REWARD_INFO)
+    rep.cbf("inj_rew", np.stack([ri[5], ri[6], ri[4]]), z["p2_rew"])
     env.close()
     print(f"cbf_functions: {rep}")
     assert rep.cbf_ok("cbf_functions"), str(rep)
+    assert all(rep.cbf_bad[k] == 0 for k in rep.cbf_bad if k.startswith("inj_")), str(rep)
     assert (z["p2_pair"] < 0).sum() > 100 and (z["p2_lane_left"] < 0).sum() > 100  # the case exercises violations
 
 

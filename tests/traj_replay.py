@@ -265,6 +265,18 @@ def replay(env, z, meta, mp, steps=None, check_next=True, twin=None) -> Report:
             rep.cbf("cbf_pair", pair, z["cbf_pair"][t])
             ri = env.get(capi.BUF_REWARD_INFO)
             rep.cbf("cbf_rew", np.stack([ri[5], ri[6], ri[4]]), z["cbf_rew"][t])
+            if "cbf_centers" in z.files and hasattr(env, "cbf_inject_centers"):
+                # The same call with the REFERENCE's float32 circle centres injected (recorded by the golden generator): the one quantity the contract's correctly
+                # rounded cos / sin can move by an ulp against torch's is taken out, and every CBF quantity is held to CBF_TOL with NO listed exception
+                # (keys cbf_inj_*: Report.cbf_ok allows none).  The channels this call leaves behind are the ones the step then adds to the reward.
+                env.cbf_inject_centers(z["cbf_centers"][t])
+                lane_l, lane_r, pair = env.cbf_rewards(z["act"][t])
+                env.cbf_inject_centers(None)
+                rep.cbf("cbf_inj_lane_left", lane_l, z["cbf_lane_left"][t])
+                rep.cbf("cbf_inj_lane_right", lane_r, z["cbf_lane_right"][t])
+                rep.cbf("cbf_inj_pair", pair, z["cbf_pair"][t])
+                ri = env.get(capi.BUF_REWARD_INFO)
+                rep.cbf("cbf_inj_rew", np.stack([ri[5], ri[6], ri[4]]), z["cbf_rew"][t])
         env.step(z["act"][t])
         compare_snapshot(rep, env, z, "post_", t, with_reward=True)
         rep.i("done", env.get(capi.BUF_DONE), z["done"][t])
