@@ -14,7 +14,8 @@ for _ in range(20):
     env.step_autoreset(act, seed=1)
 u = torch.zeros((B,N,2), dtype=torch.float64, device="cuda"); info = torch.zeros((B,2), dtype=torch.int32, device="cuda")
 env.cbf_qp(act, None, u, info); env.sync()
-d = u.reshape(B,-1)[:, :4].cpu()
+d = u.reshape(B,-1)[:, :7].cpu()
 it = info[:,0].float().cpu()
 print("cycles (x100MHz shader clock?) mean total %.0f eval %.0f chol %.0f ls %.0f ; iters mean %.2f" % (d[:,0].mean(), d[:,1].mean(), d[:,2].mean(), d[:,3].mean(), it.mean()))
 print("per iteration: eval %.0f chol %.0f ls %.0f ; outside loop %.0f" % ((d[:,1]/it).mean(), (d[:,2]/it).mean(), (d[:,3]/it).mean(), (d[:,0]-d[:,1]-d[:,2]-d[:,3]).mean()))
+print("before the Newton loop: load %.0f stencil phase %.0f lane + candidate rows %.0f" % (d[:,4].mean(), d[:,5].mean(), d[:,6].mean()))
