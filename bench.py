@@ -692,7 +692,8 @@ def main():
     try:  # HBM bytes per launch from the separate rocprofv3 --pmc passes (tools/pmc_passes.sh), corrected as the MI355X guide says
         with open(os.path.join(ROOT, "profiles", "traffic_latest.json")) as f:
             tr = json.load(f)
-        if tr.get("n_agents") == N and tr.get("envs_per_launch") == Bs and tr.get("distance") == dist_label and tr.get("obs_dim", 32) == D and tr.get("scenario", "cpm_entire") == args.scenario:
+        if tr.get("n_agents") == N and tr.get("envs_per_launch") == Bs and tr.get("distance") == dist_label and tr.get("obs_dim", 32) == D and tr.get("scenario", "cpm_entire") == args.scenario and (T > 1) == (float(tr.get("steps_per_launch", 1)) > 1):
+            # (a T-step launch writes the per-step outputs of its LAST step only: its traffic says nothing about one-launch-per-step runs, and vice versa)
             # the profile's launches may hold another number of steps: scale by the steps of ONE launch of this run
             traffic = tr["hbm_bytes_per_launch"] / float(tr.get("steps_per_launch", 1)) * steps_per_launch
             traffic_source = "profiles/traffic_latest.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload (not this run), per launch"
