@@ -253,6 +253,7 @@ class WorldCustom:
         if self._scenario is not None:
             self._scenario._obs_dirty = False
             self._scenario._auto_reset_done_this_step = False
+            self._scenario._info_batch = None
 
 
 class ScenarioRoadTraffic(BaseScenario):
@@ -387,6 +388,7 @@ class ScenarioRoadTraffic(BaseScenario):
 
     def reset_world_at(self, env_index: Optional[int] = None, agent_index: Optional[int] = None):
         p, env, mp, N = self.parameters, self.env, self.map, self.n_agents
+        self._info_batch = None
         if agent_index is not None:
             assert env_index is not None
             agent_index = int(agent_index)
@@ -456,6 +458,7 @@ class ScenarioRoadTraffic(BaseScenario):
     def done(self):
         """[B] bool (road_traffic.py:1368-1487) + the per-agent resets the reference performs here (:1435-1447, :1456-1473)."""
         is_done = self.env.done.to(torch.bool)
+        self._info_batch = None
         if self.device_side_resets:
             # cpm_mixed: every finished env draws its sub-scenario (path list) from cpm_scenario_probabilities and keeps it for its per-agent resets
             # (world_state_rt_sim.py:313-358): SigmaEnv.default_paths() hands the device sampler the scenario lists instead of one path range
@@ -476,29 +479,40 @@ class ScenarioRoadTraffic(BaseScenario):
         i = self._index(agent)
         ws, nz, B = self.world_state, self.normalizers, self.env.B
         st = agent.state
-        two_pi = 2 * math.pi
-        rot = st.rot % two_pi
-        rot = torch.where(rot > math.pi, rot - two_pi, rot)  # angle_eliminate_two_pi, helper_scenario.py:1276-1289
         empty = agent.action.u is None
         act_v = self.constants.empty_action_vel[:, i] if empty else agent.action.u[:, 0]
         act_s = self.constants.empty_action_steering[:, i] if empty else agent.action.u[:, 1]
+        # The derived entries are elementwise in the agent: they are computed for ALL agents in one batched op each, when agent 0 asks (VMAS collects the infos of
+        # all agents back to back after the step, tests/vmas_env_shim.py), and sliced per agent -- 16 x ~20 small launches become ~20 (same values: same ops).
+        if i == 0 or getattr(self, "_info_batch", None) is None:
+            state = self.env.buffer(capi.BUF_STATE)
+            two_pi = 2 * math.pi
+            rot = state[..., 2:3] % two_pi
+            rot = torch.where(rot > math.pi, rot - two_pi, rot)  # angle_eliminate_two_pi, helper_scenario.py:1276-1289
+            short = ws.ref_paths_agent_related.short_term
+            dl = ws.distances.left_boundaries.min(dim=-1)[0]
+            dr = ws.distances.right_boundaries.min(dim=-1)[0]
+            self._info_batch = dict(
+                pos_nom=state[..., 0:2] / nz.pos_world, rot=rot, rot_nom=rot / nz.rot, vel_nom=state[..., 5:7] / nz.v,
+                ref_nom=(short / nz.pos_world).reshape(B, self.n_agents, -1), distance_ref_nom=ws.distances.ref_paths / nz.distance_ref,
+                dl=dl, dl_nom=dl / nz.distance_lanelet, dr=dr, dr_nom=dr / nz.distance_lanelet,
+                col_agents=ws.collisions.with_agents.to(torch.bool).any(dim=-1), col_lane=ws.collisions.with_lanelets.to(torch.bool),
+                goal=ws.collisions.with_exit_segments.to(torch.bool), lanelet_ids=self._lanelet_table[self.env.buffer(capi.BUF_PATH)[..., 0].long()])
+        ib = self._info_batch
         short = ws.ref_paths_agent_related.short_term[:, i]
-        dl = ws.distances.left_boundaries[:, i].min(dim=-1)[0]
-        dr = ws.distances.right_boundaries[:, i].min(dim=-1)[0]
-        gp = self.env.buffer(capi.BUF_PATH)[:, i, 0].long()
         info = {
-            "pos": st.pos, "pos_nom": st.pos / nz.pos_world, "rot": rot, "rot_nom": rot / nz.rot,
-            "vel": st.vel, "vel_nom": st.vel / nz.v,
+            "pos": st.pos, "pos_nom": ib["pos_nom"][:, i], "rot": ib["rot"][:, i], "rot_nom": ib["rot_nom"][:, i],
+            "vel": st.vel, "vel_nom": ib["vel_nom"][:, i],
             "act_vel": act_v, "act_vel_nom": act_v if empty else act_v / nz.v,
             "act_steer": act_s, "act_steer_nom": act_s if empty else act_s / nz.steering,
-            "ref": short.reshape(B, -1), "ref_nom": (short / nz.pos_world).reshape(B, -1),
-            "distance_ref": ws.distances.ref_paths[:, i], "distance_ref_nom": ws.distances.ref_paths[:, i] / nz.distance_ref,
-            "distance_left_b": dl, "distance_left_b_nom": dl / nz.distance_lanelet,
-            "distance_right_b": dr, "distance_right_b_nom": dr / nz.distance_lanelet,
-            "is_collision_with_agents": ws.collisions.with_agents[:, i].to(torch.bool).any(dim=-1),
-            "is_collision_with_lanelets": ws.collisions.with_lanelets[:, i].to(torch.bool),
-            "is_reach_goal": ws.collisions.with_exit_segments[:, i].to(torch.bool),
-            "ref_lanelet_ids": self._lanelet_table[gp], "path_id": ws.ref_paths_agent_related.path_id[:, i],
+            "ref": short.reshape(B, -1), "ref_nom": ib["ref_nom"][:, i],
+            "distance_ref": ws.distances.ref_paths[:, i], "distance_ref_nom": ib["distance_ref_nom"][:, i],
+            "distance_left_b": ib["dl"][:, i], "distance_left_b_nom": ib["dl_nom"][:, i],
+            "distance_right_b": ib["dr"][:, i], "distance_right_b_nom": ib["dr_nom"][:, i],
+            "is_collision_with_agents": ib["col_agents"][:, i],
+            "is_collision_with_lanelets": ib["col_lane"][:, i],
+            "is_reach_goal": ib["goal"][:, i],
+            "ref_lanelet_ids": ib["lanelet_ids"][:, i], "path_id": ws.ref_paths_agent_related.path_id[:, i],
             "applied_action_vel": ws.applied_action_vel[:, i], "applied_action_steer": ws.applied_action_steer[:, i],
             "nominal_action_vel": ws.nominal_action_vel[:, i], "nominal_action_steer": ws.nominal_action_steer[:, i],
         }
