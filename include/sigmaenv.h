@@ -180,8 +180,9 @@ int sigmaenv_obs_dim(int32_t n_nearing);
  *   [other k] vertices 8  (NO_VERTICES: position 2, relative rotation 1, length 1, width 1) | velocity 2 | steering (STEERING) |
  *             distance (unless NO_DIST_AGENTS) | its short-term path 2*3 in the ego frame (REF_OTHERS)
  * normalised as update_state does (:345-536: positions by 10 lengths, rotations / steering by 2 pi, lengths / widths by 10 lengths).
- * With obs_flags != 0 SIGMAENV_BUF_OBS has sigmaenv_obs_dim_ex columns and is written by a separate kernel after every step / reset /
- * observe (the fused step keeps computing the default row for its own use); sigmaenv_set_slab and sigmaenv_rollout return SIGMAENV_EINVAL. */
+ * With obs_flags != 0 SIGMAENV_BUF_OBS has sigmaenv_obs_dim_full columns; the configured row is assembled INSIDE every kernel that refreshes observations
+ * (the fused step incl. its T-step loop, the resets, sigmaenv_observe), and the rollout record (sigmaenv_set_slab, sigmaenv_step_autoreset_n, sigmaenv_rollout*)
+ * carries that row: [N * D | N | 1] floats per env with D = sigmaenv_obs_dim_full. */
 #define SIGMAENV_OBS_STEERING 1        /* Parameters.is_obs_steering */
 #define SIGMAENV_OBS_REF_OTHERS 2      /* Parameters.is_observe_ref_path_other_agents */
 #define SIGMAENV_OBS_NO_VERTICES 4     /* Parameters.is_observe_vertices == False */
