@@ -737,6 +737,9 @@ __device__ __forceinline__ void observe_tile_default(const sigmaenv_config_t& c,
   const float n_pos = (float)((double)c.length * 10.0);   // normalizers.pos, road_traffic.py:588-592
   const float n_v = c.max_speed;                            // :596
   const float n_dl = (float)((double)c.lane_width * 3.0);   // :599-601 (distance_lanelet also normalises the agent distances)
+  // The observation rows are held to 1e-5, not to the bit (the ego transform is already the rotation form): the normalisers divide through their reciprocals
+  // (<= 1 ulp from the quotient; ~10 instructions less per division, 14 divisions per agent row)
+  const float r_pos = 1.0f / n_pos, r_v = 1.0f / n_v, r_dl = 1.0f / n_dl;
   topk_tile<WAVE>(s, N, K, n_slots, TID, NTHR, real_slot);
   TSO(0);
   Grp<WAVE>::sync();
@@ -766,8 +769,8 @@ __device__ __forceinline__ void observe_tile_default(const sigmaenv_config_t& c,
     }
     float dx = tx - si[0], dy = ty - si[1];
     float ci = s.cs[sl * 2], sn = s.cs[sl * 2 + 1];
-    s.obs[sl * D + pos] = masked ? 1.0f : (dx * ci + dy * sn) / n_pos;
-    s.obs[sl * D + pos + 1] = masked ? 1.0f : (dy * ci - dx * sn) / n_pos;
+    s.obs[sl * D + pos] = masked ? 1.0f : (dx * ci + dy * sn) * r_pos;
+    s.obs[sl * D + pos + 1] = masked ? 1.0f : (dy * ci - dx * sn) * r_pos;
   }
   TSO(2);
   // relative velocities (one lane per (agent, self or observed neighbour)) from the front of the block, the per-agent distances
@@ -788,24 +791,24 @@ __device__ __forceinline__ void observe_tile_default(const sigmaenv_config_t& c,
       float ci = s.cs[sl * 2], si_ = s.cs[sl * 2 + 1], cj = s.cs[sj * 2], sj_ = s.cs[sj * 2 + 1];
       float cr = cj * ci + sj_ * si_, sr = sj_ * ci - cj * si_;   // cos / sin of (psi_j - psi_i) (:439, :447-449)
       if (q == 0) {
-        s.obs[sl * D] = va / n_v;  // [own] only the longitudinal component is observed; cos(0) = 1 (:864-868, :885-887)
+        s.obs[sl * D] = va * r_v;  // [own] only the longitudinal component is observed; cos(0) = 1 (:864-868, :885-887)
       } else {
         int base = 4 + 2 * NS + 11 * (q - 1);
         const bool masked = c.is_apply_mask && s.dist[sl * DIST_STRIDE(N) + s.near[sl * K + (q - 1)]] >= c.distance_mask_agents;  // :717-719
-        s.obs[sl * D + base + 8] = masked ? 0.0f : (va * cr) / n_v;
-        s.obs[sl * D + base + 9] = masked ? 0.0f : (va * sr) / n_v;
+        s.obs[sl * D + base + 8] = masked ? 0.0f : (va * cr) * r_v;
+        s.obs[sl * D + base + 9] = masked ? 0.0f : (va * sr) * r_v;
       }
     } else if (w3 < n3) {
       const int sl = real_slot(w3);
       float ml = INFINITY, mr = INFINITY;
 #pragma unroll
       for (int q = 0; q < 5; ++q) { ml = fminf(ml, s.dleft[sl * 5 + q]); mr = fminf(mr, s.dright[sl * 5 + q]); }
-      s.obs[sl * D + 1 + 2 * NS] = s.dref[sl] / n_dl;        // :376-378, :898-904
-      s.obs[sl * D + 2 + 2 * NS] = ml / n_dl;                // :379-382
-      s.obs[sl * D + 3 + 2 * NS] = mr / n_dl;                // :383-386
+      s.obs[sl * D + 1 + 2 * NS] = s.dref[sl] * r_dl;        // :376-378, :898-904
+      s.obs[sl * D + 2 + 2 * NS] = ml * r_dl;                // :379-382
+      s.obs[sl * D + 3 + 2 * NS] = mr * r_dl;                // :383-386
       for (int k = 0; k < K; ++k) {
         const float dk = s.dist[sl * DIST_STRIDE(N) + s.near[sl * K + k]];
-        s.obs[sl * D + 4 + 2 * NS + 11 * k + 10] = (c.is_apply_mask && dk >= c.distance_mask_agents) ? 1.0f : dk / n_dl;  // :373-375, :747-749
+        s.obs[sl * D + 4 + 2 * NS + 11 * k + 10] = (c.is_apply_mask && dk >= c.distance_mask_agents) ? 1.0f : dk * r_dl;  // :373-375, :747-749
       }
     }
   }

@@ -113,6 +113,9 @@ __device__ __forceinline__ void cr_sincos(float x, float& s, float& c) { sigma_s
 __device__ __forceinline__ float norm2(float x, float y) { return sqrtf(fmaf(y, y, x * x)); }
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 __device__ __forceinline__ float remainder_pos(float a, float b) {  // torch.remainder, b > 0
+  // 0 <= a < b: fmod returns a itself, exactly (the steering-angle wrap of every step lands here); the general routine -- a loop over the exponent
+  // difference -- only runs for the lanes that need it
+  if (a >= 0.0f && a < b) return a;
   float m = fmodf(a, b);
   if (m != 0.0f && m < 0.0f) m += b;
   return m;
