@@ -65,13 +65,16 @@ SIGMA_TRIG_FN void sigma_sincos_f64(double x, double* sn, double* cs) {
 SIGMA_TRIG_FN double sigma_atan_f64(double xx) {
   const double ax = fabs(xx);
   if (ax != ax) return xx;
-  double x = ax, hi = 0.0, lo = 0.0;
+  /* numerator and denominator of the reduced argument are SELECTED, then divided once: the same quotient of the same operands as the four branch forms (a
+   * vector unit evaluates every branch of an if-chain: four float64 divisions of ~25 instructions each became one) */
+  double num = ax, den = 1.0, hi = 0.0, lo = 0.0;
   int red = 1;
   if (ax < 0.4375) { red = 0; }
-  else if (ax < 0.6875) { x = (2.0 * ax - 1.0) / (2.0 + ax); hi = 4.63647609000806093515e-01; lo = 2.26987774529616870924e-17; }
-  else if (ax < 1.1875) { x = (ax - 1.0) / (ax + 1.0); hi = 7.85398163397448278999e-01; lo = 3.06161699786838301793e-17; }
-  else if (ax < 2.4375) { x = (ax - 1.5) / (1.0 + 1.5 * ax); hi = 9.82793723247329054082e-01; lo = 1.39033110312309984516e-17; }
-  else { x = -1.0 / ax; hi = 1.57079632679489655800e+00; lo = 6.12323399573676603587e-17; }
+  else if (ax < 0.6875) { num = 2.0 * ax - 1.0; den = 2.0 + ax; hi = 4.63647609000806093515e-01; lo = 2.26987774529616870924e-17; }
+  else if (ax < 1.1875) { num = ax - 1.0; den = ax + 1.0; hi = 7.85398163397448278999e-01; lo = 3.06161699786838301793e-17; }
+  else if (ax < 2.4375) { num = ax - 1.5; den = 1.0 + 1.5 * ax; hi = 9.82793723247329054082e-01; lo = 1.39033110312309984516e-17; }
+  else { num = -1.0; den = ax; hi = 1.57079632679489655800e+00; lo = 6.12323399573676603587e-17; }
+  const double x = red ? num / den : ax;
   const double z = x * x, w = z * z;
   double s1 = 1.62858201153657823623e-02;
   s1 = fma(s1, w, 4.97687799461593236017e-02);
