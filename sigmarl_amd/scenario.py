@@ -446,7 +446,12 @@ class ScenarioRoadTraffic(BaseScenario):
         return self.env.reward[:, self._index(agent)]
 
     def observation(self, agent):
-        """[B, obs_dim] fp32 (road_traffic.py:1334-1366); uniform noise as observation_provider_rt.py:613-618 when enabled (device side)."""
+        """[B, obs_dim] fp32 (road_traffic.py:1334-1366); uniform noise as observation_provider_rt.py:613-618 when enabled (device side).
+
+        The noise is drawn ON THE DEVICE from the counter-based generator keyed on (Parameters.random_seed, the env's episodes_reset and timer.step, env, agent,
+        column) -- a pure function of the env's own counters, so the fused / separate / T-step launches, any sharding and the rollout record all see the same
+        values.  Two consequences that differ from the reference's ``torch.rand_like`` per call: observing twice at the same counters (a second ``observation()``
+        without a step or reset in between) returns the SAME noise, and seeding torch does not control it -- ``Parameters.random_seed`` does."""
         i = self._index(agent)
         if i == 0 and self._obs_dirty:
             self.env.observe()
