@@ -39,8 +39,15 @@ def one_case(rng, k):
         kw.update(is_obs_steering=bool(rng.integers(2)), is_observe_ref_path_other_agents=bool(rng.integers(2)), is_observe_vertices=bool(rng.integers(2)),
                   is_observe_distance_to_agents=bool(rng.integers(2)), is_observe_distance_to_center_line=bool(rng.integers(2)),
                   is_observe_distance_to_boundaries=bool(rng.integers(2)))
-        if rng.integers(3) == 0:
-            kw.update(is_ego_view=False, is_apply_mask=False)
+        if rng.integers(3) == 0:  # bird view, with or without the (lanelet-relation) mask; a third of those with the full observation where the reference's reshape allows it
+            kw.update(is_ego_view=False)
+            if rng.integers(3) == 0:
+                kw.update(is_partial_observation=False, n_nearing_agents_observed=int(rng.integers(1, 5)))
+                try:
+                    from sigmarl_amd.params import obs_flags
+                    capi.obs_dim(min(kw["n_nearing_agents_observed"], N - 1), obs_flags(Parameters(**kw)), kw["n_points_short_term"], N)
+                except ValueError:
+                    kw.update(is_partial_observation=True, n_nearing_agents_observed=2)
     p = Parameters(**kw)
     cfg = make_config(p, mp, B)
     dev, ora = tp._hip_env(cfg, mp), ob.OracleEnv(cfg, mp)
