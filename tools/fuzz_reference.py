@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--keep", default=None)
     ap.add_argument("--cbf", action="store_true", help="mix in rollouts with the CBF margin reward (tens of minutes each)")
+    ap.add_argument("--full-obs", action="store_true", help="every case in bird view with the full observation (is_partial_observation=False; random switches and n_nearing)")
     ap.add_argument("--only", type=int, default=-1, help="run only this case of the sequence (the others just consume their random draws)")
     args = ap.parse_args()
     sys.path.insert(0, ROOT)
@@ -66,6 +67,20 @@ def main():
                       is_observe_distance_to_boundaries=bool(rng.integers(2)))
             if rng.integers(3) == 0:
                 kw.update(is_ego_view=False, is_apply_mask=bool(rng.integers(2)))  # (with the mask: the lanelet-relation mask on OSM maps)
+        if args.full_obs:  # round 4: the full observation (observation_provider_rt.py:756-851): bird view, all agents, n_nearing chunks -- only shapes the reference's reshape takes
+            from sigmarl_amd import capi
+            from sigmarl_amd.params import Parameters as _P, obs_flags as _of
+            for _ in range(20):
+                cand = dict(is_ego_view=False, is_partial_observation=False, n_nearing_agents_observed=int(rng.integers(1, 5)), is_apply_mask=bool(rng.integers(2)),
+                            is_obs_steering=bool(rng.integers(2)), is_observe_ref_path_other_agents=bool(rng.integers(2)), is_observe_vertices=bool(rng.integers(2)),
+                            is_observe_distance_to_agents=bool(rng.integers(2)), is_observe_distance_to_center_line=bool(rng.integers(2)),
+                            is_observe_distance_to_boundaries=bool(rng.integers(2)))
+                try:
+                    capi.obs_dim(min(cand["n_nearing_agents_observed"], N - 1), _of(_P(n_agents=N, n_points_short_term=ns, **cand)), ns, N)
+                    kw.update(cand)
+                    break
+                except ValueError:
+                    continue
         if args.cbf and rng.integers(4) == 0:  # the CBF margin reward of the reference in front of every step (cbf_qp.py:2534-2804, one Python object per env: VERY slow)
             kw.update(hook="cbf", rew_method=str(rng.choice(["cbf", "cbf_sparse"])), is_using_cbf_training=True, is_solve_qp=False,
                       nom_controller_type=str(rng.choice(["rl", "clf"])), T=int(rng.integers(6, 12)), n_agents=min(N, 4))
