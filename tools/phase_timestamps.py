@@ -24,6 +24,7 @@ f = env.lib.cdll.sigmaenv_debug_timestamps
 f.restype = C.c_int; f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
 ts = np.zeros((B, 16), np.uint64)
 n = f(env.h, ts.ctypes.data_as(C.c_void_p), B)
+sub = ts[:n, [1, 10, 11, 2]].astype(np.int64)  # scan: start, end of S1 (candidate masks), end of S2 (work-list rounds), end (S3)
 stats = ts[:n, 8:10].astype(np.int64)
 ts = ts[:n, :8].astype(np.int64)
 ts = ts[ts[:, 0] > 0]
@@ -36,3 +37,6 @@ print("tile total mean", (ts[:, 7] - ts[:, 0]).mean())
 if stats[:, 1].sum():  # accumulated over the launches above
     per = stats[:, 0] / np.maximum(stats[:, 1], 1)
     print("scan work list: items per tile-step mean %.1f p10 %.0f p50 %.0f p90 %.0f max %.0f; rounds per step %.2f" % (per.mean(), np.percentile(per, 10), np.percentile(per, 50), np.percentile(per, 90), per.max(), stats[:, 1].sum() / (20.0 * len(stats))))
+sub = sub[(sub[:, 0] > 0) & (sub[:, 1] > 0)]
+if len(sub):
+    print("scan split: S1 candidate masks %.0f, S2 work-list rounds %.0f, S3 results %.0f" % ((sub[:, 1] - sub[:, 0]).mean(), (sub[:, 2] - sub[:, 1]).mean(), (sub[:, 3] - sub[:, 2]).mean()))
