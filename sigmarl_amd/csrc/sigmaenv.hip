@@ -401,11 +401,25 @@ __device__ __forceinline__ void mask_stage2(const DevMap& m, const Smem& s, Mask
   // when the rectangle is also tested for collision
   const float MARGIN = 1e-4f;
   const float glx = mt.bx - mt.ax, gly = mt.by - mt.ay;
-  const float dg = point_segment(px, py, mt.ax, mt.ay, glx, gly, glx * glx + gly * gly);
+  // dg only has to be an UPPER bound of the distance to that segment: the distance to ANY point of the segment is one, so the projection parameter may come
+  // from the approximate reciprocal and the root from the 1-ulp instruction (their rounding is far inside MARGIN) -- no IEEE division / square-root sequences
+  float dg;
+  {
+    const float vx = px - mt.ax, vy = py - mt.ay;
+    const float tq = clampf((vx * glx + vy * gly) * __builtin_amdgcn_rcpf(glx * glx + gly * gly), 0.0f, 1.0f);  // (a zero-length segment: NaN -> 0)
+    const float ex = (mt.ax + glx * tq) - px, ey = (mt.ay + gly * tq) - py;
+    dg = __builtin_amdgcn_sqrtf(fmaf(ey, ey, ex * ex)) * 1.000001f + 1e-6f;
+  }
   float T = dg;
   if (pl != 0) {
     const bool stale = stale_first && (sl % N == 0);  // (only evaluated for the step kernel: N is a kernel-uniform divisor there)
-    const float Rq = stale ? query_radius(s.vold + sl * 10, px, py) : m.rect_radius;
+    // the agent whose corner queries are last step's vertices: they lie within the circumradius of last step's position (s.thr, staged by phase A), i.e. within
+    // circumradius + |move| of the new centre -- a bound from one root instead of the exact maximum over the four corners (four roots)
+    float Rq = m.rect_radius;
+    if (stale) {
+      const float mx = px - s.thr[sl * 3], my = py - s.thr[sl * 3 + 1];
+      Rq = (m.rect_radius + __builtin_amdgcn_sqrtf(fmaf(my, my, mx * mx))) * 1.000001f + 1e-6f;
+    }
     T = fmaxf(T + 2.0f * Rq, COLLIDE ? m.rect_radius : 0.0f);
   }
   T += MARGIN;
