@@ -360,7 +360,8 @@ __device__ __forceinline__ bool box_within(const float4 b, float px, float py, f
 struct MaskTask {
   int sl, pl, path, k, npt, nch;
   float ax, ay, bx, by;          // the segment that was closest last step
-  unsigned long long nm_near, nm_far;
+  unsigned long long nm_tight, nm_near, nm_far;
+  int own;                       // chunk of the segment that was closest last step
   const float4* box;
   float px, py, T2;
   unsigned long long rest;  // neighbour-mask bits to test
@@ -371,7 +372,7 @@ __device__ __forceinline__ void mask_stage1(const DevMap& m, MaskTask& mt, int t
   const int pl = mt.pl;
   const float* poly = m.center + (size_t)pl * m.poly_stride + (size_t)path * m.P * 2;
   mt.box = m.chunk_box + ((size_t)path * 3 + pl) * m.nch;
-  const ulonglong2* neigh = m.chunk_neigh + ((size_t)path * 3 + pl) * m.nch;
+  const ulonglong4* neigh = m.chunk_neigh + ((size_t)path * 3 + pl) * m.nch;
   // One round trip: the point count, and -- speculatively, the index is almost always in range -- the segment that was closest
   // last step together with the neighbour masks of its chunk.
   int k = cp - 1;
@@ -380,8 +381,9 @@ __device__ __forceinline__ void mask_stage1(const DevMap& m, MaskTask& mt, int t
   mt.npt = m.n_center[pl * m.n_paths + path];
   const Seg4 sg = load_segment(reinterpret_cast<const float2*>(poly), k);
   mt.ax = sg.ax; mt.ay = sg.ay; mt.bx = sg.bx; mt.by = sg.by;
-  const ulonglong2 nm = neigh[k / SIGMAENV_CHUNK];
-  mt.nm_near = nm.x; mt.nm_far = nm.y;
+  const ulonglong4 nm = neigh[k / SIGMAENV_CHUNK];
+  mt.nm_tight = nm.x; mt.nm_near = nm.y; mt.nm_far = nm.z;
+  mt.own = k / SIGMAENV_CHUNK;
 }
 template <bool COLLIDE>
 __device__ __forceinline__ void mask_stage2(const DevMap& m, const Smem& s, MaskTask& mt, bool stale_first, int N) {
@@ -391,8 +393,9 @@ __device__ __forceinline__ void mask_stage2(const DevMap& m, const Smem& s, Mask
     const int k = npt - 2 < 0 ? 0 : npt - 2;
     const Seg4 sg = load_segment(reinterpret_cast<const float2*>(poly), k);
     mt.ax = sg.ax; mt.ay = sg.ay; mt.bx = sg.bx; mt.by = sg.by;
-    const ulonglong2 nm = (m.chunk_neigh + ((size_t)mt.path * 3 + pl) * m.nch)[k / SIGMAENV_CHUNK];
-    mt.nm_near = nm.x; mt.nm_far = nm.y;
+    const ulonglong4 nm = (m.chunk_neigh + ((size_t)mt.path * 3 + pl) * m.nch)[k / SIGMAENV_CHUNK];
+    mt.nm_tight = nm.x; mt.nm_near = nm.y; mt.nm_far = nm.z;
+    mt.own = k / SIGMAENV_CHUNK;
   }
   const float px = s.st[sl * 8], py = s.st[sl * 8 + 1];
   mt.px = px; mt.py = py;
@@ -429,13 +432,14 @@ __device__ __forceinline__ void mask_stage2(const DevMap& m, const Smem& s, Mask
   // dg away), i.e. in the precomputed neighbour mask of that radius (the wider one mostly serves the agent whose query points are
   // stale): only those few boxes are tested, eight loads in flight at a time.
   mt.fast = T + dg <= m.neigh_radius_far;
-  mt.rest = mt.fast ? ((T + dg <= m.neigh_radius) ? mt.nm_near : mt.nm_far) : 0ull;
+  mt.rest = mt.fast ? ((T + dg <= m.neigh_radius_tight) ? mt.nm_tight : ((T + dg <= m.neigh_radius) ? mt.nm_near : mt.nm_far)) : 0ull;
 }
 __device__ __forceinline__ void mask_stage3(const DevMap& m, const Smem& s, MaskTask& mt, int task) {
   const float px = mt.px, py = mt.py, T2 = mt.T2;
   const int nch = mt.nch;
   unsigned long long mk = 0ull;
   unsigned long long rest = mt.rest;
+  if (mt.fast && mt.own < nch) { mk |= 1ull << mt.own; rest &= ~(1ull << mt.own); }  // (see scan_tile_balanced)
   while (rest) {  // one pass unless the neighbourhood has more than eight chunks (dense map regions with the wide radius)
     int idx[8];
 #pragma unroll
@@ -1912,10 +1916,12 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
   if (const char* e = getenv("SIGMAENV_PRUNE")) prune = prune && atoi(e) != 0;
   float4 *d_box = nullptr, *d_gbox = nullptr;
   std::vector<float4> hb, hg;  // must outlive the asynchronous uploads below
-  std::vector<ulonglong2> hn;
-  ulonglong2* d_neigh = nullptr;
+  std::vector<ulonglong4> hn;
+  ulonglong4* d_neigh = nullptr;
   const float neigh_radius_far = 9.0f * (sqrtf((float)((double)cfg->length / 2.0) * (float)((double)cfg->length / 2.0) +
                                                (float)((double)cfg->width / 2.0) * (float)((double)cfg->width / 2.0)) * 1.00001f + 1e-5f);
+  const float neigh_radius_tight = 3.6f * (sqrtf((float)((double)cfg->length / 2.0) * (float)((double)cfg->length / 2.0) +
+                                                 (float)((double)cfg->width / 2.0) * (float)((double)cfg->width / 2.0)) * 1.00001f + 1e-5f);
   const float neigh_radius = 6.0f * (sqrtf((float)((double)cfg->length / 2.0) * (float)((double)cfg->length / 2.0) +
                                            (float)((double)cfg->width / 2.0) * (float)((double)cfg->width / 2.0)) * 1.00001f + 1e-5f);
   if (prune) {
@@ -1947,26 +1953,27 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
     ALLOC(d_gbox, hg.size() * sizeof(float4));
     H2D(d_gbox, hg.data(), hg.size() * sizeof(float4));
     // neighbour masks: chunks whose box is within neigh_radius of a chunk's box (double arithmetic, inclusive with slack)
-    hn.assign((size_t)np * 3 * nch, make_ulonglong2(0ull, 0ull));
+    hn.assign((size_t)np * 3 * nch, make_ulonglong4(0ull, 0ull, 0ull, 0ull));
     for (size_t pq = 0; pq < (size_t)np * 3; ++pq) {
       for (int a = 0; a < nch; ++a) {
         const float4& A = hb[pq * nch + a];
         if (A.x > A.z) continue;
-        unsigned long long bits = 0ull, bits_far = 0ull;
+        unsigned long long bits = 0ull, bits_far = 0ull, bits_tight = 0ull;
         for (int b2 = 0; b2 < nch; ++b2) {
           const float4& Bx = hb[pq * nch + b2];
           if (Bx.x > Bx.z) continue;
           double dx = std::max(std::max((double)A.x - Bx.z, (double)Bx.x - A.z), 0.0);
           double dy = std::max(std::max((double)A.y - Bx.w, (double)Bx.y - A.w), 0.0);
           const double dd = std::sqrt(dx * dx + dy * dy);
+          if (dd <= (double)neigh_radius_tight + 1e-5) bits_tight |= 1ull << b2;
           if (dd <= (double)neigh_radius + 1e-5) bits |= 1ull << b2;
           if (dd <= (double)neigh_radius_far + 1e-5) bits_far |= 1ull << b2;
         }
-        hn[pq * nch + a] = make_ulonglong2(bits, bits_far);
+        hn[pq * nch + a] = make_ulonglong4(bits_tight, bits, bits_far, 0ull);
       }
     }
-    ALLOC(d_neigh, hn.size() * sizeof(ulonglong2));
-    H2D(d_neigh, hn.data(), hn.size() * sizeof(ulonglong2));
+    ALLOC(d_neigh, hn.size() * sizeof(ulonglong4));
+    H2D(d_neigh, hn.data(), hn.size() * sizeof(ulonglong4));
   }
   const float lh = (float)((double)cfg->length / 2.0), wh = (float)((double)cfg->width / 2.0);
   const float rect_radius = sqrtf(lh * lh + wh * wh) * 1.00001f + 1e-5f;
@@ -1985,6 +1992,7 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
   }
   if (const char* e = getenv("SIGMAENV_FASTDIV")) fast_div = fast_div && atoi(e) != 0;
   h->map = DevMap{d_c, d_l, d_r, d_y, d_nc, d_nl, d_nr, d_loop, P, np, S, d_box, d_gbox, d_neigh, neigh_radius, neigh_radius_far, prune ? nch : 0, nullptr, fast_div, rect_radius, (int32_t)hc.size()};
+  h->map.neigh_radius_tight = neigh_radius_tight;
   {  // start table: derived state of an agent placed on any centre-line point, by the kernels' own scan code
     float* d_tab = nullptr;
     ALLOC(d_tab, (size_t)np * P * START_ROW * sizeof(float));

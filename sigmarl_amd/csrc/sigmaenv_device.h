@@ -34,7 +34,7 @@ struct DevMap {
   // pruning table: axis-aligned boxes of runs of CHUNK consecutive real segments, [n_paths][3 (centre,left,right)][nch]
   const float4* chunk_box;  // (min_x, min_y, max_x, max_y)
   const float4* group_box;  // union boxes of groups of 8 consecutive chunks, [n_paths][3][8]
-  const ulonglong2* chunk_neigh;  // [n_paths][3][nch]: bit c set iff the box of chunk c is within neigh_radius (.x) / neigh_radius_far (.y) of this chunk's box
+  const ulonglong4* chunk_neigh;  // [n_paths][3][nch]: bit c set iff the box of chunk c is within neigh_radius_tight (.x) / neigh_radius (.y) / neigh_radius_far (.z) of this chunk's box
   float neigh_radius, neigh_radius_far;
   int32_t nch;              // boxes per polyline (stride); 0 disables pruning (brute-force scan)
   const float* start_table; // derived state of an agent freshly placed on centre-line point pt of path p, [n_paths][P][START_ROW]
@@ -45,6 +45,7 @@ struct DevMap {
   // sub-scenario from (sigmaenv_set_scenario_lists); used by the device-side resets when the launch passes path_count = SIGMAENV_SCENARIO_LISTS
   int32_t n_lists;
   float cdf0, cdf1, cdf2;
+  float neigh_radius_tight;  // the narrowest neighbour mask: the common case (an agent near its lane) tests the own chunk's +-4 neighbours in ONE pass of eight boxes
   unsigned long long list_first16, list_count16;  // first path / path count of list k in bits [16 k, 16 k + 16): selected by a shift (a select between
                                                   // members becomes a select between their ADDRESSES and puts the whole struct on the stack)
 };
