@@ -58,6 +58,7 @@ __device__ __constant__ uint32_t W_REF_BITS[NS] = SIGMAENV_W_REF_BITS;
 #define NEAR_CAP 8                 /* boundary segments within the circumradius listed per (agent, side); more are tested in place */
 struct Smem {
   float *st, *vold, *vnew, *shrt, *dref, *dleft, *dright, *dbound, *dist, *obs, *thr, *cs, *rew;
+  float* carry;  // [S][3] tan(steering), cos / sin(yaw + sideslip) of the slot's CURRENT state: what the next bicycle step of the same launch starts from (phase A)
   int *path, *cp, *near, *flags, *npts;
   unsigned long long* cmask;  // candidate-chunk masks of the centre / left / right scan, [S][3]            (block layout only)
   uint8_t* cand;              // the first CAND_LIST set bits of every mask as a list of chunk indices, [S][3][CAND_LIST]   (block layout only)
@@ -110,6 +111,7 @@ struct Smem {
     thr = f; f += S * 3;   // step kernel: last step's position (x, y) of the slot, loaded early for the reward phase
     cs = f; f += S * 2;    // cos / sin of the yaw (shared by the vertices and the ego-view transforms)
     rew = f; f += S * 2;   // reward per slot, then done flag per env (rollout slab record)
+    carry = f; f += S * 3;
     int* i = reinterpret_cast<int*>(f);
     path = i; i += S;
     cp = i; i += S * 3;
@@ -128,7 +130,7 @@ struct Smem {
     fresh = col + (size_t)S * COL_STRIDE(N);
   }
   __host__ __device__ static __forceinline__ size_t bytes(int S, int N, int K, int D, bool lean = false) {
-    size_t f = stage_floats(S, D, lean) + (size_t)S * 8 + S * 10 * 2 + S * NS * 2 + S + S * 5 * 2 + S + (size_t)S * DIST_STRIDE(N) + S * 3 + S * 2 + S * 2;
+    size_t f = stage_floats(S, D, lean) + (size_t)S * 8 + S * 10 * 2 + S * NS * 2 + S + S * 5 * 2 + S + (size_t)S * DIST_STRIDE(N) + S * 3 + S * 2 + S * 2 + S * 3;
     size_t i = (size_t)S + S * 3 + S * (K > 0 ? K : 1) + S * 4 + S * 3 + 1;  // (+ 1: the alignment word)
     i += lean ? (size_t)S * 2 : ((size_t)S * 3 * 2 + (size_t)S * 3 * (CAND_LIST / 4));
     return (lean ? 0 : ESCR_BYTES) + (f + i + (size_t)(N * (N - 1) / 2 + 1) / 2) * 4 + (size_t)S * COL_STRIDE(N) + (((size_t)S + 3) & ~(size_t)3) + 16;
@@ -1512,6 +1514,9 @@ __device__ __forceinline__ void place_from_start_table(const DevMap& m, const De
     gv[k] = make_float2(r[START_VERT + 2 * k], r[START_VERT + 2 * k + 1]);
   }
   s.cs[sl * 2] = r[START_CS]; s.cs[sl * 2 + 1] = r[START_CS + 1];
+  // what the next bicycle step of this launch starts from (phase A): steering 0 -> tan 0, sideslip 0, and cos / sin(yaw + 0): the start table's cos / sin of
+  // the yaw (same function, same argument; `+ 0.0f` turns the sine of a yaw of -0.0 into the +0.0 that sin(-0.0 + 0.0) is)
+  s.carry[sl * 3] = 0.0f; s.carry[sl * 3 + 1] = r[START_CS]; s.carry[sl * 3 + 2] = r[START_CS + 1] + 0.0f;
   s.dref[sl] = r[START_DREF];
   g.dist_ref[gi] = r[START_DREF];
 #pragma unroll
