@@ -363,6 +363,7 @@ struct MaskTask {
   int sl, pl, path, k, npt, nch;
   float ax, ay, bx, by;          // the segment that was closest last step
   unsigned long long nm_tight, nm_near, nm_far;
+  int lvl;                       // neighbour level the threshold selects: 0 tight, 1 near, 2 far, 3 none (two-level search over all boxes)
   int own;                       // chunk of the segment that was closest last step
   const float4* box;
   float px, py, T2;
@@ -434,7 +435,8 @@ __device__ __forceinline__ void mask_stage2(const DevMap& m, const Smem& s, Mask
   // dg away), i.e. in the precomputed neighbour mask of that radius (the wider one mostly serves the agent whose query points are
   // stale): only those few boxes are tested, eight loads in flight at a time.
   mt.fast = T + dg <= m.neigh_radius_far;
-  mt.rest = mt.fast ? ((T + dg <= m.neigh_radius_tight) ? mt.nm_tight : ((T + dg <= m.neigh_radius) ? mt.nm_near : mt.nm_far)) : 0ull;
+  mt.lvl = mt.fast ? ((T + dg <= m.neigh_radius_tight) ? 0 : ((T + dg <= m.neigh_radius) ? 1 : 2)) : 3;
+  mt.rest = mt.fast ? (mt.lvl == 0 ? mt.nm_tight : (mt.lvl == 1 ? mt.nm_near : mt.nm_far)) : 0ull;
 }
 __device__ __forceinline__ void mask_stage3(const DevMap& m, const Smem& s, MaskTask& mt, int task) {
   const float px = mt.px, py = mt.py, T2 = mt.T2;
@@ -1740,6 +1742,7 @@ struct sigmaenv {
   unsigned long long* lanelet_neigh = nullptr;  // [n_lanelets] neighbour bit masks
   int n_lanelets = 0, lanelet_pts = 0;
   int DL = 0;                     // floats per agent slot of the kernels' LDS staging of the observation rows (= D unless SIGMAENV_OBS_FULL, see ObsLayout)
+  void* cbf_cand_big = nullptr;   // [B][N (N - 1) C^2] u32: the CBF-QP's candidate pair rows for 33 .. 64 vehicles (allocated by the first such sigmaenv_cbf_qp)
   int32_t* cbf_groups = nullptr;  // [B,N] group index of every vehicle (grouped CBF-QPs), formed by the first sigmaenv_cbf_qp call
   bool cbf_groups_valid = false;
   std::string err;

@@ -26,6 +26,7 @@ ts = np.zeros((B, 16), np.uint64)
 n = f(env.h, ts.ctypes.data_as(C.c_void_p), B)
 sub = ts[:n, [1, 10, 11, 2]].astype(np.int64)  # scan: start, end of S1 (candidate masks), end of S2 (work-list rounds), end (S3)
 stats = ts[:n, 8:10].astype(np.int64)
+lvl = ts[:n, 12:16].astype(np.int64)
 ts = ts[:n, :8].astype(np.int64)
 ts = ts[ts[:, 0] > 0]
 d = np.diff(ts, axis=1)
@@ -40,3 +41,7 @@ if stats[:, 1].sum():  # accumulated over the launches above
 sub = sub[(sub[:, 0] > 0) & (sub[:, 1] > 0)]
 if len(sub):
     print("scan split: S1 candidate masks %.0f, S2 work-list rounds %.0f, S3 results %.0f" % ((sub[:, 1] - sub[:, 0]).mean(), (sub[:, 2] - sub[:, 1]).mean(), (sub[:, 3] - sub[:, 2]).mean()))
+if lvl.sum():
+    steps = np.maximum(stats[:, 1], 1)
+    print("scan neighbour levels: tasks beyond the near level per tile-step %.2f, tile-steps with such a task %.3f, tasks at the tight level per tile-step %.1f" % ((lvl[:, 0] / steps).mean(), (lvl[:, 1] / steps).mean(), (lvl[:, 2] / steps).mean()))
+    print("  of those: the first agent's (stale corner queries) %.2f per tile-step" % ((lvl[:, 3] / steps).mean()))
