@@ -438,7 +438,7 @@ int sigmaenv_cbf_inject_centers(sigmaenv_t* h, const float* centers);
  * rate).  info (optional): DEVICE i32 [B,2] = Newton iterations, converged flag.  SIGMAENV_BUF_CBF_NOMINAL receives what the reference
  * leaves in world_state.nominal_action_*: the safe action when is_apply_cbf_action == 0 (the caller then steps with the policy's action,
  * :1343-1379), the clamped policy action when it is 1 (the caller steps with actions_safe, :1262-1283, 1315-1325); with
- * SIGMAENV_REW_CBF_QP the next step penalises the distance between the two (road_traffic.py:1117-1135).  n_agents <= 32 (SIGMAENV_EINVAL
+ * SIGMAENV_REW_CBF_QP the next step penalises the distance between the two (road_traffic.py:1117-1135).  n_agents <= 64 (SIGMAENV_EINVAL
  * beyond: the 2N x 2N Hessian is kept in LDS).  Repeated launches on the same state return the same bits. */
 int sigmaenv_cbf_qp(sigmaenv_t* h, const float* actions, float* actions_safe, double* u_opt, int32_t* info);
 

@@ -257,13 +257,14 @@ def test_cbf_requires_attach_and_rejects_grouping_without_qp():
 
 
 @pytest.mark.parametrize("nominal,adaptive,N", [("rl", False, 16), ("rl", True, 16), ("clf", False, 16), ("clf", True, 8), ("rl", False, 32), ("rl", False, 3), ("rl", True, 1),
-                                                ("rl", True, 9), ("rl", False, 13), ("clf", True, 5)])  # (2 N not a power of two: the factor's LDS area)
+                                                ("rl", True, 9), ("rl", False, 13), ("clf", True, 5),  # (2 N not a power of two: the factor's LDS area)
+                                                ("rl", False, 33), ("clf", True, 40), ("rl", True, 64)])  # beyond 32 vehicles: packed Hessian, candidate list in HBM
 def test_cbf_qp_vs_oracle_and_kkt(nominal, adaptive, N):
     """The centralized CBF-QP (sigmarl/cbf_qp.py:733-1400): HIP minimiser == the oracle's, and it satisfies the KKT conditions of the
     original problem (checked in numpy on the constraint data; cvxpy / OSQP are absent, see tests/test_cbf_qp.py)."""
     from test_cbf_qp import check_kkt, qp_case
 
-    B = 48 if N <= 16 else 12
+    B = 48 if N <= 16 else (12 if N <= 32 else 6)
     dev, act = qp_case(_hip_env, N=N if N <= 16 else 16, B=B, nominal=nominal, adaptive_lambda=adaptive) if N <= 16 else (None, None)
     if N > 16:  # 32 agents: sampled starts (the set-state fixture has 16 agents per env)
         mp = load_map("cpm_entire")
@@ -340,13 +341,14 @@ def test_cbf_qp_rollout_reward_vs_oracle(apply, nominal):
     ora.close()
 
 
-def test_cbf_qp_dense_cluster_uses_the_full_system():
-    """24 vehicles piled within half a metre: (almost) every vehicle is coupled to others through active pair rows, more than the 16 the
-    compacted register factorisation takes -- the full-system LDS path; same minimiser as the oracle, KKT conditions hold."""
+@pytest.mark.parametrize("N", [24, 40])
+def test_cbf_qp_dense_cluster_uses_the_full_system(N):
+    """24 (40: the packed-Hessian variant) vehicles piled within half a metre: (almost) every vehicle is coupled to others through active pair rows, more than
+    the 16 the compacted register factorisation takes -- the full-system LDS path; same minimiser as the oracle, KKT conditions hold."""
     from test_cbf_qp import check_kkt
 
     z, meta = _cbf_fixture()
-    N, B = 24, 6
+    B = 6
     mp = load_map("cpm_entire")
     p = Parameters(n_agents=N, scenario_type="cpm_entire", dt=0.05, rew_method="cbf", is_solve_qp=True, is_using_cbf_training=True,
                    is_obs_noise=False, is_apply_mask=False)
@@ -630,3 +632,30 @@ def test_grouped_qp_unknown_count_not_a_power_of_two():
             env.close()
         assert outs[0][1][:, 1].all() and outs[1][1][:, 1].all()
         assert np.array_equal(outs[0][2], outs[1][2]) and np.abs(outs[0][0] - outs[1][0]).max() <= 1e-7
+
+
+def test_grouped_qp_beyond_32_vehicles():
+    """40 vehicles in groups of at most 6 (grouped CBF-QPs, cbf_qp.py:1562-2281) on sampled starts: the groups and the minimiser of the packed-Hessian variant
+    equal the oracle's."""
+    N, B = 40, 6
+    mp = load_map("cpm_entire")
+    p = Parameters(n_agents=N, scenario_type="cpm_entire", dt=0.05, rew_method="cbf", is_solve_qp=True, is_using_cbf_training=True, is_obs_noise=False,
+                   is_apply_mask=False, adaptive_lambda=True, is_grouping_agents=True, max_group_size=6, observation_range=0.5)
+    cfg = make_config(p, mp, B)
+    dev, ora = _hip_env(cfg, mp), ob.OracleEnv(cfg, mp)
+    seg_l, seg_r = cbf.load_segment_tables(mp)
+    for e in (dev, ora):
+        e.cbf_attach(cbf.make_cbf_config(p), seg_l, seg_r)
+    dev.env.buffer(capi.BUF_DONE).fill_(1)
+    ora.get(capi.BUF_DONE, copy=False)[:] = 1
+    dev.auto_reset(5, 0, mp.list_first[0], mp.list_count[0])
+    ora.auto_reset(5, 0, mp.list_first[0], mp.list_count[0])
+    act = np.random.default_rng(11).uniform(-0.6, 1.2, (B, N, 2)).astype(np.float32)
+    safe_d, u_d, info_d = dev.cbf_qp(act)[:3]
+    safe_o, u_o, info_o = ora.cbf_qp(act)[:3]
+    assert np.array_equal(dev.cbf_groups(), ora.cbf_groups())
+    assert info_d[:, 1].all() and info_o[:, 1].all(), (info_d, info_o)
+    assert np.abs(u_d - u_o).max() <= 1e-7, np.abs(u_d - u_o).max()
+    assert np.abs(safe_d - safe_o).max() <= 1e-6
+    dev.close()
+    ora.close()
