@@ -334,7 +334,7 @@ int sigmaenv_actor_forward(sigmaenv_t* h, sigmaenv_actor_t* a, const float* obs,
                            uint64_t counter, int32_t deterministic);
 
 /* ---- the reference's networks in the reference's precision ------------------------------------------------------------------------
- * Exact-fp32 shared-parameter MLP on the matrix cores (v_mfma_f32_32x32x2_f32: an fp32 fma chain), Tanh between the layers, hidden width 256:
+ * fp32 shared-parameter MLP on the matrix cores (two arithmetic modes, below), Tanh between the layers, hidden width 256:
  *   actor   sigmarl/modules/decision_making_module.py:34-52   dims = {obs_dim, 256, 256, 256, 4}, one row per agent
  *   critic  sigmarl/modules/optimization_module.py:16-32      dims = {n_agents * obs_dim, 256, 256, 256, 1}, one row per env (MAPPO, centralised:
  *           the observations of all agents of the env concatenated -- exactly a row of SIGMAENV_BUF_OBS viewed as [B, N * D]; the one output
@@ -342,6 +342,16 @@ int sigmaenv_actor_forward(sigmaenv_t* h, sigmaenv_actor_t* a, const float* obs,
  * weights[l]: torch.nn.Linear layout [dims[l+1], dims[l]] row-major fp32 (host pointers), biases[l]: [dims[l+1]].
  * sigmaenv_actor_forward_f32 = this MLP + the distribution head of sigmaenv_actor_forward (same outputs); scratch: device f32 [B * N * 4]. */
 typedef struct sigmaenv_mlp32 sigmaenv_mlp32_t;
+/* How the products of these fp32 networks are formed.  Both modes accumulate in fp32 and are held to torch.nn (fp32, CPU) within 1e-5 by the test-suite.
+ *   EXACT  v_mfma_f32_32x32x2_f32: an fp32 fma chain, one rounding per product -- the fp32 VECTOR rate (157 TF), 1/16 of the half-precision matrix rate
+ *   SPLIT  (default) every fp32 operand as hi + lo, two fp16 numbers (22 significant bits, scaled so that lo is a normal number); w x = w_hi x_hi + w_hi x_lo
+ *          + w_lo x_hi on v_mfma_f32_32x32x16_f16 with exact products: 3/16 of the matrix time.  Measured against fp64 on K = 256 dot products: 3.6e-7 against
+ *          6.4e-7 for the exact chain (tools/mfma_probe/probe_f16_split.hip).  Ranges: |weight| < 255 (else the handle stays EXACT and set_mode(SPLIT)
+ *          returns SIGMAENV_EINVAL), |input| < 4094 (an input outside gives inf / nan rows). */
+#define SIGMAENV_MLP32_EXACT 0
+#define SIGMAENV_MLP32_SPLIT 1
+int sigmaenv_mlp32_set_mode(sigmaenv_mlp32_t* m, int32_t mode);
+int sigmaenv_mlp32_get_mode(const sigmaenv_mlp32_t* m);
 int sigmaenv_mlp32_create(int32_t n_layers, const int32_t* dims, const float* const* weights, const float* const* biases, sigmaenv_mlp32_t** out);
 void sigmaenv_mlp32_destroy(sigmaenv_mlp32_t* m);
 int sigmaenv_mlp32_forward(sigmaenv_t* h, sigmaenv_mlp32_t* m, const float* in, int32_t rows, float* out);

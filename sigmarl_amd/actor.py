@@ -27,9 +27,14 @@ def make_mlp(obs_dim: int = 32, hidden: int = 256, n_out: int = 4) -> torch.nn.S
 
 
 class Mlp32:
-    """``sigmaenv_mlp32_*``: a Tanh MLP with hidden width 256 in exact fp32 (matrix cores); ``forward(env, x[rows, in_dim]) -> [rows, out_dim]``."""
+    """``sigmaenv_mlp32_*``: a Tanh MLP with hidden width 256 in fp32 on the matrix cores; ``forward(env, x[rows, in_dim]) -> [rows, out_dim]``.
+    ``mode``: ``"split"`` (default: every fp32 operand as two fp16 numbers, three exact-product MFMAs per fp32 product, 3/16 of the fp32 matrix time; falls back
+    to exact when a weight is outside +-255) or ``"exact"`` (``v_mfma_f32_32x32x2_f32`` fma chains).  Both are held to torch.nn within 1e-5."""
 
-    def __init__(self, mlp: torch.nn.Module, lib: capi.Library | None = None):
+    def __init__(self, mlp: torch.nn.Module, lib: capi.Library | None = None, mode: str = "split"):
+        if mode not in ("split", "exact"):
+            raise ValueError("mode must be 'split' or 'exact'")
+        self.mode = mode
         # A handle belongs to the library that made it, and an env handle to the build of ITS n_points_short_term (libsigmaenv_ns<k>.so): every call
         # that takes ``env.h`` goes through ``env.lib`` with a network handle created by that same library (one per library, made on first use).
         self.lib = lib or capi.load_library()
@@ -55,8 +60,21 @@ class Mlp32:
             rc = lib.mlp32_create(len(ws), dims.ctypes.data_as(C.c_void_p), wp, bp, C.byref(h))
             if rc != 0:
                 raise RuntimeError(f"sigmaenv_mlp32_create failed with code {rc}")
+            if self.mode == "exact":
+                lib.mlp32_set_mode(h, capi.MLP32_EXACT)
             ent = self._handles[lib.path] = (lib, h)
         return ent[1]
+
+    def set_mode(self, mode: str) -> str:
+        """Switch every handle to ``"split"`` / ``"exact"``; returns the mode in force (a network outside the split form's range stays exact)."""
+        if mode not in ("split", "exact"):
+            raise ValueError("mode must be 'split' or 'exact'")
+        self.mode = mode
+        got = mode
+        for lib, h in self._handles.values():
+            lib.mlp32_set_mode(h, capi.MLP32_SPLIT if mode == "split" else capi.MLP32_EXACT)
+            got = "split" if lib.mlp32_get_mode(h) == capi.MLP32_SPLIT else "exact"
+        return got
 
     def close(self):
         for lib, h in getattr(self, "_handles", {}).values():
@@ -96,12 +114,12 @@ class Critic(Mlp32):
 
 
 class Actor:
-    def __init__(self, mlp: torch.nn.Module, low, high, lib: capi.Library | None = None, precision: str = "fp32"):
+    def __init__(self, mlp: torch.nn.Module, low, high, lib: capi.Library | None = None, precision: str = "fp32", mode: str = "split"):
         if precision not in ("fp32", "bf16"):
             raise ValueError("precision must be 'fp32' (the reference's arithmetic) or 'bf16' (fast inference variant)")
         self.precision = precision
         self.lib = lib or capi.load_library()
-        self._mlp32 = Mlp32(mlp, self.lib)  # the exact network (also kept by the bf16 variant: a caller may ask for either per call)
+        self._mlp32 = Mlp32(mlp, self.lib, mode=mode)  # the exact network (also kept by the bf16 variant: a caller may ask for either per call)
         self._scratch4 = None
         lin = [m for m in mlp.modules() if isinstance(m, torch.nn.Linear)]
         if len(lin) != 4 or lin[1].in_features != 256 or lin[2].out_features != 256 or lin[3].out_features != 4:

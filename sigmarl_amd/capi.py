@@ -107,6 +107,7 @@ def rew_flags_from_method(rew_method: str, is_solve_qp: bool = True) -> int:
 
 
 KERNEL_STEP, KERNEL_CBF_QP, KERNEL_CBF_MARGIN, KERNEL_MLP32, KERNEL_ACTOR_BF16 = range(5)
+MLP32_EXACT, MLP32_SPLIT = 0, 1  # sigmaenv_mlp32_set_mode
 KERNEL_NAMES = ("sigmaenv_step_wave_kernel", "cbf::sigmaenv_cbf_qp_kernel", "cbf::sigmaenv_cbf_kernel", "sigmaenv_mlp32_kernel", "sigmaenv_actor_kernel")
 SCENARIO_LISTS = -1  # path_count of a device-side reset that draws from the handle's sub-scenario lists (cpm_mixed)
 OBS_STEERING, OBS_REF_OTHERS, OBS_NO_VERTICES, OBS_NO_DIST_AGENTS, OBS_NO_DIST_CENTER, OBS_BIRD_VIEW, OBS_BOUNDARY_POINTS, OBS_OPPONENT_PAD = 1, 2, 4, 8, 16, 32, 64, 128
@@ -176,6 +177,8 @@ _PRODUCT_ONLY = {
     "mlp32_create": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "mlp32_destroy": (None, [C.c_void_p]),
     "mlp32_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "mlp32_set_mode": (C.c_int, [C.c_void_p, C.c_int32]),
+    "mlp32_get_mode": (C.c_int, [C.c_void_p]),
     "actor_forward_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
                                     C.c_int32]),
     "rollout_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,

@@ -76,11 +76,12 @@ def test_actor_matches_torch_and_the_bf16_restatement():
     actor.close()
 
 
+@pytest.mark.parametrize("mode", ["split", "exact"])
 @pytest.mark.parametrize("scaled", [False, True])
-def test_fp32_actor_matches_torch_nn(scaled):
-    """The exact-fp32 actor (sigmaenv_actor_forward_f32: v_mfma_f32_32x32x2_f32, an fp32 fma chain) == torch.nn in fp32 within 1e-5 on the
-    default initialisation (and within 1e-4 relative with 1.7 x larger weights, where the pre-activations are ~10): loc, scale and the
-    deterministic action."""
+def test_fp32_actor_matches_torch_nn(scaled, mode):
+    """The fp32 actor (sigmaenv_actor_forward_f32) in both arithmetic modes -- "exact": v_mfma_f32_32x32x2_f32, an fp32 fma chain; "split" (the default): every
+    operand as hi + lo fp16, three exact-product v_mfma_f32_32x32x16_f16 per fp32 product -- == torch.nn in fp32 within 1e-5 on the default initialisation
+    (and within 1e-4 relative with 1.7 x larger weights, where the pre-activations are ~10): loc, scale and the deterministic action."""
     import torch
     from sigmarl_amd.actor import Actor, make_mlp
     from sigmarl_amd.env import SigmaEnv
@@ -96,9 +97,12 @@ def test_fp32_actor_matches_torch_nn(scaled):
                 if isinstance(m, torch.nn.Linear):
                     m.weight.mul_(1.7)
                     m.bias.uniform_(-0.3, 0.3)
-    actor = Actor(mlp, low=[-1.0, -0.6], high=[1.0, 0.6])  # precision "fp32" is the default
+    actor = Actor(mlp, low=[-1.0, -0.6], high=[1.0, 0.6], mode=mode)  # precision "fp32" is the default
+    assert actor._mlp32.set_mode(mode) == mode
     R = env.B * env.N
     obs = (torch.rand((R, env.D), device="cuda") * 2 - 1) * 1.5
+    obs[:64, :4] *= 1e-4  # (values whose fp16 hi / lo parts are subnormal)
+    obs[64:128, 4:8] *= 100.0
     act = torch.zeros((env.B, env.N, 2), device="cuda")
     ls = torch.zeros((env.B, env.N, 4), device="cuda")
     actor.forward(env, act, None, ls, obs=obs, deterministic=True)
@@ -122,9 +126,10 @@ def test_fp32_actor_matches_torch_nn(scaled):
     actor.close()
 
 
-def test_fp32_critic_matches_torch_nn():
-    """The MAPPO critic (optimization_module.py:16-32: centralised, shared parameters, N D -> 256 -> 256 -> 256 -> 1, Tanh) in exact fp32 ==
-    torch.nn in fp32 within 1e-5 on the default initialisation; one value per env, handed to every agent."""
+@pytest.mark.parametrize("mode", ["split", "exact"])
+def test_fp32_critic_matches_torch_nn(mode):
+    """The MAPPO critic (optimization_module.py:16-32: centralised, shared parameters, N D -> 256 -> 256 -> 256 -> 1, Tanh) in fp32 (both arithmetic
+    modes) == torch.nn in fp32 within 1e-5 on the default initialisation; one value per env, handed to every agent."""
     import torch
     from sigmarl_amd.actor import Critic
     from sigmarl_amd.env import SigmaEnv
@@ -136,7 +141,7 @@ def test_fp32_critic_matches_torch_nn():
     env.reset_random(seed=5)
     net = torch.nn.Sequential(torch.nn.Linear(N * env.D, 256), torch.nn.Tanh(), torch.nn.Linear(256, 256), torch.nn.Tanh(), torch.nn.Linear(256, 256), torch.nn.Tanh(),
                               torch.nn.Linear(256, 1))
-    critic = Critic(net)
+    critic = Critic(net, mode=mode)
     v = critic.values(env)
     env.sync()
     assert tuple(v.shape) == (env.B, N, 1)

@@ -13,7 +13,9 @@ env = SigmaEnv(Parameters(n_agents=N, scenario_type="cpm_entire", dt=0.05, is_us
 env.reset_random(seed=1)
 torch.manual_seed(0)
 mlp = make_mlp(env.D)
-actor = Actor(mlp, low=[-1.0, -0.6], high=[1.0, 0.6])
+MODE = os.environ.get("MODE", "split")  # arithmetic of the fp32 network: split (fp16 hi + lo, default) | exact (fp32 MFMA)
+actor = Actor(mlp, low=[-1.0, -0.6], high=[1.0, 0.6], mode=MODE)
+print("mode:", MODE)
 act = torch.zeros((B, N, 2), device="cuda")
 lp = torch.zeros((B, N), device="cuda")
 ls = torch.zeros((B, N, 4), device="cuda")
@@ -37,7 +39,10 @@ for t in range(64):
     actor.forward(env, act, lp, None, seed=1, counter=t)
 ms, n = env.kernel_time_ms(capi.KERNEL_MLP32)
 flops = 2.0 * B * N * (32 * 256 + 2 * 256 * 256 + 256 * 4)
-print("sigmaenv_mlp32_kernel alone: %.2f us per launch over %d brackets = %.1f TFLOP/s = %.1f %% of the 157.3 TFLOP/s fp32 matrix peak" % (ms * 1e3, n, flops / (ms * 1e-3) / 1e12, flops / (ms * 1e-3) / 157.3e12 * 100))
+print("fp32 MLP kernel alone: %.2f us per launch over %d brackets = %.1f TFLOP/s of fp32-equivalent products = %.1f %% of the 157.3 TFLOP/s fp32 matrix peak"
+      % (ms * 1e3, n, flops / (ms * 1e-3) / 1e12, flops / (ms * 1e-3) / 157.3e12 * 100))
+if MODE == "split":
+    print("  split mode issues 3 fp16 matrix products per fp32 product: %.1f TFLOP/s on the fp16 pipe = %.1f %% of its 2.5 PFLOP/s" % (3 * flops / (ms * 1e-3) / 1e12, 3 * flops / (ms * 1e-3) / 2.5e15 * 100))
 T = 256
 for name, kw in (("rollout (policy + step)", {}),):
     torch.cuda.synchronize(); t0 = time.perf_counter()
