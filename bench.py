@@ -280,7 +280,7 @@ class GpuRun:
             mlp = make_mlp(self.D)
             for k, e in enumerate(self.envs):
                 with torch.cuda.stream(self.streams[k]):
-                    self.actors.append(Actor(mlp, low=[-1.0, -0.6109], high=[1.0, 0.6109], precision=args.policy_precision))  # -/+ (max_speed, max_steering)
+                    self.actors.append(Actor(mlp, low=[-1.0, -0.6109], high=[1.0, 0.6109], precision=args.policy_precision, mode=args.policy_mode))  # -/+ (max_speed, max_steering)
                     self.act_bufs.append(torch.zeros((Bs, N, 2), dtype=torch.float32, device=device))
         self.safe_bufs = [torch.zeros((Bs, N, 2), dtype=torch.float32, device=device) for _ in range(S)] if args.cbf_qp else []
         self.W = N * (self.D + 1) + 1
@@ -296,6 +296,17 @@ class GpuRun:
 
     def run_steps(self, t0, n):
         """n steps starting at step index t0: launches of up to T steps (T > 1), else one launch per step and shard."""
+        if self.T == 1 and self.policy_chunked():
+            done = 0
+            while done < n:  # sigmaenv_rollout(_f32): up to chunk_steps x (actor, head, fused step + record + resets) enqueued by ONE binding call
+                k = min(self.chunk_steps if self.gather is not None else 32, n - done)
+                slab = self.gather.chunk() if self.gather is not None else None
+                self.actors[0].rollout(self.env, k, slab=slab, seed=self.seed, counter0=self.counter, path_first=self.pf, path_count=self.pc)
+                self.counter += k
+                if self.gather is not None:
+                    self.gather.commit(k)
+                done += k
+            return
         if self.T == 1:
             for t in range(n):
                 self.one_step(t0 + t)
@@ -305,6 +316,12 @@ class GpuRun:
             k = min(self.T, n - done)
             self.run_chunk(t0 + done, k)
             done += k
+
+    def policy_chunked(self):
+        """--policy without a CBF launch between policy and step, one env shard: the C-side rollout loop enqueues the steps (the host is out of the loop: per-step
+        Python calls cost 0.10 - 0.16 ms per step on the GPU box's host cores, more than the 0.11 ms of GPU work)"""
+        a = self.args
+        return bool(a.policy) and self.fused and not (a.cbf or a.cbf_qp) and self.S == 1 and not a.policy_per_step_calls
 
     def run_chunk(self, t0, k):
         """ONE launch: k <= T fused steps of every env, the record rows of the k steps into the chunk buffer, then the chunk's exchange."""
@@ -601,12 +618,16 @@ def main():
     ap.add_argument("--no-reset", action="store_true", help="diagnostic: leave finished envs un-reset")
     ap.add_argument("--separate-reset", action="store_true", help="two launches per step (sigmaenv_step; sigmaenv_auto_reset) instead of the fused one")
     ap.add_argument("--no-gather", action="store_true", help="diagnostic: no rollout record (and no exchange for N > 1)")
-    ap.add_argument("--streams", type=int, default=2, help="env shards per GPU, each stepped by its own handle on its own HIP stream "
-                    "(envs are independent: same total work per step; the tail of one shard's launch -- its reset-heavy wavefronts -- overlaps the other's)")
+    ap.add_argument("--streams", type=int, default=None, help="env shards per GPU, each stepped by its own handle on its own HIP stream "
+                    "(envs are independent: same total work per step; the tail of one shard's launch -- its reset-heavy wavefronts -- overlaps the other's).  Default 2; "
+                    "1 with --policy (the network kernel holds the CUs' LDS: two shards' launches stretch each other to the full batch's duration -- 0.245 against 0.117 ms per step)")
     ap.add_argument("--policy", action="store_true", help="widening (SURVEY 8f-3): the actor MLP runs on the device before every step "
                     "(sigmaenv_actor_forward) instead of replaying precomputed actions; reported in config.policy")
-    ap.add_argument("--policy-precision", choices=["fp32", "bf16"], default="fp32", help="--policy: the reference's fp32 arithmetic (exact, MFMA f32) or the bf16 "
-                    "inference variant")
+    ap.add_argument("--policy-precision", choices=["fp32", "bf16"], default="fp32", help="--policy: the reference's fp32 arithmetic or the bf16 inference variant")
+    ap.add_argument("--policy-per-step-calls", action="store_true", help="--policy: one Actor.forward + one step call per step from Python instead of the C-side rollout loop")
+    ap.add_argument("--policy-mode", choices=["split", "exact"], default="split", help="--policy with fp32: how the fp32 products are formed on the matrix cores -- split "
+                    "(default: every operand as hi + lo fp16, three exact-product v_mfma_f32_32x32x16_f16 per fp32 product, fp32 accumulation) or exact (v_mfma_f32_32x32x2_f32 fma "
+                    "chains at the fp32 vector rate); both are held to torch.nn fp32 within 1e-5 (tests/test_gpu_actor.py)")
     ap.add_argument("--cbf", action="store_true", help="widening (SURVEY 8f-4): rew_method='cbf' with the QP-free CBF margin reward "
                     "(sigmaenv_cbf_rewards before every step); reported in config.cbf")
     ap.add_argument("--cbf-group-size", type=int, default=0, help="--cbf-qp: solve the grouped CBF-QPs with this max_group_size instead of the centralized QP")
@@ -622,6 +643,8 @@ def main():
                     "rendezvous, env ranges, the chunk exchange (gloo, host buffers tagged by rank and step, checked), barrier / MAX reduction, ONE JSON line from "
                     "rank 0 (`dry_run: true`, `value: 0`) -- so that `torch.distributed.run ... bench.py --gpus 8` can be rehearsed on a box without GPUs")
     args = ap.parse_args()
+    if args.streams is None:
+        args.streams = 1 if args.policy else 2
     ensure_world(args)
     if args.dry_run:
         return dry_run(args)
@@ -728,8 +751,11 @@ def main():
                         + ((f"({T} steps per launch)" if T > 1 else "(one launch per step)") if run.fused else "(two launches)" if not args.no_reset else "(resets disabled)")
                         + ((" + rollout record" + ((" + " + run.gather.mode) if run.gather.collective else "")) if run.gather else ""),
             "n_agents": N, "envs_per_gpu": B, "envs_total": B * world, "distance": dist_label, "scenario": args.scenario, "env_shards_per_gpu": S, "steps_per_launch": T,
-            "policy": (f"actor MLP 32-256-256-256-4 ({args.policy_precision}) on device before every step" if args.policy
+            "policy": (f"actor MLP {D}-256-256-256-4 ({args.policy_precision}" + (f", {args.policy_mode} products" if args.policy_precision == "fp32" else "")
+                       + ") on device before every step" if args.policy
                        else "none in the timed region (precomputed actions resident in HBM)"),
+            **({"policy_enqueue": (f"sigmaenv_rollout{'_f32' if args.policy_precision == 'fp32' else ''}: up to {getattr(run, 'chunk_steps', 32)} x (actor, head, fused step + record + resets) per binding call"
+                                   if getattr(run, "policy_chunked", lambda: False)() else "one Actor.forward + one step call per step and env shard from Python")} if args.policy else {}),
             **({"cbf": ("centralized CBF-QP safety filter of every env (sigmaenv_cbf_qp: 2 N controls, lane + pair constraints, projected "
                         "Newton in float64) solved before every step; the step penalises the deviation from the safe action"
                         + (f"; grouped QPs, max_group_size {args.cbf_group_size}" if args.cbf_group_size > 0 else "") if args.cbf_qp else
@@ -777,6 +803,19 @@ def main():
                               "(float64 projected-Newton solve, fp16 / float64 margin stencils, or MFMA), which is what the small HBM fraction states",
             "kernel_time_share": step_r["kernel_time_share"], "step_kernel": {k: step_r[k] for k in ("achieved", "frac", "kernel_avg_ms", "kernel_launches", "algorithmic_bytes_per_launch")},
         }
+        if dom in (_capi.KERNEL_MLP32, _capi.KERNEL_ACTOR_BF16):
+            # the network kernels are matrix work: their roofline is the matrix pipe they issue on.  fp32 "split" issues three fp16 MFMAs per fp32 product (2.5 PFLOP/s
+            # pipe), "exact" one fp32 MFMA (157.3 TFLOP/s), the bf16 variant one bf16 MFMA (2.5 PFLOP/s)
+            macs = N * Bs * (D * 256 + 2 * 256 * 256 + 256 * 4)
+            split = dom == _capi.KERNEL_MLP32 and args.policy_mode == "split"
+            issued = 2.0 * macs * (3 if split else 1)
+            peak = FP32_PEAK_TFLOPS if (dom == _capi.KERNEL_MLP32 and not split) else 2500.0
+            out["roofline"].update({
+                "bound": "mfma", "achieved": issued / (dms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": issued / (dms * 1e-3) / 1e12 / peak,
+                "fp32_equivalent_tflops": 2.0 * macs / (dms * 1e-3) / 1e12, "hbm_frac": dom_bytes / (dms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "achieved_basis": "the DOMINANT kernel of this workload is the actor network: matrix-pipe FLOP issued per launch (2 x MACs of 32-256-256-256-4 per row; x 3 in split "
+                                  "mode: hi hi + hi lo + lo hi) / its average launch duration by HIP events, against the dense peak of the pipe it issues on "
+                                  "(fp16 / bf16 2.5 PFLOP/s, fp32 157.3 TFLOP/s); fp32_equivalent_tflops counts every fp32 product once"})
         try:  # fp64 / MFMA issue figures of that kernel from its committed PMC pass (tools/make_valu_json.py --kernel)
             with open(os.path.join(ROOT, "profiles", "valu_dominant_latest.json")) as f:
                 vj = json.load(f)

@@ -20,5 +20,5 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 #include "sigmaenv_mlp32s.inc"
 EOS
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -mllvm -disable-machine-licm --cuda-device-only "$@" -S -Rpass-analysis=kernel-resource-usage -o /tmp/_mlp32s.s _mlp_only.hip 2>&1 \
-  | grep -E "error|VGPRs|Scratch|Occupancy" | sed -e 's/.*remark: *//' -e 's/ \[-Rpass.*//'
+  | grep -E "error|Function Name|VGPRs|Scratch|Occupancy" | sed -e 's/.*remark: *//' -e 's/ \[-Rpass.*//'
 rm -f _mlp_only.hip
