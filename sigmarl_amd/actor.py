@@ -3,10 +3,11 @@
 ``Actor`` wraps ``sigmaenv_actor_*`` / ``sigmaenv_rollout`` of the C-ABI: the actor network of
 ``sigmarl/modules/decision_making_module.py:34-82`` (torchrl ``MultiAgentMLP(depth=3, num_cells=256, activation=Tanh, share_params=True)``
 + ``NormalParamExtractor`` + ``TanhNormal``).  Two precisions:
-  ``precision="fp32"`` (default)  the reference's own arithmetic: exact-fp32 MLP on the matrix cores (``sigmaenv_actor_forward_f32``)
+  ``precision="fp32"`` (default)  the reference's fp32 network on the matrix cores (``sigmaenv_actor_forward_f32``); ``mode="split"`` (default) forms every fp32 product
+                                  from three exact fp16 products, ``mode="exact"`` runs fp32 fma chains (2.7 x slower); both within 1e-5 of torch.nn
   ``precision="bf16"``            the fast inference variant: bf16 weights / activations, fp32 accumulation, one fused MFMA kernel; also what
                                   ``sigmaenv_rollout`` (policy + step without the host in the loop) runs
-``Critic`` is the MAPPO critic of ``sigmarl/modules/optimization_module.py:16-32`` (centralised, shared parameters) in exact fp32.
+``Critic`` is the MAPPO critic of ``sigmarl/modules/optimization_module.py:16-32`` (centralised, shared parameters) in fp32 (same modes).
 Weights come from any ``torch.nn.Sequential`` of four ``Linear`` layers (the parameter layout torchrl's shared-parameter MLP has).
 """
 from __future__ import annotations
@@ -131,7 +132,7 @@ class Actor:
             arrs.append(np.ascontiguousarray(m.bias.detach().cpu().numpy(), np.float32))
         self._keep = arrs + [np.ascontiguousarray(low, np.float32), np.ascontiguousarray(high, np.float32)]
         # the bf16 kernel handle exists only for the widths its MFMA tiling takes (sigmaenv_actor_create: obs_dim in {8, 16, 24, 32}); other
-        # observation switches (e.g. is_obs_steering: 35) run the exact-fp32 network, which takes any width
+        # observation switches (e.g. is_obs_steering: 35) run the fp32 network, which takes any width
         self._bf16 = {}  # library path -> (library, handle): see Mlp32
         if precision == "bf16":
             self._bf16_handle(self.lib)
