@@ -265,8 +265,10 @@ int sigmaenv_step_autoreset_many(sigmaenv_t** hs, int32_t n, const float* const*
  * (seed, counter0 + t) and records into slab + t * slab_stride floats ([B, N (D + 1) + 1]; slab may be NULL).  End state, record rows and reset
  * draws are bit-identical to n_steps calls of sigmaenv_step_autoreset with sigmaenv_set_slab(slab + t * slab_stride) before call t; the
  * pointer of sigmaenv_set_slab itself is neither used nor changed.  Every wavefront walks its own env tile through the n_steps steps (envs
- * never read each other), so launch ramp / tail and the host's enqueue are paid once per call.  Not available (EINVAL) with a "cbf" rew_method
- * when n_steps > 1: those need sigmaenv_cbf_rewards / sigmaenv_cbf_qp between the steps. */
+ * never read each other), so launch ramp / tail and the host's enqueue are paid once per call.  With a "cbf" rew_method (after sigmaenv_cbf_attach; EINVAL
+ * without it) the chunk is n_steps x (sigmaenv_cbf_rewards | sigmaenv_cbf_qp on step t's actions, then the fused step -- with the QP's safe action when
+ * is_apply_cbf_action / grouping say so) enqueued back to back: CBFQP.update_qp between policy and env.step (helper_training.py:1616-1627), same bits as the
+ * per-step calls, the host out of the loop. */
 int sigmaenv_step_autoreset_n(sigmaenv_t* h, const float* actions, int32_t n_steps, int64_t action_stride, float* slab, int64_t slab_stride,
                               uint64_t seed, uint64_t counter0, int32_t path_first, int32_t path_count);
 

@@ -2314,6 +2314,9 @@ extern "C" int sigmaenv_step_autoreset(sigmaenv_t* h, const float* actions, uint
   return launch_step(h, actions, seed, counter, path_first, path_count);
 }
 
+extern "C" int sigmaenv_cbf_rewards(sigmaenv_t* h, const float* actions, double* margins);  // sigmaenv_cbf.inc
+extern "C" int sigmaenv_cbf_qp(sigmaenv_t* h, const float* actions, float* actions_safe, double* u_opt, int32_t* info);
+
 // n_steps fused steps (step + rollout record + device-side resets) of every env in ONE launch: the reference's rollout loop over a chunk of steps
 // (helper_training.py:687-788: policy -> env.step -> step_mdp, T times) for actions that are already on the device.  Same end state, same record
 // rows and same reset draws as n_steps calls of sigmaenv_step_autoreset(h, actions + t * action_stride, seed, counter0 + t, ...) with the slab set to
@@ -2328,9 +2331,28 @@ extern "C" int sigmaenv_step_autoreset_n(sigmaenv_t* h, const float* actions, in
     return SIGMAENV_EINVAL;
   }
   if (n_steps > 1 && (h->cfg.rew_flags & (SIGMAENV_REW_CBF | SIGMAENV_REW_CBF_QP))) {
-    // the CBF reward channels / the safe action of step t come from a separate launch between the policy and step t (sigmaenv_cbf_rewards / _qp)
-    h->err = "step_autoreset_n: rew_method with \"cbf\" needs the CBF launch before every step; use sigmaenv_step_autoreset (or sigmaenv_rollout)";
-    return SIGMAENV_EINVAL;
+    // rew_method with "cbf": the reward channels / the safe action of step t come from the CBF launch on step t's actions (CBFQP.update_qp between policy and
+    // env.step, helper_training.py:1616-1627).  The chunk is then n_steps x (CBF launch, fused step + record + resets) enqueued back to back -- the same calls,
+    // hence the same bits, as sigmaenv_cbf_rewards / sigmaenv_cbf_qp + sigmaenv_step_autoreset per step (tests/test_gpu_nstep.py), without returning to the caller.
+    if (!h->cbf_seg4) {
+      h->err = "step_autoreset_n: rew_method with \"cbf\" needs sigmaenv_cbf_attach before a chunk of steps";
+      return SIGMAENV_EINVAL;
+    }
+    for (int t = 0; t < n_steps; ++t) {
+      const float* act = actions + (size_t)t * (size_t)action_stride;
+      const float* step_act = act;
+      int rc;
+      if (h->cfg.rew_flags & SIGMAENV_REW_CBF) {
+        rc = sigmaenv_cbf_rewards(h, act, nullptr);
+      } else {
+        rc = sigmaenv_cbf_qp(h, act, (float*)h->cbf_safe, nullptr, nullptr);
+        if (h->cbf_cfg.is_apply_cbf_action || h->cbf_cfg.is_grouping) step_act = (const float*)h->cbf_safe;  // (as sigmaenv_rollout: cbf_qp.py:2211-2222)
+      }
+      if (rc) return rc;
+      rc = launch_step(h, step_act, seed, counter0 + (uint64_t)t, path_first, path_count, 1, 0, slab ? slab + (size_t)t * (size_t)slab_stride : nullptr, 0, false);
+      if (rc) return rc;
+    }
+    return SIGMAENV_OK;
   }
   return launch_step(h, actions, seed, counter0, path_first, path_count, n_steps, (size_t)action_stride, slab, (size_t)slab_stride, false);
 }

@@ -240,12 +240,55 @@ def test_nstep_rejects_what_it_cannot_do():
     p = Parameters(n_agents=4, scenario_type="cpm_entire", rew_method="cbf", is_solve_qp=False, is_using_cbf_training=True, is_apply_mask=False, is_obs_noise=False)
     dev = _hip_env(make_config(p, mp, 8), mp)
     acts = torch.zeros((2, 8, 4, 2), device="cuda")
-    with pytest.raises(RuntimeError, match="cbf"):
+    with pytest.raises(RuntimeError, match="cbf_attach"):  # a CBF-informed chunk needs the segment tables
         dev.env.step_autoreset_n(acts)
     dev.env.step_autoreset_n(acts[:1])  # one step is the plain fused launch
     with pytest.raises(ValueError):
         dev.env.step_autoreset_n(acts[0])
     dev.close()
+
+
+@pytest.mark.parametrize("qp,apply_action", [(False, False), (True, False), (True, True)])
+def test_nstep_chunk_with_cbf_launches_equals_stepwise_calls(qp, apply_action):
+    """rew_method "cbf" (QP-free margins, the centralized QP, the QP with its safe action applied): a chunk of T steps through ``sigmaenv_step_autoreset_n`` runs
+    the CBF launch on step t's actions before step t (helper_training.py:1616-1627) and is bit-identical to the per-step calls -- every buffer, every record row."""
+    import torch
+    from sigmarl_amd.shard import slab_width
+
+    N, B, T = 6, 40, 5
+    p = Parameters(n_agents=N, scenario_type="cpm_entire", rew_method="cbf", dt=0.05, is_solve_qp=qp, is_using_cbf_training=True, is_apply_cbf_action=apply_action,
+                   is_apply_mask=False, is_obs_noise=False, max_steps=9)
+    from sigmarl_amd.env import NumpyAdapter, SigmaEnv
+
+    one, many = NumpyAdapter(SigmaEnv(p, n_envs=B, device="cuda:0")), NumpyAdapter(SigmaEnv(p, n_envs=B, device="cuda:0"))
+    mp = one.env.map
+    pf, pc = mp.list_first[0], mp.list_count[0]
+    for d in (one, many):
+        d.env.cbf_attach()
+        d.env.buffer(capi.BUF_DONE).fill_(1)
+        d.auto_reset(5, 0, pf, pc)
+    W = slab_width(N, one.env.D)
+    acts = torch.as_tensor(_actions(np.random.default_rng(3), T, B, N, False)).cuda()
+    rec_one = torch.full((T, B, W), float("nan"), device="cuda")
+    rec_many = torch.full((T, B, W), float("nan"), device="cuda")
+    safe = torch.zeros((B, N, 2), device="cuda")
+    for t in range(T):
+        one.env.set_slab(rec_one[t])
+        if qp:
+            one.env.cbf_qp(acts[t], safe)
+            one.env.step_autoreset(safe if apply_action else acts[t], 5, 100 + t, pf, pc)
+        else:
+            one.env.cbf_rewards(acts[t])
+            one.env.step_autoreset(acts[t], 5, 100 + t, pf, pc)
+    one.env.set_slab(None)
+    many.env.step_autoreset_n(acts, rec_many, 5, 100, pf, pc)
+    many.env.sync()
+    assert torch.equal(rec_one.view(torch.int32), rec_many.view(torch.int32)), "record rows differ"
+    for w in INT_BUFS + FLT_BUFS + [capi.BUF_REWARD_INFO]:
+        assert one.get(w).tobytes() == many.get(w).tobytes(), f"buffer {w} differs between the per-step calls and the {T}-step chunk"
+    assert np.abs(one.get(capi.BUF_REWARD_INFO)).sum() > 0
+    one.close()
+    many.close()
 
 
 @pytest.mark.parametrize("N", [1, 2])
