@@ -301,7 +301,11 @@ class GpuRun:
             while done < n:  # sigmaenv_rollout(_f32): up to chunk_steps x (actor, head, fused step + record + resets) enqueued by ONE binding call
                 k = min(self.chunk_steps if self.gather is not None else 32, n - done)
                 slab = self.gather.chunk() if self.gather is not None else None
-                self.actors[0].rollout(self.env, k, slab=slab, seed=self.seed, counter0=self.counter, path_first=self.pf, path_count=self.pc)
+                if self.S == 1:
+                    self.actors[0].rollout(self.env, k, slab=slab, seed=self.seed, counter0=self.counter, path_first=self.pf, path_count=self.pc)
+                else:  # (experiment, --no-gather only: every shard's chain of k steps on its own stream)
+                    for q, e in enumerate(self.envs):
+                        self.actors[q].rollout(e, k, slab=None, seed=self.shard_seeds[q], counter0=self.counter, path_first=self.pf, path_count=self.pc)
                 self.counter += k
                 if self.gather is not None:
                     self.gather.commit(k)
@@ -321,7 +325,7 @@ class GpuRun:
         """--policy without a CBF launch between policy and step, one env shard: the C-side rollout loop enqueues the steps (the host is out of the loop: per-step
         Python calls cost 0.10 - 0.16 ms per step on the GPU box's host cores, more than the 0.11 ms of GPU work)"""
         a = self.args
-        return bool(a.policy) and self.fused and not (a.cbf or a.cbf_qp) and self.S == 1 and not a.policy_per_step_calls
+        return bool(a.policy) and self.fused and not (a.cbf or a.cbf_qp) and (self.S == 1 or self.gather is None) and not a.policy_per_step_calls
 
     def run_chunk(self, t0, k):
         """ONE launch: k <= T fused steps of every env, the record rows of the k steps into the chunk buffer, then the chunk's exchange."""
