@@ -1716,7 +1716,8 @@ struct sigmaenv {
   int wave_G = 1, wave_wpb = 1, wave_grid = 1;  // step kernel: environments per wavefront tile, wavefronts per workgroup, workgroups
   size_t wave_tile_lds = 0;
   int wave_spec = 0;  // agents * 256 + envs per wavefront of a fixed-shape instantiation of the step kernel (2 observed neighbours), else 0
-  sigmaenv_config_t* d_cfg = nullptr;  // device copy of cfg (the step kernel reads it through scalar loads)
+  sigmaenv_config_t* d_cfg = nullptr;  // device copy of cfg (the step kernel reads it through scalar loads): a DevConfig -- the config, then the derived block
+  DevConfig cfg_derived;
   int grid = 1;
   void* bufs[SIGMAENV_BUF_COUNT] = {nullptr};
   size_t buf_bytes[SIGMAENV_BUF_COUNT] = {0};
@@ -2101,7 +2102,8 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
     if (cfg->envs_per_group >= 1 && cfg->envs_per_group * N <= 64) wg = cfg->envs_per_group;
     if (const char* e = getenv("SIGMAENV_WAVE_G")) { int v = atoi(e); if (v >= 1 && v * N <= 64) wg = v; }
     h->wave_G = wg;
-    if (dev_alloc(h, (void**)&h->d_cfg, sizeof(sigmaenv_config_t)) != SIGMAENV_OK || hipMemcpyAsync(h->d_cfg, &h->cfg, sizeof(sigmaenv_config_t), hipMemcpyHostToDevice, h->stream) != hipSuccess) {
+    h->cfg_derived = DevConfig{h->cfg, derive_config(h->cfg)};  // (a member: the asynchronous copy reads it after this function returns)
+    if (dev_alloc(h, (void**)&h->d_cfg, sizeof(DevConfig)) != SIGMAENV_OK || hipMemcpyAsync(h->d_cfg, &h->cfg_derived, sizeof(DevConfig), hipMemcpyHostToDevice, h->stream) != hipSuccess) {
       sigmaenv_destroy(h);
       return SIGMAENV_EHIP;
     }

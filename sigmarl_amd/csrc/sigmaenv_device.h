@@ -50,6 +50,32 @@ struct DevMap {
                                                   // members becomes a select between their ADDRESSES and puts the whole struct on the stack)
 };
 #define SIGMAENV_CHUNK 4
+// Kernel-uniform quantities the step kernel used to derive from the config per lane and step (float64 conversions, a float64 division, a correctly rounded root:
+// ~70 vector instructions per tile-step).  derive_config evaluates the SAME IEEE expressions once on the host (-ffp-contract=off on both sides; sqrtf is correctly
+// rounded on both): the same bits.  The device copy of the config is a DevConfig; kernels that take `const sigmaenv_config_t*` read the derived block behind it.
+struct CfgDerived {
+  float l_wb;       // (float)((double)l_f + (double)l_r)                                   dynamics.py:62-192
+  float k_beta;     // (float)((double)l_r / ((double)l_f + (double)l_r))
+  float lh, wh;     // (float)((double)length / 2.0), (float)((double)width / 2.0)          helper_scenario.py:695-826
+  float diag;       // sqrtf(world_x_dim * world_x_dim + world_y_dim * world_y_dim)         helper_scenario.py:1140-1143
+  float rew_denom;  // (float)((double)max_speed * (double)dt)                               road_traffic.py:986-991
+};
+struct DevConfig {
+  sigmaenv_config_t c;
+  CfgDerived d;
+};
+inline CfgDerived derive_config(const sigmaenv_config_t& c) {
+  CfgDerived d;
+  d.l_wb = (float)((double)c.l_f + (double)c.l_r);
+  d.k_beta = (float)((double)c.l_r / ((double)c.l_f + (double)c.l_r));
+  d.lh = (float)((double)c.length / 2.0);
+  d.wh = (float)((double)c.width / 2.0);
+  const float xx = c.world_x_dim * c.world_x_dim, yy = c.world_y_dim * c.world_y_dim;
+  d.diag = sqrtf(xx + yy);
+  d.rew_denom = (float)((double)c.max_speed * (double)c.dt);
+  return d;
+}
+
 // row of the start table (floats): everything reset_init_distances_and_short_term_ref_path derives for an agent standing on a
 // centre-line point with the map's yaw there -- a pure function of (path, point), computed once at sigmaenv_create by the very
 // kernels' own scan code and copied by the device-side resets
