@@ -744,7 +744,7 @@ __device__ __forceinline__ void topk_tile(const Smem& s, int N, int K, int n_slo
 // over "virtual" slots v = (position in env_sel) * N + agent, so that the lanes stay densely used.
 template <bool WAVE>
 __device__ __forceinline__ void observe_tile_default(const sigmaenv_config_t& c, const Smem& s, const DevBufs& g, const Tile& t,
-                                                     const int* env_sel, int n_sel, bool write_global, const int* tim) {
+                                                     const int* env_sel, int n_sel, bool write_global, const int* tim, const CfgDerived* dvp = nullptr) {
   // tim: the timer rows [nenv][4] of the tile's envs (LDS copy of the step kernel's step loop; default: SIGMAENV_BUF_TIMER) -- the observation
   // noise is keyed on an env's (episodes_reset, timer.step)
   const int N = t.N, K = t.K, D = t.D;
@@ -761,7 +761,8 @@ __device__ __forceinline__ void observe_tile_default(const sigmaenv_config_t& c,
   const float n_dl = (float)((double)c.lane_width * 3.0);   // :599-601 (distance_lanelet also normalises the agent distances)
   // The observation rows are held to 1e-5, not to the bit (the ego transform is already the rotation form): the normalisers divide through their reciprocals
   // (<= 1 ulp from the quotient; ~10 instructions less per division, 14 divisions per agent row)
-  const float r_pos = 1.0f / n_pos, r_v = 1.0f / n_v, r_dl = 1.0f / n_dl;
+  // (dvp: the step kernel hands in the host-derived reciprocals -- derive_config, the same three IEEE divisions -- instead of dividing per lane and call)
+  const float r_pos = dvp ? dvp->r_pos : 1.0f / n_pos, r_v = dvp ? dvp->r_v : 1.0f / n_v, r_dl = dvp ? dvp->r_dl : 1.0f / n_dl;
   topk_tile<WAVE>(s, N, K, n_slots, TID, NTHR, real_slot);
   TSO(0);
   Grp<WAVE>::sync();
@@ -1127,10 +1128,11 @@ __device__ __forceinline__ void observe_tile_variant(const sigmaenv_config_t& c,
 // VARIANTS = false compiles the non-default rows out (the fixed-shape instantiations of the step kernel are only launched with obs_flags == 0)
 template <bool WAVE = false, bool VARIANTS = true>
 __device__ __forceinline__ void observe_tile(const sigmaenv_config_t& c, const Smem& s, const DevBufs& g, const Tile& t, int ts_base = -1,
-                                             const int* env_sel = nullptr, int n_sel = 0, bool write_global = true, const int* tim = nullptr) {
+                                             const int* env_sel = nullptr, int n_sel = 0, bool write_global = true, const int* tim = nullptr,
+                                             const CfgDerived* dvp = nullptr) {
   (void)ts_base;
   if (VARIANTS && c.obs_flags != 0) observe_tile_variant<WAVE>(c, s, g, t, env_sel, n_sel, write_global, tim);
-  else observe_tile_default<WAVE>(c, s, g, t, env_sel, n_sel, write_global, tim);
+  else observe_tile_default<WAVE>(c, s, g, t, env_sel, n_sel, write_global, tim, dvp);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1191,7 +1193,7 @@ struct ResetPrefetch {
 template <bool WAVE = false, bool VARIANTS = true>
 __device__ __forceinline__ void auto_reset_tile(const sigmaenv_config_t& c, const DevMap& m, const DevBufs& g, const Smem& s, const Tile& t,
                                        const unsigned long long* s_mask, const int* s_full, uint64_t seed, uint64_t counter, int path_first,
-                                       int path_count, int obs_mode, const ResetPrefetch& pre, int g_cap = 64, int* lds_tim = nullptr);
+                                       int path_count, int obs_mode, const ResetPrefetch& pre, int g_cap = 64, int* lds_tim = nullptr, const CfgDerived* dvp = nullptr);
 #define MAX_G 64
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1247,7 +1249,8 @@ __global__ void sigmaenv_reset_scatter_kernel(DevBufs g, int N, int n, const int
 // per-env agent bit mask, full[e] the full-env flag.  All threads of the block participate.
 template <bool WAVE = false, bool VARIANTS = true>
 __device__ inline void reset_finish_body(const sigmaenv_config_t& c, const DevBufs& g, const Smem& s, const Tile& t,
-                                         const unsigned long long* agent_mask, const int* full, int with_obs, int g_cap = 64, int* lds_tim = nullptr);
+                                         const unsigned long long* agent_mask, const int* full, int with_obs, int g_cap = 64, int* lds_tim = nullptr,
+                                         const CfgDerived* dvp = nullptr);
 __device__ inline void reset_derive_body(const sigmaenv_config_t& c, const DevMap& m, const DevBufs& g, const Smem& s, const Tile& t,
                                          const unsigned long long* agent_mask, const int* full, int with_obs) {
   const int N = t.N;
@@ -1323,11 +1326,11 @@ __device__ inline void reset_derive_body(const sigmaenv_config_t& c, const DevMa
 // agents in LDS and HBM.
 template <bool WAVE, bool VARIANTS>
 __device__ inline void reset_finish_body(const sigmaenv_config_t& c, const DevBufs& g, const Smem& s, const Tile& t,
-                                         const unsigned long long* agent_mask, const int* full, int with_obs, int g_cap, int* lds_tim) {
+                                         const unsigned long long* agent_mask, const int* full, int with_obs, int g_cap, int* lds_tim, const CfgDerived* dvp) {
   const int N = t.N;
   const int tid = Grp<WAVE>::tid();
 #define TS2(k) PROF_TS2(g, tid, k)
-  const float diag = sqrtf(c.world_x_dim * c.world_x_dim + c.world_y_dim * c.world_y_dim);
+  const float diag = dvp ? dvp->diag : sqrtf(c.world_x_dim * c.world_x_dim + c.world_y_dim * c.world_y_dim);
   for (int p = tid; p < t.slots * N; p += Grp<WAVE>::size()) {
     int si = fdiv(p, g.mN), j = p - si * N;
     int e = fdiv(si, g.mN);
@@ -1368,7 +1371,7 @@ __device__ inline void reset_finish_body(const sigmaenv_config_t& c, const DevBu
         env_sel[0] = cnt;
       }
       Grp<WAVE>::sync();
-      observe_tile<WAVE, VARIANTS>(c, s, g, t, -1, env_sel + 1, env_sel[0], true, lds_tim);
+      observe_tile<WAVE, VARIANTS>(c, s, g, t, -1, env_sel + 1, env_sel[0], true, lds_tim, dvp);
     } else {
       load_tile_for_observation(s, g, t);
       observe_tile<WAVE, VARIANTS>(c, s, g, t);
@@ -1554,15 +1557,20 @@ __device__ __forceinline__ void place_from_start_table(const DevMap& m, const De
 template <bool WAVE, bool VARIANTS>
 __device__ __forceinline__ void auto_reset_tile(const sigmaenv_config_t& c, const DevMap& m, const DevBufs& g, const Smem& s, const Tile& t,
                                        const unsigned long long* s_mask, const int* s_full, uint64_t seed, uint64_t counter, int path_first,
-                                       int path_count, int obs_mode, const ResetPrefetch& pre, int g_cap, int* lds_tim) {
+                                       int path_count, int obs_mode, const ResetPrefetch& pre, int g_cap, int* lds_tim, const CfgDerived* dvp) {
   const int N = t.N;
   const int tid = Grp<WAVE>::tid(), lane = tid & 63, wave = tid >> 6, n_waves = Grp<WAVE>::size() >> 6;
   const bool mixed = path_count < 0;  // SIGMAENV_SCENARIO_LISTS: every env draws from the path list of ITS sub-scenario
   ResetDraw rd{seed, counter, path_first, path_count, c.is_testing_mode, c.env_index_base};
 #define TS2(k) PROF_TS2(g, tid, k)
   TS2(1);
-  const float min_d = sqrtf((float)((double)c.length * (double)c.length + (double)c.width * (double)c.width)) * 1.5f;  // road_traffic.py:679-684
-  const float min_d_sq = min_d * min_d;
+  float min_d_sq;  // road_traffic.py:679-684
+  if (dvp) {
+    min_d_sq = dvp->min_d_sq;
+  } else {
+    const float min_d = sqrtf((float)((double)c.length * (double)c.length + (double)c.width * (double)c.width)) * 1.5f;
+    min_d_sq = min_d * min_d;
+  }
   const int TR = 64 / N > 0 ? 64 / N : 1;  // tries per agent evaluated up front (all agents at once, loads in flight together)
   for (int e = wave; e < t.nenv; e += n_waves) {
     const int b = t.env0 + e;
@@ -1651,7 +1659,7 @@ __device__ __forceinline__ void auto_reset_tile(const sigmaenv_config_t& c, cons
   __threadfence_block();
   Grp<WAVE>::sync();
   TS2(2);
-  reset_finish_body<WAVE, VARIANTS>(c, g, s, t, s_mask, s_full, obs_mode, g_cap, lds_tim);
+  reset_finish_body<WAVE, VARIANTS>(c, g, s, t, s_mask, s_full, obs_mode, g_cap, lds_tim, dvp);
 #undef TS2
 }
 
