@@ -327,6 +327,43 @@ def test_bench_gpus_without_a_launcher_relaunches_itself_and_a_mismatch_is_an_er
     assert "torch.distributed.run" in bad.stderr
 
 
+def test_bench_device_conditioning_is_a_rank_independent_step_count():
+    """bench.py --condition-ms: the conditioning before the W warm-up steps is a STEP COUNT derived from the MAX-reduced cold time (the same on every rank: the ranks
+    must issue the same number of chunk exchanges), whole launches of T steps, at least the requested milliseconds, with a host synchronisation every 8 launches."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    class FakeRun:
+        def __init__(self):
+            self.calls, self.finished = [], 0
+
+        def run_steps(self, t0, n):
+            self.calls.append((t0, n))
+
+        def finish_chunk(self):
+            self.finished += 1
+
+    class FakeTorch:
+        class cuda:
+            syncs = 0
+
+            @staticmethod
+            def synchronize():
+                FakeTorch.cuda.syncs += 1
+
+    for ms, step_s, per in [(200.0, 29e-6, 20), (200.0, 29e-6, 32), (50.0, 0.4e-3, 1), (1.0, 1.0, 4)]:
+        r = FakeRun()
+        FakeTorch.cuda.syncs = 0
+        n = bench.condition_device(r, FakeTorch, ms, step_s, per)
+        assert n % per == 0 and n * step_s >= ms * 1e-3 and (n - per) * step_s < ms * 1e-3
+        assert sum(k for _, k in r.calls) == n and all(k <= 8 * per for _, k in r.calls)
+        assert [t0 for t0, _ in r.calls] == [8 * per * i for i in range(len(r.calls))]  # consecutive step indices: the action windows of the timed runs
+        assert r.finished == len(r.calls) == FakeTorch.cuda.syncs
+    assert bench.condition_device(FakeRun(), FakeTorch, 0.0, 29e-6, 32) == 0
+
+
 @pytest.mark.parametrize("tag,testing", [("train", False), ("test", True)])
 def test_device_sampler_specification_matches_the_reference_distribution(tag, testing):
     """The counter-based reset sampler (oracle side of the specification the HIP kernels share) draws (path, point, speed) with the marginals of
