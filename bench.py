@@ -291,6 +291,9 @@ class GpuRun:
                     self.act_bufs.append(torch.zeros((Bs, N, 2), dtype=torch.float32, device=device))
         self.safe_bufs = [torch.zeros((Bs, N, 2), dtype=torch.float32, device=device) for _ in range(S)] if args.cbf_qp else []
         self.W = N * (self.D + 1) + 1
+        if args.policy and S > 1:  # the shards' rollouts record into one [T, B, W] chunk: step stride B W, shard q starts at row q Bs (sigmaenv_set_rollout_slab_stride)
+            for e in self.envs:
+                e.set_rollout_slab_stride(B * self.W)
         self.act_ptrs = [[self.acts[q].data_ptr() + k * Bs * N * 2 * 4 for k in range(S)] for q in range(self.n_act)]
         self.shard_seeds = [self.seed for k in range(S)]
         self.fused = not (args.no_reset or args.separate_reset)
@@ -307,15 +310,17 @@ class GpuRun:
             done = 0
             while done < n:  # sigmaenv_rollout(_f32): up to chunk_steps x (actor, head, fused step + record + resets) enqueued by ONE binding call
                 k = min(self.chunk_steps if self.gather is not None else 32, n - done)
-                slab = self.gather.chunk() if self.gather is not None else None
+                multi = self.streams if self.S > 1 else None
+                slab = self.gather.chunk(multi) if self.gather is not None else None
                 if self.S == 1:
                     self.actors[0].rollout(self.env, k, slab=slab, seed=self.seed, counter0=self.counter, path_first=self.pf, path_count=self.pc)
-                else:  # (experiment, --no-gather only: every shard's chain of k steps on its own stream)
+                else:  # every shard's chain of k steps on its own stream; shard q records rows [q Bs, (q + 1) Bs) of every step's block of the ONE [T, B, W] chunk
                     for q, e in enumerate(self.envs):
-                        self.actors[q].rollout(e, k, slab=None, seed=self.shard_seeds[q], counter0=self.counter, path_first=self.pf, path_count=self.pc)
+                        sp = (slab.data_ptr() + q * self.Bs * self.W * 4) if slab is not None else None
+                        self.actors[q].rollout(e, k, slab_ptr=sp, seed=self.shard_seeds[q], counter0=self.counter, path_first=self.pf, path_count=self.pc)
                 self.counter += k
                 if self.gather is not None:
-                    self.gather.commit(k)
+                    self.gather.commit(k, multi)
                 done += k
             return
         if self.T == 1:
@@ -332,7 +337,7 @@ class GpuRun:
         """--policy without a CBF launch between policy and step, one env shard: the C-side rollout loop enqueues the steps (the host is out of the loop: per-step
         Python calls cost 0.10 - 0.16 ms per step on the GPU box's host cores, more than the 0.11 ms of GPU work)"""
         a = self.args
-        return bool(a.policy) and self.fused and not (a.cbf or a.cbf_qp) and (self.S == 1 or self.gather is None) and not a.policy_per_step_calls
+        return bool(a.policy) and self.fused and not (a.cbf or a.cbf_qp) and not a.policy_per_step_calls
 
     def run_chunk(self, t0, k):
         """ONE launch: k <= T fused steps of every env, the record rows of the k steps into the chunk buffer, then the chunk's exchange."""
@@ -652,7 +657,9 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="diagnostic: no rollout record (and no exchange for N > 1)")
     ap.add_argument("--streams", type=int, default=None, help="env shards per GPU, each stepped by its own handle on its own HIP stream "
                     "(envs are independent: same total work per step; the tail of one shard's launch -- its reset-heavy wavefronts -- overlaps the other's).  Default 2; "
-                    "1 with --policy (the network kernel holds the CUs' LDS: two shards' launches stretch each other to the full batch's duration -- 0.245 against 0.117 ms per step)")
+                    "with --policy 2 for the fp32 split-product actor (every shard's chain of (actor, head, step) launches is enqueued by sigmaenv_rollout_f32 on its own "
+                    "stream and records into its rows of the one [T, B, W] chunk -- sigmaenv_set_rollout_slab_stride: 0.1008 against 0.1047 ms per step on one stream) and 1 "
+                    "for the exact-fp32 and bf16 actors (bf16: 0.0717 on one stream against 0.0731 on two)")
     ap.add_argument("--policy", action="store_true", help="widening (SURVEY 8f-3): the actor MLP runs on the device before every step "
                     "(sigmaenv_actor_forward) instead of replaying precomputed actions; reported in config.policy")
     ap.add_argument("--policy-precision", choices=["fp32", "bf16"], default="fp32", help="--policy: the reference's fp32 arithmetic or the bf16 inference variant")
@@ -676,7 +683,7 @@ def main():
                     "rank 0 (`dry_run: true`, `value: 0`) -- so that `torch.distributed.run ... bench.py --gpus 8` can be rehearsed on a box without GPUs")
     args = ap.parse_args()
     if args.streams is None:
-        args.streams = 1 if args.policy else 2
+        args.streams = (2 if args.policy_precision == "fp32" and args.policy_mode == "split" else 1) if args.policy else 2
     ensure_world(args)
     if args.dry_run:
         return dry_run(args)

@@ -294,6 +294,12 @@ int sigmaenv_opponent_fill(sigmaenv_t* h, const float* actions);
  * pointer through its rollout buffer; NULL disables the record.  Replaces the per-step tensordict stacking of
  * SyncDataCollectorCustom.rollout (sigmarl/helper_training.py:687-788) for (observation, reward, done). */
 int sigmaenv_set_slab(sigmaenv_t* h, void* dev_ptr);
+/* Stride (in floats) between the record blocks of consecutive steps of sigmaenv_rollout / sigmaenv_rollout_f32: step t records into
+ * slab_base + t * stride.  0 (the default) = B * (N*(D+1)+1), i.e. a [T, B, W] buffer of this handle alone.  A batch that is split over several
+ * handles (env shards on their own HIP streams: shard k owns envs [k Bs, (k+1) Bs) of the batch) records into ONE [T, B_total, W] buffer -- the layout
+ * SyncDataCollectorCustom.rollout stacks (sigmarl/helper_training.py:687-788) -- by passing slab_base + k * Bs * W and the stride B_total * W, as
+ * sigmaenv_step_autoreset_n does through its slab_stride argument.  Returns SIGMAENV_EINVAL for a stride below the handle's own block. */
+int sigmaenv_set_rollout_slab_stride(sigmaenv_t* h, int64_t stride_floats);
 
 /* Blocks until everything enqueued on the handle's stream has finished. */
 int sigmaenv_sync(sigmaenv_t* h);

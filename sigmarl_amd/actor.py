@@ -182,26 +182,28 @@ class Actor:
 
     def rollout(self, env: SigmaEnv, n_steps: int, slab: torch.Tensor | None = None, log_prob: torch.Tensor | None = None,
                 actions: torch.Tensor | None = None, seed: int = 0, counter0: int = 0, path_first: int | None = None, path_count: int | None = None,
-                deterministic: bool = False, precision: str | None = None):
+                deterministic: bool = False, precision: str | None = None, slab_ptr: int | None = None):
         """``n_steps`` x (policy -> fused step + record + resets) enqueued back to back; optional records ``slab [T,B,W]``,
-        ``log_prob [T,B,N]``, ``actions [T,B,N,2]`` (CUDA float32, contiguous).  ``precision`` (default: the actor's): "fp32" = the reference's
+        ``log_prob [T,B,N]``, ``actions [T,B,N,2]`` (CUDA float32, contiguous).  ``slab_ptr``: the record target as a raw device address instead of ``slab`` (an env
+        shard's first row inside a ``[T, B_total, W]`` buffer of the whole batch, with ``env.set_rollout_slab_stride(B_total * W)``).  ``precision`` (default: the actor's): "fp32" = the reference's
         arithmetic (``sigmaenv_rollout_f32``), "bf16" = the fast inference variant (``sigmaenv_rollout``)."""
         if path_first is None:
             path_first, path_count = env.default_paths()
         if not hasattr(self, "_scratch") or self._scratch.shape[0] != env.B or self._scratch.device != env.device:
             self._scratch = torch.zeros((env.B, env.N, 2), dtype=torch.float32, device=env.device)
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+        p_slab = C.c_void_p(int(slab_ptr)) if slab_ptr else p(slab)
         if (precision or self.precision) == "fp32":
             if self._scratch4 is None or self._scratch4.shape[0] != env.B * env.N or self._scratch4.device != env.device:
                 self._scratch4 = torch.empty((env.B * env.N, 4), dtype=torch.float32, device=env.device)
             lo, hi = self._keep[-2], self._keep[-1]
             rc = env.lib.rollout_f32(env.h, self._mlp32.handle(env.lib), lo.ctypes.data_as(C.c_void_p), hi.ctypes.data_as(C.c_void_p), p(self._scratch4), int(n_steps),
-                                      p(self._scratch), p(slab), p(log_prob), p(actions), int(seed), int(counter0), int(path_first), int(path_count),
+                                      p(self._scratch), p_slab, p(log_prob), p(actions), int(seed), int(counter0), int(path_first), int(path_count),
                                       int(bool(deterministic)))
             if rc != 0:
                 raise RuntimeError(f"sigmaenv_rollout_f32 failed with code {rc}: {env.lib.last_error(env.h).decode()}")
             return
-        rc = env.lib.rollout(env.h, self._bf16_handle(env.lib), int(n_steps), p(self._scratch), p(slab), p(log_prob), p(actions), int(seed), int(counter0), int(path_first),
+        rc = env.lib.rollout(env.h, self._bf16_handle(env.lib), int(n_steps), p(self._scratch), p_slab, p(log_prob), p(actions), int(seed), int(counter0), int(path_first),
                               int(path_count), int(bool(deterministic)))
         if rc != 0:
             raise RuntimeError(f"sigmaenv_rollout failed with code {rc}: {env.lib.last_error(env.h).decode()}")

@@ -167,6 +167,7 @@ _PRODUCT_ONLY = {
     "step_time_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "kernel_time_ms": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "set_slab": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "set_rollout_slab_stride": (C.c_int, [C.c_void_p, C.c_int64]),
     "trig_selftest": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "step_autoreset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32]),
     "step_autoreset_n": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32]),

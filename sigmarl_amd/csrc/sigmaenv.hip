@@ -1726,6 +1726,7 @@ struct sigmaenv {
   int wave_spec = 0;  // agents * 256 + envs per wavefront of a fixed-shape instantiation of the step kernel (2 observed neighbours), else 0
   sigmaenv_config_t* d_cfg = nullptr;  // device copy of cfg (the step kernel reads it through scalar loads): a DevConfig -- the config, then the derived block
   DevConfig cfg_derived;
+  size_t rollout_slab_stride = 0;  // floats between the record blocks of consecutive steps of sigmaenv_rollout* (0: B * W)
   int grid = 1;
   void* bufs[SIGMAENV_BUF_COUNT] = {nullptr};
   size_t buf_bytes[SIGMAENV_BUF_COUNT] = {0};
@@ -2418,6 +2419,15 @@ extern "C" int sigmaenv_sync(sigmaenv_t* h) {
 extern "C" int sigmaenv_set_slab(sigmaenv_t* h, void* dev_ptr) {
   if (!h) return SIGMAENV_EINVAL;
   h->buf.slab = reinterpret_cast<float*>(dev_ptr);
+  return SIGMAENV_OK;
+}
+
+// Stride between the record blocks of consecutive steps of sigmaenv_rollout* (0: the handle's own [T, B, W] layout); see include/sigmaenv.h
+extern "C" int sigmaenv_set_rollout_slab_stride(sigmaenv_t* h, int64_t stride_floats) {
+  if (!h) return SIGMAENV_EINVAL;
+  const int64_t own = (int64_t)h->B * ((int64_t)h->N * (h->D + 1) + 1);
+  if (stride_floats != 0 && stride_floats < own) { h->err = "set_rollout_slab_stride: stride below the handle's own record block B * (N * (D + 1) + 1)"; return SIGMAENV_EINVAL; }
+  h->rollout_slab_stride = (size_t)stride_floats;
   return SIGMAENV_OK;
 }
 

@@ -362,6 +362,11 @@ class SigmaEnv:
             raise ValueError(f"slab must be a contiguous float32 CUDA tensor of shape {(self.B, self.N * (self.D + 1) + 1)}")
         self._chk(self.lib.set_slab(self.h, C.c_void_p(slab.data_ptr())), "set_slab")
 
+    def set_rollout_slab_stride(self, stride_floats: int = 0):
+        """Floats between the record blocks of consecutive steps of ``Actor.rollout`` (0: this handle's own ``[T, B, W]`` layout).  An env shard that records into
+        a ``[T, B_total, W]`` buffer of the whole batch passes ``B_total * W`` here and the address of its first row as the rollout's slab pointer."""
+        self._chk(self.lib.set_rollout_slab_stride(self.h, int(stride_floats)), "set_rollout_slab_stride")
+
     # pointer-level variants for rollout loops that precompute their device addresses (no per-call tensor checks / views)
     def set_slab_ptr(self, ptr: int):
         self._chk(self.lib.set_slab(self.h, C.c_void_p(ptr)), "set_slab")

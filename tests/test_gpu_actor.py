@@ -314,6 +314,62 @@ def test_fp32_rollout_equals_stepwise_fp32_calls_with_observation_noise():
         ac.close()
 
 
+def test_two_env_shards_roll_out_into_one_record_buffer():
+    """sigmaenv_set_rollout_slab_stride: a batch split over two handles (shard k = envs [k Bs, (k + 1) Bs), `env_index_base`) rolls out on two streams into ONE
+    [T, B, W] record -- shard k's rows at slab + k Bs W with the step stride B W -- and the record, the log-probabilities and the final buffers equal the
+    unsharded handle's bit for bit (every draw is keyed on the env's index in the whole batch); a stride below the handle's own block is refused."""
+    import torch
+    from sigmarl_amd import capi
+    from sigmarl_amd.actor import Actor, make_mlp
+    from sigmarl_amd.env import SigmaEnv
+    from sigmarl_amd.params import Parameters
+    from sigmarl_amd.shard import slab_width
+
+    B, Bs, T = 64, 32, 5
+    kw = dict(n_agents=16, scenario_type="cpm_entire", is_use_mtv_distance=False, is_apply_mask=False, is_obs_noise=True, obs_noise_level=0.05, random_seed=3)
+    torch.manual_seed(1)
+    whole = SigmaEnv(Parameters(**kw), n_envs=B, device="cuda:0")
+    whole.reset_random(seed=3)
+    mlp = make_mlp(whole.D)
+    W = slab_width(whole.N, whole.D)
+    a_whole = Actor(mlp, low=[-1.0, -0.6], high=[1.0, 0.6])
+    slab = torch.zeros((T, B, W), device="cuda")
+    lp = torch.zeros((T, B, whole.N), device="cuda")
+    a_whole.rollout(whole, T, slab=slab, log_prob=lp, seed=9, counter0=100)
+    whole.sync()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    shards, actors = [], []
+    for k in range(2):
+        with torch.cuda.stream(streams[k]):
+            e = SigmaEnv(Parameters(**kw), n_envs=Bs, device="cuda:0", env_index_base=k * Bs)
+            e.reset_random(seed=3)
+            shards.append(e)
+            actors.append(Actor(mlp, low=[-1.0, -0.6], high=[1.0, 0.6]))
+    with pytest.raises(RuntimeError):
+        shards[0].set_rollout_slab_stride(Bs * W - 1)
+    slab2 = torch.zeros((T, B, W), device="cuda")
+    lp2 = [torch.zeros((T, Bs, whole.N), device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    for k, e in enumerate(shards):
+        e.set_rollout_slab_stride(B * W)
+        actors[k].rollout(e, T, slab_ptr=slab2.data_ptr() + k * Bs * W * 4, log_prob=lp2[k], seed=9, counter0=100)
+    for e in shards:
+        e.sync()
+    assert torch.equal(slab, slab2)
+    assert torch.equal(lp, torch.cat(lp2, dim=1))
+    for w in (capi.BUF_OBS, capi.BUF_STATE, capi.BUF_TIMER, capi.BUF_REWARD):
+        assert torch.equal(whole.buffer(w), torch.cat([e.buffer(w) for e in shards], dim=0))
+    shards[0].set_rollout_slab_stride(0)  # back to the handle's own [T, Bs, W] layout
+    own = torch.zeros((2, Bs, W), device="cuda")
+    actors[0].rollout(shards[0], 2, slab=own, seed=9, counter0=200)
+    shards[0].sync()
+    assert own.abs().sum().item() > 0
+    for e in shards + [whole]:
+        e.close()
+    for a in actors + [a_whole]:
+        a.close()
+
+
 def test_actor_rollout_on_a_short_term_build_variant_equals_stepwise_calls():
     """An env with n_points_short_term = 5 lives in libsigmaenv_ns5.so; Actor / Critic must drive it through THAT library (they bound the
     default NS = 3 build, whose step kernel then ran on buffers laid out for NS = 5).  rollout == actor forward + fused step, call by call, bit for bit,
