@@ -886,7 +886,7 @@ __device__ __forceinline__ float full_obs_value(const sigmaenv_config_t& c, cons
 
 template <bool WAVE>
 __device__ __forceinline__ void observe_tile_variant(const sigmaenv_config_t& c, const Smem& s, const DevBufs& g, const Tile& t, const int* env_sel, int n_sel,
-                                            bool write_global, const int* tim) {
+                                            bool write_global, const int* tim, const CfgDerived* dvp = nullptr) {
   const int N = t.N, K = t.K, F = c.obs_flags;
   const ObsLayout L(F, N, K);
   const int D = L.full ? L.own_w : L.D;   // row stride of the staging area
@@ -906,6 +906,11 @@ __device__ __forceinline__ void observe_tile_variant(const sigmaenv_config_t& c,
   const float n_rot = (float)(2.0 * 3.141592653589793);      // normalizers.rot, :597
   const float n_da = (float)((double)c.length * 10.0);       // normalizers.distance_agent, :605-607
   const float nwx = c.world_x_dim, nwy = c.world_y_dim;      // normalizers.pos_world (bird view, :537-575)
+  // As in the default row, the rows are held to 1e-5, not to the bit: every normaliser divides through its reciprocal (<= 1 ulp from the quotient; ~9 instructions
+  // less per division, two divisions per observed point); the step kernel hands in the host-derived reciprocals (dvp, derive_config)
+  const float r_pos = dvp ? dvp->r_pos : 1.0f / n_pos, r_v = dvp ? dvp->r_v : 1.0f / n_v, r_dl = dvp ? dvp->r_dl : 1.0f / n_dl;
+  const float r_rot = 1.0f / n_rot, r_da = dvp ? dvp->r_pos : 1.0f / n_da;  // (n_da == n_pos; n_rot is a literal: its reciprocal folds)
+  const float r_wx = dvp ? dvp->r_wx : 1.0f / nwx, r_wy = dvp ? dvp->r_wy : 1.0f / nwy;
   const bool bird = L.bird != 0;
   // ---- nearest neighbours (:629-636); the full observation has none and leaves nearing_agents_indices at zero
   if (L.full) {
@@ -988,12 +993,12 @@ __device__ __forceinline__ void observe_tile_variant(const sigmaenv_config_t& c,
     }
     float ox, oy;
     if (bird) {
-      ox = tx / nwx; oy = ty / nwy;
+      ox = tx * r_wx; oy = ty * r_wy;
     } else {  // ego view: rel = R(-psi_i) (p - p_i), helper_scenario.py:1241-1273
       const float dx = tx - si[0], dy = ty - si[1];
       const float ci = s.cs[sl * 2], sn = s.cs[sl * 2 + 1];
-      ox = (dx * ci + dy * sn) / n_pos;
-      oy = (dy * ci - dx * sn) / n_pos;
+      ox = (dx * ci + dy * sn) * r_pos;
+      oy = (dy * ci - dx * sn) * r_pos;
     }
     s.obs[sl * D + pos] = mk ? 1.0f : ox;
     s.obs[sl * D + pos + 1] = mk ? 1.0f : oy;
@@ -1006,21 +1011,21 @@ __device__ __forceinline__ void observe_tile_variant(const sigmaenv_config_t& c,
     const int ebase = fdiv(sl, g.mN) * N;
     const float* si = s.st + sl * 8;
     if (q == 0) {
-      if (bird) { s.obs[sl * D + 3] = si[5] / n_v; s.obs[sl * D + 4] = si[6] / n_v; }
-      else s.obs[sl * D] = norm2(si[5], si[6]) / n_v;
+      if (bird) { s.obs[sl * D + 3] = si[5] * r_v; s.obs[sl * D + 4] = si[6] * r_v; }
+      else s.obs[sl * D] = norm2(si[5], si[6]) * r_v;
     } else {
       const int k = q - 1, j = s.near[sl * K + k], sj = ebase + j, base = L.own_w + k * L.oth_w + L.q_vel;
       const bool mk = masked(sl, ebase, j);
       const float* sjp = s.st + sj * 8;
       if (bird) {
-        s.obs[sl * D + base] = mk ? 0.0f : sjp[5] / n_v;
-        s.obs[sl * D + base + 1] = mk ? 0.0f : sjp[6] / n_v;
+        s.obs[sl * D + base] = mk ? 0.0f : sjp[5] * r_v;
+        s.obs[sl * D + base + 1] = mk ? 0.0f : sjp[6] * r_v;
       } else {
         const float va = norm2(sjp[5], sjp[6]);
         const float ci = s.cs[sl * 2], si_ = s.cs[sl * 2 + 1], cj = s.cs[sj * 2], sj_ = s.cs[sj * 2 + 1];
         const float cr = cj * ci + sj_ * si_, sr = sj_ * ci - cj * si_;  // cos / sin of (psi_j - psi_i)
-        s.obs[sl * D + base] = mk ? 0.0f : (va * cr) / n_v;
-        s.obs[sl * D + base + 1] = mk ? 0.0f : (va * sr) / n_v;
+        s.obs[sl * D + base] = mk ? 0.0f : (va * cr) * r_v;
+        s.obs[sl * D + base + 1] = mk ? 0.0f : (va * sr) * r_v;
       }
     }
   }
@@ -1031,29 +1036,29 @@ __device__ __forceinline__ void observe_tile_variant(const sigmaenv_config_t& c,
     const float* si = s.st + sl * 8;
     float* ob = s.obs + sl * D;
     if (bird) {                                                                                   // [own] position, rotation (:862-877)
-      ob[0] = si[0] / nwx; ob[1] = si[1] / nwy;
-      ob[2] = angle_eliminate_two_pi(si[2]) / n_rot;
+      ob[0] = si[0] * r_wx; ob[1] = si[1] * r_wy;
+      ob[2] = angle_eliminate_two_pi(si[2]) * r_rot;
     }
-    if (L.p_steer >= 0) ob[L.p_steer] = angle_eliminate_two_pi(si[4]) / n_rot;                    // :356-360, :392, :888-892
-    if (L.p_dcen >= 0) ob[L.p_dcen] = s.dref[sl] / n_dl;                                          // :376-378, :898-904
+    if (L.p_steer >= 0) ob[L.p_steer] = angle_eliminate_two_pi(si[4]) * r_rot;                    // :356-360, :392, :888-892
+    if (L.p_dcen >= 0) ob[L.p_dcen] = s.dref[sl] * r_dl;                                          // :376-378, :898-904
     if (!L.n_bnd_pts) {
       float ml = INFINITY, mr = INFINITY;
 #pragma unroll
       for (int q = 0; q < 5; ++q) { ml = fminf(ml, s.dleft[sl * 5 + q]); mr = fminf(mr, s.dright[sl * 5 + q]); }
-      ob[L.p_bnd] = ml / n_dl;                                                                    // :379-386
-      ob[L.p_bnd + 1] = mr / n_dl;
+      ob[L.p_bnd] = ml * r_dl;                                                                    // :379-386
+      ob[L.p_bnd + 1] = mr * r_dl;
     }
     for (int k = 0; k < Kv; ++k) {
       const int j = s.near[sl * K + k], sj = ebase + j, base = L.own_w + k * L.oth_w;
       const bool mk = masked(sl, ebase, j);
       const float* sjp = s.st + sj * 8;
       if (F & SIGMAENV_OBS_NO_VERTICES) {                                                         // rotation, length, width (:437, :551-553, :683-698)
-        ob[base + 2] = (mk ? 0.0f : (bird ? angle_eliminate_two_pi(sjp[2]) : angle_eliminate_two_pi(sjp[2] - si[2]))) / n_rot;
-        ob[base + 3] = c.length / n_da;
-        ob[base + 4] = c.width / n_da;
+        ob[base + 2] = (mk ? 0.0f : (bird ? angle_eliminate_two_pi(sjp[2]) : angle_eliminate_two_pi(sjp[2] - si[2]))) * r_rot;
+        ob[base + 3] = c.length * r_da;
+        ob[base + 4] = c.width * r_da;
       }
-      if (L.q_steer >= 0) ob[base + L.q_steer] = mk ? 0.0f : angle_eliminate_two_pi(sjp[4]) / n_rot;   // :699-706
-      if (L.q_dist >= 0) ob[base + L.q_dist] = mk ? 1.0f : s.dist[sl * DIST_STRIDE(N) + j] / n_dl;      // :373-375, :747-749
+      if (L.q_steer >= 0) ob[base + L.q_steer] = mk ? 0.0f : angle_eliminate_two_pi(sjp[4]) * r_rot;   // :699-706
+      if (L.q_dist >= 0) ob[base + L.q_dist] = mk ? 1.0f : s.dist[sl * DIST_STRIDE(N) + j] * r_dl;      // :373-375, :747-749
     }
     if (!L.full) for (int k = 0; k < L.pad; ++k) ob[L.own_w + K * L.oth_w + k] = 0.0f;             // placeholders, padded BEFORE the noise (:606-611)
   }
@@ -1084,11 +1089,11 @@ __device__ __forceinline__ void observe_tile_variant(const sigmaenv_config_t& c,
       float val = 0.0f;                                                                            // F_DIST: zero (:776-778)
       if (kind == ObsLayout::F_VERT) val = s.vnew[sj * 10 + q] / ((q & 1) ? nwy : nwx);           // :555-563
       else if (kind == ObsLayout::F_POS) val = sjp[q] / (q ? nwy : nwx);                          // :539-546
-      else if (kind == ObsLayout::F_ROT) val = angle_eliminate_two_pi(sjp[2]) / n_rot;            // :550-553
-      else if (kind == ObsLayout::F_LEN) val = c.length / n_da;                                   // :387-389
-      else if (kind == ObsLayout::F_WID) val = c.width / n_da;                                    // :390-391
-      else if (kind == ObsLayout::F_VEL) val = sjp[5 + q] / n_v;                                  // :547-549
-      else if (kind == ObsLayout::F_STEER) val = angle_eliminate_two_pi(sjp[4]) / n_rot;          // :356-360, :392
+      else if (kind == ObsLayout::F_ROT) val = angle_eliminate_two_pi(sjp[2]) * r_rot;            // :550-553
+      else if (kind == ObsLayout::F_LEN) val = c.length * r_da;                                   // :387-389
+      else if (kind == ObsLayout::F_WID) val = c.width * r_da;                                    // :390-391
+      else if (kind == ObsLayout::F_VEL) val = sjp[5 + q] * r_v;                                  // :547-549
+      else if (kind == ObsLayout::F_STEER) val = angle_eliminate_two_pi(sjp[4]) * r_rot;          // :356-360, :392
       else if (kind == ObsLayout::F_REF) val = s.shrt[sj * NS * 2 + q] / ((q & 1) ? nwy : nwx);   // :564-571
       oth[e * L.W_oth + r] = val;
     }
@@ -1131,7 +1136,7 @@ __device__ __forceinline__ void observe_tile(const sigmaenv_config_t& c, const S
                                              const int* env_sel = nullptr, int n_sel = 0, bool write_global = true, const int* tim = nullptr,
                                              const CfgDerived* dvp = nullptr) {
   (void)ts_base;
-  if (VARIANTS && c.obs_flags != 0) observe_tile_variant<WAVE>(c, s, g, t, env_sel, n_sel, write_global, tim);
+  if (VARIANTS && c.obs_flags != 0) observe_tile_variant<WAVE>(c, s, g, t, env_sel, n_sel, write_global, tim, dvp);
   else observe_tile_default<WAVE>(c, s, g, t, env_sel, n_sel, write_global, tim, dvp);
 }
 

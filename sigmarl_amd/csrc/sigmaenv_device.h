@@ -60,6 +60,7 @@ struct CfgDerived {
   float diag;       // sqrtf(world_x_dim * world_x_dim + world_y_dim * world_y_dim)         helper_scenario.py:1140-1143
   float rew_denom;  // (float)((double)max_speed * (double)dt)                               road_traffic.py:986-991
   float r_pos, r_v, r_dl;  // reciprocals of the default observation row's normalisers: 1 / (float)(length * 10), 1 / max_speed, 1 / (float)(lane_width * 3)
+  float r_wx, r_wy;  // 1 / world_x_dim, 1 / world_y_dim (bird view's position normalisers)
   float min_d_sq;   // (sqrtf((float)(length^2 + width^2)) * 1.5f)^2: the minimum start distance of the resets, squared   road_traffic.py:679-684
 };
 struct DevConfig {
@@ -77,6 +78,7 @@ inline CfgDerived derive_config(const sigmaenv_config_t& c) {
   d.rew_denom = (float)((double)c.max_speed * (double)c.dt);
   const float n_pos = (float)((double)c.length * 10.0), n_v = c.max_speed, n_dl = (float)((double)c.lane_width * 3.0);
   d.r_pos = 1.0f / n_pos; d.r_v = 1.0f / n_v; d.r_dl = 1.0f / n_dl;
+  d.r_wx = 1.0f / c.world_x_dim; d.r_wy = 1.0f / c.world_y_dim;
   const float min_d = sqrtf((float)((double)c.length * (double)c.length + (double)c.width * (double)c.width)) * 1.5f;
   d.min_d_sq = min_d * min_d;
   return d;
