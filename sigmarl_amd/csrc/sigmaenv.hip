@@ -2141,6 +2141,8 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_wave_kernel<false, true, 0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_wave_kernel<false, false, 0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_wave_kernel<true, true, 16, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_wave_kernel<true, true, 16, 1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_wave_kernel<true, true, 16, 1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_wave_kernel<true, true, 32, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_wave_kernel<true, true, 8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sigmaenv_step_wave_kernel<true, true, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -2315,6 +2317,8 @@ static int launch_step(sigmaenv* h, const float* actions, uint64_t seed, uint64_
         default: break;
       }
     }
+    if (h->cfg.distance_type != SIGMAENV_DIST_C2C && h->map.fast_div && h->wave_spec == 16 * 256 + 1)  // mtv at the metric's shape: per-rectangle records staged per agent
+      kern = h->cfg.obs_flags != 0 ? sigmaenv_step_wave_kernel<true, true, 16, 1, true, true> : sigmaenv_step_wave_kernel<true, true, 16, 1, false, true>;
     const StepKernArgs ka{h->map, h->buf, actions, slab, act_stride, slab_stride, seed, counter, h->wave_G, (int)h->wave_tile_lds, path_first, path_count, n_steps};
     hipLaunchKernelGGL(kern, dim3(h->wave_grid), dim3(64 * h->wave_wpb), h->wave_tile_lds * h->wave_wpb, h->stream, (const sigmaenv_config_t*)h->d_cfg, ka);
   }

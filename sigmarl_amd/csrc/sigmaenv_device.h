@@ -357,6 +357,70 @@ __device__ inline void mtv_half(const float* va, const float* vb, const float ax
   pos_min = pm;
   any_inside = inside_any;
 }
+// The same with the per-RECTANGLE quantities taken from a staged record instead of being recomputed for every pair the rectangle is part of: its two unit
+// edge axes (a correctly rounded root and two IEEE divisions each) and the extents of its own vertices on them.  rect_mtv_record evaluates them with the very
+// operations of rect_axes / mtv_half, in the same order: mtv_pair_staged(vi, vj, rec_i, rec_j) == mtv_pair(vi, vj) bit for bit.
+// record: ax[0][0], ax[0][1], ax[1][0], ax[1][1], minbb[0], minbb[1], maxbb[0], maxbb[1]
+#define MTV_REC 8
+__device__ inline void rect_mtv_record(const float* v, float* rec) {
+  float ax[2][2];
+  rect_axes(v, ax);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    float mx = -INFINITY, mn = INFINITY;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float pb = v[2 * q] * ax[k][0] + v[2 * q + 1] * ax[k][1];
+      mx = fmaxf(mx, pb); mn = fminf(mn, pb);
+    }
+    rec[2 * k] = ax[k][0]; rec[2 * k + 1] = ax[k][1];
+    rec[4 + k] = mn; rec[6 + k] = mx;
+  }
+}
+__device__ inline void mtv_half_staged(const float* va, const float* recb, float& pos_min, float& omin_out, bool& any_inside) {
+  float maxbb[2], minbb[2], maxab[2], minab[2], pab[4][2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    maxbb[k] = recb[6 + k]; minbb[k] = recb[4 + k]; maxab[k] = -INFINITY; minab[k] = INFINITY;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      float pa = va[2 * v] * recb[2 * k] + va[2 * v + 1] * recb[2 * k + 1];
+      pab[v][k] = pa;
+      maxab[k] = fmaxf(maxab[k], pa); minab[k] = fminf(minab[k], pa);
+    }
+  }
+  float ov0 = fminf(maxbb[0], maxab[0]) - fmaxf(minbb[0], minab[0]);
+  float ov1 = fminf(maxbb[1], maxab[1]) - fmaxf(minbb[1], minab[1]);
+  float omin = fminf(ov0, ov1);
+  omin_out = omin;
+  bool inside_any = false;
+  float pm = INFINITY;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    float g[2];
+    bool inside = true;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      float p = pab[v][k];
+      g[k] = (p - minbb[k]) * (p <= minbb[k] ? 1.0f : 0.0f) + (maxbb[k] - p) * (p >= maxbb[k] ? 1.0f : 0.0f);
+      inside = inside && (p > minbb[k]) && (p < maxbb[k]);
+    }
+    pm = fminf(pm, norm2(g[0], g[1]));
+    float neg = -omin * (inside ? 1.0f : 0.0f);
+    if (fabsf(neg) > 0.0f) inside_any = true;
+  }
+  pos_min = pm;
+  any_inside = inside_any;
+}
+__device__ inline float mtv_pair_staged(const float* vi, const float* vj, const float* reci, const float* recj) {
+  float pij, pji, omin_j, omin_i;
+  bool neg_ij, neg_ji;
+  mtv_half_staged(vi, recj, pij, omin_j, neg_ij);
+  mtv_half_staged(vj, reci, pji, omin_i, neg_ji);
+  float d = fminf(pij, pji);
+  if (neg_ij || neg_ji) d = -fminf(omin_j, omin_i);
+  return d;
+}
 __device__ inline float mtv_pair(const float* vi, const float* vj) {
   float axi[2][2], axj[2][2], pij, pji, omin_j, omin_i;
   bool neg_ij, neg_ji;
