@@ -1367,7 +1367,10 @@ __device__ inline void reset_finish_body(const sigmaenv_config_t& c, const DevBu
     __threadfence_block();
     Grp<WAVE>::sync();
     TS2(5);
-    if (with_obs == 2) {
+    if (with_obs == 2 && t.nenv == 1 && agent_mask[0]) {
+      // a one-env tile (the 16 x 1 instantiations know it at compile time): the touched env IS the tile -- no env list, no slot indirection
+      observe_tile<WAVE, VARIANTS>(c, s, g, t, -1, nullptr, 0, true, lds_tim, dvp);
+    } else if (with_obs == 2) {
       // every input of the observation is in LDS (fused tail / a tile whose envs were all reset): only the touched envs' rows change
       int* env_sel = const_cast<int*>(full) + g_cap + 2;  // after s_full, s_any and the step kernel's pair counter
       if (tid == 0) {
