@@ -204,7 +204,11 @@ class Library:
         sigs = dict(_SIGS)
         sigs.update(extra or {})
         self.names = list(sigs)
+        # SIGMAENV_LIB_OLD_ABI=1 (tools/ab_libs.sh only): an OLDER build of the HIP library as the A/B baseline may lack the newest entry points
+        lenient = os.environ.get("SIGMAENV_LIB_OLD_ABI") == "1" and "SIGMAENV_LIB" in os.environ
         for name, (res, args) in sigs.items():
+            if lenient and not hasattr(self.cdll, prefix + name):
+                continue
             f = getattr(self.cdll, prefix + name)  # AttributeError if the symbol is missing
             f.restype = res
             f.argtypes = args

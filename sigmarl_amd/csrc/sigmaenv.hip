@@ -2156,7 +2156,7 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
   return SIGMAENV_OK;
 }
 
-#include "sigmaenv_obs_variant.inc"
+#include "sigmaenv_opponent_fill.inc"
 
 extern "C" int sigmaenv_set_lanelets(sigmaenv_t* h, int32_t n_lanelets, int32_t max_points, const float* centers, const uint64_t* neighbors) {
   if (!h) return SIGMAENV_EINVAL;
