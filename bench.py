@@ -5,11 +5,13 @@ Contract (see the round prompt): ``python bench.py --gpus N --steps K --warmup W
 ``python -m torch.distributed.run`` with one rank per GPU.  W untimed warm-up steps, then exactly K timed steps bracketed by a
 barrier + torch.cuda.synchronize() on both sides, MAX over ranks, rank 0 prints ONE JSON line.
 
-Device conditioning (--condition-ms, default 200): an MI355X that idled for ~10 ms is back at its idle clocks and needs tens of milliseconds of load to
-reach its sustained ones -- a timed region of 20 steps (0.6 ms) sees 29 us per step, a rollout loop that has been running for 50 ms sees 26.3.  bench.py
-therefore measures twice, each time W warm-up + K timed steps exactly as above: FIRST on the device as the setup left it (reported in
-config.cold_start), then, after --condition-ms of the same step launches, again: that second measurement is `value` (and everything derived from it:
-ms_per_step, roofline).  --condition-ms 0 skips the conditioning: `value` is then the cold-start figure.
+`value` is the contract measurement to the letter: W warm-up steps, then K timed steps, on the device as the setup left it.  An MI355X that idled for
+~10 ms is back at its idle clocks and needs tens of milliseconds of load to reach its sustained ones -- a timed region of 20 steps (0.6 ms) sees 29 us per
+step, a rollout loop that has been running for 50 ms sees 26.3 -- so bench.py ALSO reports what a running rollout loop sees: after `value` is taken it runs
+--condition-ms (default 200) of the same step launches and then W + K steps again: `value_sustained` / `ms_per_step_sustained` at the top level
+(`warmup_effective_steps_sustained` says how many steps preceded that timed region), details in config.sustained.  --condition-ms 0 skips it.  Rounds
+1-3 reported the contract figure as `value`, round 4 the sustained one (with the contract figure in config.cold_start); from round 5 on `value` is the
+contract figure again and stays comparable with rounds 1-3 and with the driver's clock.
 
 A "step" is one pass of the hot path over one batch of synthetic input: agents x envs stepped once by the fused kernel, which also writes
 the rollout record of the step (observation incl. the terminal one, reward, done -- the reference's step_and_maybe_reset keeps both the
@@ -644,10 +646,10 @@ def main():
     ap.add_argument("--sweep-steps", type=int, default=64)
     ap.add_argument("--chunk", type=int, default=0, help="steps per launch (sigmaenv_step_autoreset_n); 0 = the largest divisor of --steps up to 32; 1 = one launch "
                     "per step (sigmaenv_step_autoreset); modes with a launch between the steps (--policy, --cbf, --cbf-qp, --separate-reset) always use 1")
-    ap.add_argument("--condition-ms", type=float, default=200.0, help="device conditioning before the W warm-up steps: this many milliseconds of the SAME step launches, "
-                    "so that the timed steps run at the GPU's sustained clocks (an MI355X that idled for 10 ms is back at its idle clocks, and a launch of 20 steps -- "
-                    "0.6 ms -- is over before they have risen: 29 us per step cold against 26.5 us sustained).  The contract's W + K steps on the device AS THE SETUP "
-                    "LEFT IT are measured first and reported in config.cold_start.  0: no conditioning (value == the cold-start figure)")
+    ap.add_argument("--condition-ms", type=float, default=200.0, help="after `value` (the contract's W warm-up + K timed steps on the device as the setup left it) is taken: this "
+                    "many milliseconds of the SAME step launches, then W + K steps again -- the GPU's sustained clocks, what a running rollout loop sees (an MI355X that idled "
+                    "for 10 ms is back at its idle clocks, and a launch of 20 steps -- 0.6 ms -- is over before they have risen: 29 us per step against 26.5 sustained).  "
+                    "Reported as value_sustained / config.sustained; 0 skips it")
     ap.add_argument("--no-one-stream", "--no-compare", dest="no_compare", action="store_true",
                     help="skip the additional per-step-launch measurement reported in config.per_step_launch")
     ap.add_argument("--emulate-ranks", type=int, default=0, help="after the headline: BASELINE config 3's workload on this ONE GPU -- R shards of --envs-per-gpu envs "
@@ -723,33 +725,34 @@ def main():
     # nothing but the warm-up steps runs on the GPU right before the timed region (no reduction kernel, no device-to-host copy: both would let the
     # queue run empty and the first timed launch pay for it)
     run.arm_timing()  # arms the HIP-event bracketing of the step launches (on the env's stream)
-    cold = None
-    resets_before = run.episodes_reset()  # (a torch reduction + a device-to-host copy: BEFORE everything that is timed or conditions the device)
+    resets_before = run.episodes_reset()  # (a torch reduction + a device-to-host copy: BEFORE everything that is timed)
     steps_counted = args.warmup + args.steps
-    if args.condition_ms > 0 and not args.surface:
-        # (1) the contract to the letter on the device as the setup left it: W warm-up steps, K timed steps -> config.cold_start
-        run.run_steps(0, args.warmup)
-        run.finish_chunk()
-        torch.cuda.synchronize()
-        run.kernel_timing()
-        el_cold = timed(run, args.steps, args.warmup, use_dist, dist, torch, device)
-        kt_cold = run.kernel_timing()
-        from sigmarl_amd import capi as _capi0
-        k_ms, k_n = kt_cold.get(_capi0.KERNEL_STEP, (0.0, 0))
-        cold = {"value": args.agents * B * world * args.steps / el_cold, "ms_per_step": el_cold / args.steps * 1e3,
-                "step_kernel_ms_per_launch": k_ms, "step_kernel_launches_bracketed": k_n,
-                "note": "the same W warm-up + K timed steps, measured FIRST on the device as the setup left it (GPU clocks at their idle level)"}
-        # (2) device conditioning: the same launches for --condition-ms (a step count derived from the MAX-reduced cold time: equal on every rank, so that the ranks
-        # issue the same number of chunk exchanges)
-        n_cond = condition_device(run, torch, args.condition_ms, el_cold / args.steps, T)
-        cold["conditioning_steps"] = n_cond
-        steps_counted += args.warmup + args.steps + n_cond
+    # (1) `value`: the contract to the letter on the device as the setup left it -- W warm-up steps, K timed steps
     run.run_steps(0, args.warmup)
     run.finish_chunk()
     torch.cuda.synchronize()
     run.kernel_timing()  # drops the warm-up launches' brackets
     elapsed = timed(run, args.steps, args.warmup, use_dist, dist, torch, device)
     ktimes = run.kernel_timing()
+    sustained = None
+    if args.condition_ms > 0 and not args.surface:
+        # (2) what a running rollout loop sees: the same launches for --condition-ms (a step count derived from the MAX-reduced time of (1): equal on every rank, so
+        # that the ranks issue the same number of chunk exchanges), then W + K steps again
+        n_cond = condition_device(run, torch, args.condition_ms, elapsed / args.steps, T)
+        run.run_steps(0, args.warmup)
+        run.finish_chunk()
+        torch.cuda.synchronize()
+        run.kernel_timing()
+        el_s = timed(run, args.steps, args.warmup, use_dist, dist, torch, device)
+        kt_s = run.kernel_timing()
+        from sigmarl_amd import capi as _capi0
+        k_ms, k_n = kt_s.get(_capi0.KERNEL_STEP, (0.0, 0))
+        sustained = {"value": args.agents * B * world * args.steps / el_s, "ms_per_step": el_s / args.steps * 1e3,
+                     "step_kernel_ms_per_launch": k_ms, "step_kernel_launches_bracketed": k_n, "conditioning_steps": n_cond,
+                     "warmup_effective_steps": 2 * args.warmup + args.steps + n_cond,
+                     "note": f"the same W warm-up + K timed steps, measured AFTER `value` and {args.condition_ms:g} ms ({n_cond} steps) of the same step launches: the GPU's "
+                             "sustained clocks, what a rollout loop sees after its first milliseconds"}
+        steps_counted += args.warmup + args.steps + n_cond
     from sigmarl_amd import capi as _capi
     # the kernel with the largest share of GPU time in the timed region names the roofline (every timed kernel is bracketed with the same stride)
     dom = max(ktimes, key=lambda k: ktimes[k][0] * ktimes[k][1]) if ktimes else _capi.KERNEL_STEP
@@ -796,11 +799,20 @@ def main():
             }
     except Exception:  # noqa: BLE001
         pass
+    loop_kind = ("drop-in surface, one launch per step" if args.surface else
+                 "closed loop: policy on device before every step" if args.policy else
+                 "CBF-QP filter launch before every step" if args.cbf_qp else "CBF margin launch before every step" if args.cbf else
+                 f"open loop, {T} step{'s' if T > 1 else ''} per launch")
     out = {
-        "metric": f"env-steps/sec (agents x envs x steps), {'CPM' if args.scenario.startswith('cpm') else args.scenario} scenario, {N} agents",
+        "metric": f"env-steps/sec (agents x envs x steps), {'CPM' if args.scenario.startswith('cpm') else args.scenario} scenario, {N} agents ({loop_kind})",
         "value": value, "unit": "agent-env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
+        # `value` is the contract measurement (W warm-up + K timed steps on the device as the setup left it: warmup_effective_steps == warmup).  What a rollout loop
+        # that has been running for a while sees (the GPU's sustained clocks) is reported BESIDE it, never as `value`:
+        "warmup_effective_steps": args.warmup,
+        **({"value_sustained": sustained["value"], "ms_per_step_sustained": sustained["ms_per_step"],
+            "warmup_effective_steps_sustained": sustained["warmup_effective_steps"]} if sustained is not None else {}),
         "config": {
             "workload": f"{args.scenario} map, {N} agents x {B} envs per GPU ({B * world} envs total), {dist_label} distance, "
                         f"rew_method={make_params_kw(args, B)['rew_method']}{params_note(args)}, dt=0.05, obs_dim={D}, start: {run.start}, "
@@ -826,10 +838,7 @@ def main():
             "resets_per_step_per_gpu": dones / max(1, args.steps),
             "agent_reset_requests_last_step": req_last, "entry_exit_crossings_last_step": entry_exit_last,
             "rollout_gather": run.gather_fail or run.gather_note,
-            **({"device_conditioning": f"{args.condition_ms:g} ms ({cold['conditioning_steps']} steps) of the same step launches BEFORE the W warm-up steps, so that the W + K "
-                                       "steps of `value` run at the GPU's sustained clocks (what a rollout loop sees after its first milliseconds); the same W + K steps on "
-                                       "the device as the setup left it were measured first: config.cold_start (--condition-ms 0: `value` is that figure)",
-                "cold_start": cold} if cold is not None else {}),
+            **({"sustained": sustained} if sustained is not None else {}),
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
@@ -842,6 +851,8 @@ def main():
             # what the kernel actually moves: the PMC-measured HBM bytes of one launch / its duration.  A T-step launch keeps the tile in LDS between its steps and
             # writes section 8(d)'s per-step outputs (distance rows, collision rows, closest indices ...) for the LAST step only, so this is BELOW `achieved`
             "achieved_measured": (traffic / (kernel_ms * 1e-3) / 1e9) if (traffic and kernel_ms > 0) else None,
+            "frac_measured": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if (traffic and kernel_ms > 0) else None,
+            **({"frac_sustained": bytes_per * sustained["value"] / world / 1e9 / HBM_PEAK_GBPS} if sustained is not None else {}),
             "traffic_over_algorithmic": (traffic / per_launch_bytes) if traffic else None,
             "achieved_basis": "algorithmic bytes per agent-env-step (SURVEY.md 8d: 44 + 251 + 5 N) x agent-env-steps/s of one GPU; achieved_per_launch = the same "
                               "bytes of ONE launch / its average duration by HIP events (launches of different shards overlap); achieved_incl_record adds the "
@@ -896,7 +907,8 @@ def main():
         r1.finish_chunk()
         el1 = timed(r1, args.steps, args.warmup, use_dist, dist, torch, device)
         out["config"]["per_step_launch"] = {"ms_per_step": el1 / args.steps * 1e3, "value": total_agent_steps / el1, "env_shards_per_gpu": r1.S,
-                                            "note": "same steps, one launch per step and env shard (sigmaenv_step_autoreset), timed after the headline region (same device conditioning)"}
+                                            "note": "same steps, one launch per step and env shard (sigmaenv_step_autoreset), timed after the headline regions at the GPU's "
+                                                    "sustained clocks (compare with value_sustained, not with value)"}
         r1.close()
     if args.emulate_ranks > 1 and world == 1:
         # BASELINE config 3 (16 agents x 32768 envs over 8 GPUs) on the one GPU of this box: rank r's shard -- envs [r B, (r + 1) B) of the batch, the

@@ -39,6 +39,7 @@
 typedef struct sigmaenv_oracle {
   sigmaenv_config_t cfg;
   int B, N, K, D, P, n_paths, yaw_stride;
+  uint32_t observe_calls, obs_salt;  /* stand-alone observe calls so far; the salt of the observation being assembled (0 inside steps and resets) */
   float *center, *left, *right; /* [n_paths][P][2] padded as world_state_rt.py:313-420 */
   float* yaw;                   /* [n_paths][yaw_stride] */
   int32_t *n_center, *n_left, *n_right;
@@ -670,7 +671,9 @@ static void agent_observation(oracle_t* o, int b, int i) {
    * specification of sigmaenv_config_t.obs_noise_level: the counter-based generator keyed on the env's own counters (episodes_reset, timer.step) */
   if (c->obs_noise_level > 0.0f) {
     const uint64_t seed = ((uint64_t)c->obs_noise_seed_hi << 32) | c->obs_noise_seed_lo;
-    const uint64_t counter = (uint64_t)(uint32_t)o->timer[b * 4 + 3] * 65537ull + (uint64_t)(uint32_t)o->timer[b * 4];
+    /* + the salt of an observation that is TAKEN AGAIN at the same counters (sigmaenv_oracle_observe: its n-th call on the handle; 0 inside steps and resets):
+     * the reference draws rand_like on every observation() call */
+    const uint64_t counter = (uint64_t)(uint32_t)o->timer[b * 4 + 3] * 65537ull + (uint64_t)(uint32_t)o->timer[b * 4] + (uint64_t)(uint32_t)(o->obs_salt * 0x632BE5ABu);
     for (int k = 0; k < p; ++k) {
       const float u = (float)(rng_u32(seed, counter, (uint32_t)(c->env_index_base + b), (uint32_t)i, 9000u + (uint32_t)k) >> 8) * (1.0f / 16777216.0f);
       ob[k] = ob[k] + c->obs_noise_level * u;
@@ -1019,9 +1022,11 @@ int sigmaenv_oracle_step(oracle_t* o, const float* actions) {
 
 int sigmaenv_oracle_observe(oracle_t* o) {
   if (!o) return SIGMAENV_EINVAL;
+  o->obs_salt = ++o->observe_calls;
 #pragma omp parallel for schedule(static)
   for (int b = 0; b < o->B; ++b)
     for (int i = 0; i < o->N; ++i) agent_observation(o, b, i);
+  o->obs_salt = 0u;
   return SIGMAENV_OK;
 }
 

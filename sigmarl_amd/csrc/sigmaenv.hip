@@ -844,7 +844,7 @@ __device__ __forceinline__ void observe_tile_default(const sigmaenv_config_t& c,
       const int v = w / D, k = w - v * D;
       const int sl = real_slot(v);
       const int e = fdiv(sl, g.mN), i = sl - e * N;
-      s.obs[sl * D + k] = s.obs[sl * D + k] + obs_noise(c, c.env_index_base + t.env0 + e, i, k, tim[e * 4 + 3], tim[e * 4]);
+      s.obs[sl * D + k] = s.obs[sl * D + k] + obs_noise(c, c.env_index_base + t.env0 + e, i, k, tim[e * 4 + 3], tim[e * 4], g.obs_salt);
     }
     Grp<WAVE>::sync();
   }
@@ -877,10 +877,10 @@ __device__ __forceinline__ void observe_tile_default(const sigmaenv_config_t& c,
 // resets, sigmaenv_observe) produces the configured row itself.  Ego-view transforms use the rotation form of the default path.
 // Value k of agent slot sl's row in SIGMAENV_OBS_FULL mode, from the staging of observe_tile_variant: the [own] blocks of the `slots` agents, then ONE copy of the
 // [others] part per env (it does not depend on the observing agent in the bird view), placeholders zero; plus the sensor noise of element k.
-__device__ __forceinline__ float full_obs_value(const sigmaenv_config_t& c, const Smem& s, const Tile& t, const ObsLayout& L, int e, int i, int k, const int* tim) {
+__device__ __forceinline__ float full_obs_value(const sigmaenv_config_t& c, const Smem& s, const Tile& t, const ObsLayout& L, int e, int i, int k, const int* tim, uint32_t salt = 0u) {
   const int sl = e * t.N + i;
   float v = k < L.own_w ? s.obs[sl * L.own_w + k] : (k < L.own_w + L.W_oth ? s.obs[t.slots * L.own_w + e * L.W_oth + (k - L.own_w)] : 0.0f);
-  if (c.obs_noise_level > 0.0f) v = v + obs_noise(c, c.env_index_base + t.env0 + e, i, k, tim[e * 4 + 3], tim[e * 4]);
+  if (c.obs_noise_level > 0.0f) v = v + obs_noise(c, c.env_index_base + t.env0 + e, i, k, tim[e * 4 + 3], tim[e * 4], salt);
   return v;
 }
 
@@ -1105,7 +1105,7 @@ __device__ __forceinline__ void observe_tile_variant(const sigmaenv_config_t& c,
       const int v = w / DR, k = w - v * DR;
       const int sl = real_slot(v);
       const int e = fdiv(sl, g.mN), i = sl - e * N;
-      s.obs[sl * DR + k] = s.obs[sl * DR + k] + obs_noise(c, c.env_index_base + t.env0 + e, i, k, tim[e * 4 + 3], tim[e * 4]);
+      s.obs[sl * DR + k] = s.obs[sl * DR + k] + obs_noise(c, c.env_index_base + t.env0 + e, i, k, tim[e * 4 + 3], tim[e * 4], g.obs_salt);
     }
     Grp<WAVE>::sync();
   }
@@ -1121,7 +1121,7 @@ __device__ __forceinline__ void observe_tile_variant(const sigmaenv_config_t& c,
       const int e = env_sel ? env_sel[q] : q;
       float* go = g.obs + (t.a0 + (size_t)e * N) * DR;
       if (L.full) {
-        for (int k = TID; k < ND; k += NTHR) { const int i = k / DR; go[k] = full_obs_value(c, s, t, L, e, i, k - i * DR, tim); }
+        for (int k = TID; k < ND; k += NTHR) { const int i = k / DR; go[k] = full_obs_value(c, s, t, L, e, i, k - i * DR, tim, g.obs_salt); }
       } else {
         for (int k = TID; k < ND; k += NTHR) go[k] = s.obs[e * ND + k];
       }
@@ -1734,6 +1734,7 @@ struct sigmaenv {
   int wave_spec = 0;  // agents * 256 + envs per wavefront of a fixed-shape instantiation of the step kernel (2 observed neighbours), else 0
   sigmaenv_config_t* d_cfg = nullptr;  // device copy of cfg (the step kernel reads it through scalar loads): a DevConfig -- the config, then the derived block
   DevConfig cfg_derived;
+  uint32_t observe_calls = 0;      // stand-alone sigmaenv_observe calls so far (the salt of their sensor noise)
   size_t rollout_slab_stride = 0;  // floats between the record blocks of consecutive steps of sigmaenv_rollout* (0: B * W)
   int grid = 1;
   void* bufs[SIGMAENV_BUF_COUNT] = {nullptr};
@@ -2072,6 +2073,7 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
   g.dbg_ts = nullptr;
   g.dbg_ts2 = nullptr;
   g.dbg_skip = 0;
+  g.obs_salt = 0u;
 #ifdef SIGMAENV_PROFILE
   if (const char* e = getenv("SIGMAENV_DEBUG_SKIP")) g.dbg_skip = atoi(e);
 #endif
@@ -2398,7 +2400,9 @@ extern "C" int sigmaenv_step_autoreset_many(sigmaenv_t** hs, int32_t n, const fl
 extern "C" int sigmaenv_observe(sigmaenv_t* h) {
   if (!h) return SIGMAENV_EINVAL;
   HIPCHK(h, hipSetDevice(h->device));
-  hipLaunchKernelGGL(sigmaenv_observe_kernel, dim3(h->grid), dim3(h->block), h->smem_bytes, h->stream, h->cfg, h->buf, h->G);
+  DevBufs b = h->buf;
+  b.obs_salt = ++h->observe_calls;  // an observation taken AGAIN draws its own sensor noise (obs_noise; shared specification with the oracle's observe)
+  hipLaunchKernelGGL(sigmaenv_observe_kernel, dim3(h->grid), dim3(h->block), h->smem_bytes, h->stream, h->cfg, b, h->G);
   HIPCHK(h, hipGetLastError());
   return SIGMAENV_OK;
 }

@@ -118,6 +118,7 @@ struct DevBufs {
   const uint8_t* bnd_is_loop;
   int32_t bnd_poly_stride, bnd_P;
   uint32_t mVT1;                          // magic multiplier of the variant rows' points per agent (observe_tile)
+  uint32_t obs_salt;                      // 0 in every launch that steps or re-places envs; n in the n-th stand-alone sigmaenv_observe of the handle (obs_noise)
   // magic multipliers ceil(2^32 / d) for the divisors the kernels' index arithmetic divides by (fdiv below): agents per env, items per
   // agent of the two observation passes, unordered pairs per env, floats per rollout record row
   uint32_t mN, mT1, mT2, mTP, mW, mSG;  // mSG: slots of a full tile of the step kernel (G * N)
@@ -516,10 +517,12 @@ __device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint64_t counter, uin
 }
 
 // observation noise of element k of agent `agent` of env `env_global` at the env's counters (episodes_reset, timer.step): level * U[0, 1)
-// (observation_provider_rt.py:613-618; specification shared with the oracle, see sigmaenv_config_t.obs_noise_level)
-__device__ __forceinline__ float obs_noise(const sigmaenv_config_t& c, int env_global, int agent, int k, int episodes, int step) {
+// (observation_provider_rt.py:613-618; specification shared with the oracle, see sigmaenv_config_t.obs_noise_level).  The reference draws rand_like on EVERY
+// observation() call: the observations a step or a reset produces are told apart by the env's own counters, and an observation that is TAKEN AGAIN at the same
+// counters (sigmaenv_observe) by `salt`, the number of that call on its handle -- so it gets draws of its own, as the reference's second call does.
+__device__ __forceinline__ float obs_noise(const sigmaenv_config_t& c, int env_global, int agent, int k, int episodes, int step, uint32_t salt) {
   const uint64_t seed = ((uint64_t)c.obs_noise_seed_hi << 32) | c.obs_noise_seed_lo;
-  const uint64_t counter = (uint64_t)(uint32_t)episodes * 65537ull + (uint64_t)(uint32_t)step;
+  const uint64_t counter = (uint64_t)(uint32_t)episodes * 65537ull + (uint64_t)(uint32_t)step + (uint64_t)(salt * 0x632BE5ABu);
   const float u = (float)(rng_u32(seed, counter, (uint32_t)env_global, (uint32_t)agent, 9000u + (uint32_t)k) >> 8) * (1.0f / 16777216.0f);
   return c.obs_noise_level * u;
 }

@@ -252,6 +252,7 @@ class WorldCustom:
             a.action.u = clamped[:, i]
         if self._scenario is not None:
             self._scenario._obs_dirty = False
+            self._scenario._obs_served.clear()  # (a step's observations are new ones)
             self._scenario._auto_reset_done_this_step = False
             self._scenario._info_batch = None
 
@@ -299,6 +300,7 @@ class ScenarioRoadTraffic(BaseScenario):
         self._world = world
         self._build_views()
         self._obs_dirty = True
+        self._obs_served = set()  # agents whose current observation has been handed out (observation(): a second request draws new sensor noise)
         # device_side_resets: serve BOTH the per-agent reset requests and the resets of finished envs inside done() with the
         # device sampler (sigmaenv_auto_reset) instead of the reference's host loops over torch's generator.  The callbacks'
         # results are the same tensors; only the random stream differs (distributional parity).  Off by default.
@@ -436,6 +438,7 @@ class ScenarioRoadTraffic(BaseScenario):
                 st8.append((x, y, rot32, sp32, 0.0, vx, vy, 0.0))
         env.reset(env_idx, agent_idx, np.asarray(ids, np.int32), np.asarray(st8, np.float32), full_env=agent_index is None)
         self._obs_dirty = True
+        self._obs_served.clear()
 
     # ---- callbacks -------------------------------------------------------------------------------------------------
     def _index(self, agent) -> int:
@@ -450,12 +453,19 @@ class ScenarioRoadTraffic(BaseScenario):
 
         The noise is drawn ON THE DEVICE from the counter-based generator keyed on (Parameters.random_seed, the env's episodes_reset and timer.step, env, agent,
         column) -- a pure function of the env's own counters, so the fused / separate / T-step launches, any sharding and the rollout record all see the same
-        values.  Two consequences that differ from the reference's ``torch.rand_like`` per call: observing twice at the same counters (a second ``observation()``
-        without a step or reset in between) returns the SAME noise, and seeding torch does not control it -- ``Parameters.random_seed`` does."""
+        values -- plus, for an observation that is requested AGAIN without a step or reset in between, the number of that re-observation on the handle: like the
+        reference's ``torch.rand_like`` per call (observation_provider_rt.py:613-618) a second ``observation(agent)`` returns fresh noise.  What still differs:
+        seeding torch does not control the noise -- ``Parameters.random_seed`` does."""
         i = self._index(agent)
-        if i == 0 and self._obs_dirty:
-            self.env.observe()
-            self._obs_dirty = False
+        if self._obs_dirty:
+            if i == 0:
+                self.env.observe()
+                self._obs_dirty = False
+                self._obs_served.clear()
+        elif i in self._obs_served and self.parameters.is_obs_noise:
+            self.env.observe()  # taken again at the same counters: sigmaenv_observe salts the draws with its call count
+            self._obs_served.clear()
+        self._obs_served.add(i)
         obs = self.env.obs[:, i]  # incl. the sensor noise: added on the device (sigmaenv_config_t.obs_noise_level), so the rollout record and the
         self.stored_observations[i] = obs  # on-device actor see the same noisy observation the trainer does
         return obs
@@ -470,6 +480,7 @@ class ScenarioRoadTraffic(BaseScenario):
             self.env.auto_reset(seed=int(getattr(self.parameters, "random_seed", 0)))
             self._auto_reset_done_this_step = True
             self._obs_dirty = False  # the reset kernel refreshed the observations of every touched env
+            self._obs_served.clear()
             return is_done
         if self.parameters.is_testing_mode or self.parameters.scenario_type != "cpm_entire":
             req = self.env.buffer(capi.BUF_COL_FLAGS)[..., 3]

@@ -755,7 +755,7 @@ TRAJS = {
     # BASELINE config 4: 32 agents on the on-ramp map.  The reference's rejection sampler cannot place them, so the
     # start is injected (Parameters.predefined_ref_path_idx / init_state); vehicles overlap from the first step on, every env is "done" at
     # every step and none is reset: non-reset steps only, as the survey prescribes for this configuration
-    "onramp32_c2c": dict(T=16, B=3, seed=27, mode_pattern=[1, 0, 1], no_reset=True, inject=dict(first_point=3, stride=3), n_agents=32,
+    "onramp32_c2c": dict(T=32, B=3, seed=27, mode_pattern=[1, 0, 1], no_reset=True, inject=dict(first_point=3, stride=3), n_agents=32,
                          scenario_type="on_ramp_1", dt=0.05, is_use_mtv_distance=False, rew_method="distance"),
     # "clf" nominal controller (cbf_qp.py:2616-2628): the margins are evaluated at a P controller's action instead of the policy's
     "onramp4_cbf_clf": dict(T=24, B=3, seed=23, mode_pattern=[1, 0, 1], hook="cbf", n_agents=4, scenario_type="on_ramp_1", dt=0.05,

@@ -44,6 +44,19 @@ def test_default_line_follows_the_contract():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert c["per_step_launch"]["ms_per_step"] > 0 and c["per_step_launch"]["env_shards_per_gpu"] == 2
+    # `value` is the contract measurement (W warm-up steps on the device as the setup left it); the sustained-clock figure stands beside it, never in its place
+    assert d["metric"].endswith("(open loop, 24 steps per launch)")
+    assert d["warmup_effective_steps"] == d["warmup"] == 4
+    assert d["value_sustained"] > 0 and d["warmup_effective_steps_sustained"] == 2 * 4 + 24 + c["sustained"]["conditioning_steps"] > d["warmup"]
+    assert abs(d["value_sustained"] - 16 * 4096 / (d["ms_per_step_sustained"] * 1e-3)) <= 1e-6 * d["value_sustained"]
+    assert c["sustained"]["value"] == d["value_sustained"] and "cold_start" not in c
+    assert abs(r["frac_sustained"] - 375 * d["value_sustained"] / 1e9 / 8000.0) <= 1e-12
+    assert r["frac_measured"] is None or abs(r["frac_measured"] - r["achieved_measured"] / 8000.0) <= 1e-12
+
+
+def test_without_conditioning_there_is_no_sustained_figure():
+    d = _run("--cpu-seconds", "0", "--no-compare", "--condition-ms", "0")
+    assert "value_sustained" not in d and "sustained" not in d["config"] and d["warmup_effective_steps"] == 4
 
 
 def test_config4_and_qp_lines_name_their_workload():
@@ -51,7 +64,7 @@ def test_config4_and_qp_lines_name_their_workload():
     assert "on_ramp_1" in d["config"]["workload"] and d["config"]["n_agents"] == 32 and "cpu_baseline" not in d
     assert d["roofline"]["algorithmic_bytes_per_agent_env_step"] == 44 + 251 + 5 * 32
     d = _run("--cpu-seconds", "0", "--no-compare", "--cbf-qp", "--envs-per-gpu", "512")
-    assert "cbf" in d["config"] and d["value"] > 0
+    assert "cbf" in d["config"] and d["value"] > 0 and d["metric"].endswith("(CBF-QP filter launch before every step)")
 
 
 def _trace_top_kernel(tmp_path, *bench_args):

@@ -74,6 +74,55 @@ def _compare_all(dev, ora, tag, diff_by_buffer=None):
     return n_float_diff
 
 
+class _OneEnvFixture:
+    """Env `e` of a golden trajectory as a fixture of its own (B = 1): every [B, ...] / [T, B, ...] array sliced, the reset events of the other envs dropped."""
+
+    def __init__(self, z, e):
+        B = z["init_pos"].shape[0]
+        keep = np.nonzero(z["ev_env"] == e)[0]
+        self._d = {}
+        for k in z.files:
+            a = z[k]
+            if k == "meta_json":
+                pass
+            elif k.startswith("ev_"):
+                a = a[keep]
+                if k == "ev_env":
+                    a = np.zeros_like(a)
+            elif k.startswith("init_"):
+                a = a[e:e + 1]
+            elif k.startswith("post_") or k.startswith("next_") or k in ("act", "done"):   # [T, B, ...]
+                assert a.shape[1] == B, k
+                a = a[:, e:e + 1]
+            self._d[k] = a
+        self.files = list(self._d)
+
+    def __getitem__(self, k):
+        return self._d[k]
+
+
+# (env 0 only: the reference's env-0 reset quirk -- traj_replay.replay -- leaves traces in the OTHER envs' snapshots that only the batched replay can account for)
+@pytest.mark.parametrize("name,e", [("intersection4_c2c", 0), ("cpm16_c2c", 0), ("intersection4_birdview_mask", 0), ("onramp6_mtv", 0), ("intersection4_mask", 0)])
+def test_single_env_replay_of_reference_goldens(name, e):
+    """BASELINE config 1 is "4 agents, num_envs = 1": a launch of ONE wavefront.  Env e of a reference trajectory replayed ALONE through the C-ABI (a handle with
+    n_envs = 1): the same tolerances as the batched replay (masks / indices / counters bit-exact, fp32 within 1e-5 of the reference)."""
+    z, meta = tr.load_fixture(name)
+    if "cbf_in_state" in z.files:
+        pytest.skip("CBF fixtures carry per-batch margins")
+    one = _OneEnvFixture(z, e)
+    meta1 = dict(meta, B=1)
+    cfg, mp = tr.config_from_meta(meta1, n_envs=1)
+    assert cfg.n_envs == 1
+    env = _hip_env(cfg, mp)
+    twin = ob.OracleEnv(cfg, mp)
+    rep = tr.replay(env, one, meta1, mp, twin=twin)
+    env.close()
+    twin.close()
+    assert getattr(rep, "unchecked", 0) == 0
+    assert rep.total_mismatch() == 0, str(rep)
+    assert rep.worst_float() <= FTOL, str(rep)
+
+
 CASES = [
     # scenario, N, B, mtv, rew_method, dt, testing, steps
     ("cpm_entire", 16, 64, False, "distance", 0.05, False, 12),
@@ -84,6 +133,10 @@ CASES = [
     ("cpm_entire", 8, 24, True, "sparse", 0.1, True, 12),           # testing mode: colliders are re-placed one by one on device
     ("intersection_1", 4, 40, False, "distance", 0.1, False, 16),  # non-loop map: entry/exit segments, reset requests
     ("on_ramp_1", 6, 40, True, "ttc", 0.1, False, 16),
+    # BASELINE config 1's shape: num_envs = 1 -- ONE wavefront, one tile, every per-env reduction over a single env
+    ("intersection_1", 4, 1, False, "distance", 0.1, False, 40),
+    ("cpm_entire", 16, 1, False, "distance", 0.05, False, 40),
+    ("cpm_entire", 16, 1, True, "ttc_sparse", 0.1, True, 30),
 ]
 
 

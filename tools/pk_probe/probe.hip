@@ -1,5 +1,7 @@
 // Issue-rate probe: is one v_pk_{fma,mul,add}_f32 as cheap as one v_fma_f32 on gfx950 for a VALU-bound kernel (4 wavefronts per SIMD)?
-// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o tools/pk_probe/probe tools/pk_probe/probe.hip ; run on the GPU box.
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -o tools/pk_probe/probe tools/pk_probe/probe.hip ; run on the GPU box.
+// (-fno-slp-vectorize is essential: without it the SLP vectoriser turns the "scalar" modes into v_pk_* code as well -- the round-4 run of this probe compared packed with
+// packed: SQ_INSTS_VALU of mode 0 was HALF of 16 x iterations x wavefronts, profiles/r05_valu_calibration.txt)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f2 __attribute__((ext_vector_type(2)));
