@@ -8,7 +8,7 @@ REPS=${REPS:-3}; STEPS=${STEPS:-256}
 for r in $(seq 1 $REPS); do
   for lib in "$@"; do
     SIGMAENV_LIB=$R/sigmarl_amd/csrc/$lib python $R/bench.py --cpu-seconds 0 --steps $STEPS --warmup 32 $BENCH_EXTRA 2>/dev/null |
-      python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$lib', $r, '%.4e' % d['value'], '%.5f' % d['ms_per_step'], '%.5f' % d['config'].get('per_step_launch',{}).get('ms_per_step',0))" | tee -a $out/ab.txt
+      python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$lib', $r, '%.4e' % d.get('value_sustained', d['value']), '%.5f' % d['ms_per_step'], '%.5f' % d['config'].get('per_step_launch',{}).get('ms_per_step',0))" | tee -a $out/ab.txt
   done
 done
 python - <<PY

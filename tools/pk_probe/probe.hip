@@ -22,9 +22,21 @@ __global__ void __launch_bounds__(256) k(float* out, int iters, float a, float b
     } else if (MODE == 2) {  // mul + add, scalar
 #pragma unroll
       for (int i = 0; i < 16; ++i) { r[i] = r[i] * a; r[i] = r[i] + b; }
-    } else {                 // mul + add, packed
+    } else if (MODE == 3) {  // mul + add, packed
 #pragma unroll
       for (int i = 0; i < 8; ++i) { p[i] = p[i] * a2; p[i] = p[i] + b2; }
+    } else if (MODE == 4) {  // scalar fma, three DIFFERENT vector operands (what real code looks like: no operand is a loop constant)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) r[i] = __builtin_fmaf(r[i], r[(i + 5) & 15], r[(i + 11) & 15]);
+    } else if (MODE == 5) {  // packed fma, three different register pairs
+#pragma unroll
+      for (int i = 0; i < 8; ++i) p[i] = __builtin_elementwise_fma(p[i], p[(i + 3) & 7], p[(i + 5) & 7]);
+    } else if (MODE == 6) {  // scalar: one splat operand + two different vector operands (a segment's direction x a per-query value + a per-query value)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) r[i] = __builtin_fmaf(r[i], a, r[(i + 11) & 15]);
+    } else {                 // packed: one operand read through op_sel from one half of a pair, two different pairs
+#pragma unroll
+      for (int i = 0; i < 8; ++i) p[i] = __builtin_elementwise_fma(p[i], (f2){p[(i + 3) & 7].x, p[(i + 3) & 7].x}, p[(i + 5) & 7]);
     }
   }
   float s = 0;
@@ -49,5 +61,10 @@ int main() {
   const double waves = 256.0 * 4 * 4, inst0 = 16.0 * iters;
   printf("cycles per scalar VALU instruction per SIMD (2.4 GHz, 4 waves/SIMD): %.2f ; per packed instruction: %.2f\n",
          t0 * 1e-3 * 2.4e9 / (inst0 * waves / 1024), t1 * 1e-3 * 2.4e9 / (inst0 / 2 * waves / 1024));
+  const float t4 = run<4>(d, iters), t5 = run<5>(d, iters), t6 = run<6>(d, iters), t7 = run<7>(d, iters);
+  printf("three different vector operands: scalar fma %.3f ms (%.2f cycles per instruction) | packed fma %.3f ms (%.2f cycles per instruction, x%.2f)\n", t4,
+         t4 * 1e-3 * 2.4e9 / (inst0 * waves / 1024), t5, t5 * 1e-3 * 2.4e9 / (inst0 / 2 * waves / 1024), t4 / t5);
+  printf("one splat + two different operands: scalar fma %.3f ms (%.2f) | packed fma with op_sel %.3f ms (%.2f, x%.2f)\n", t6,
+         t6 * 1e-3 * 2.4e9 / (inst0 * waves / 1024), t7, t7 * 1e-3 * 2.4e9 / (inst0 / 2 * waves / 1024), t6 / t7);
   return 0;
 }
