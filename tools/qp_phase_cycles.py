@@ -1,6 +1,6 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["SIGMAENV_CBF_DEBUG_SKIP"]="128"
+os.environ.setdefault("SIGMAENV_CBF_DEBUG_SKIP", "128")
 os.environ.setdefault("SIGMAENV_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sigmarl_amd", "csrc", "libsigmaenv_prof.so"))  # profile build (make -C sigmarl_amd/csrc prof)
 import torch
 from sigmarl_amd.env import SigmaEnv
