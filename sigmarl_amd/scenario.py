@@ -206,6 +206,7 @@ class WorldCustom:
         self.parameters = None
         self._actions = torch.zeros((env.B, env.N, 2), dtype=torch.float32, device=env.device)
         self._scenario = None
+        self._clamped_views = None
         self.dim_c, self.dim_p = 0, 2  # no communication channel, planar positions (vmas World defaults; Environment._set_action reads dim_c)
 
     def to(self, device):
@@ -242,14 +243,16 @@ class WorldCustom:
         return
 
     def step(self):
-        for i, a in enumerate(self._agents):
-            if a.action.u is None:
-                raise ValueError("agent.action.u is None: VMAS sets the actions before world.step()")
-            self._actions[:, i].copy_(a.action.u)
+        us = [a.action.u for a in self._agents]
+        if any(u is None for u in us):
+            raise ValueError("agent.action.u is None: VMAS sets the actions before world.step()")
+        torch.stack(us, dim=1, out=self._actions)  # ONE launch for the [B, N, 2] action block (N copies cost the host 17 % of a surface step)
         self._env.step(self._actions)
-        clamped = self._env.buffer(capi.BUF_ACTION)
-        for i, a in enumerate(self._agents):  # WorldCustom.step clamps entity.action.u in place (helper_training.py:807-818)
-            a.action.u = clamped[:, i]
+        if self._clamped_views is None:  # WorldCustom.step clamps entity.action.u in place (helper_training.py:807-818): per-agent views of the clamped block, built once
+            clamped = self._env.buffer(capi.BUF_ACTION)
+            self._clamped_views = [clamped[:, i] for i in range(len(self._agents))]
+        for a, v in zip(self._agents, self._clamped_views):
+            a.action.u = v
         if self._scenario is not None:
             self._scenario._obs_dirty = False
             self._scenario._obs_served.clear()  # (a step's observations are new ones)
@@ -307,6 +310,9 @@ class ScenarioRoadTraffic(BaseScenario):
         self.device_side_resets = bool(kwargs.pop("device_side_resets", getattr(self, "device_side_resets", False)))
         self._auto_reset_done_this_step = False
         self.stored_observations = [None] * self.n_agents
+        self._info_buf, self._info_batch = None, None
+        self._info_cache, self._info_cache_empty = [None] * self.n_agents, [None] * self.n_agents
+        self._reward_views = None
         self._lanelet_table = torch.zeros((self.map.n_paths, max(1, self.map.n_lanelets_all)), dtype=torch.int32, device=device)
         ids = torch.as_tensor(self.map.lanelet_ids)
         self._lanelet_table[:, : ids.shape[1]] = ids.to(device)
@@ -442,11 +448,17 @@ class ScenarioRoadTraffic(BaseScenario):
 
     # ---- callbacks -------------------------------------------------------------------------------------------------
     def _index(self, agent) -> int:
-        return self.world.agents.index(agent)
+        i = getattr(agent, "_sigma_index", None)
+        if i is None:
+            i = agent._sigma_index = self.world.agents.index(agent)
+        return i
 
     def reward(self, agent):
         """[B] fp32, already computed by the fused step (road_traffic.py:925-1253)."""
-        return self.env.reward[:, self._index(agent)]
+        if self._reward_views is None:
+            r = self.env.reward
+            self._reward_views = [r[:, i] for i in range(self.n_agents)]
+        return self._reward_views[self._index(agent)]
 
     def observation(self, agent):
         """[B, obs_dim] fp32 (road_traffic.py:1334-1366); uniform noise as observation_provider_rt.py:613-618 when enabled (device side).
@@ -490,56 +502,99 @@ class ScenarioRoadTraffic(BaseScenario):
                     self.reset_world_at(env_index=e, agent_index=a)
         return is_done
 
-    def info(self, agent) -> Dict[str, torch.Tensor]:
-        """The 27 + 12 entries of road_traffic.py:1489-1635 (+ 2 with is_using_prioritized_marl)."""
-        i = self._index(agent)
-        ws, nz, B = self.world_state, self.normalizers, self.env.B
-        st = agent.state
-        empty = agent.action.u is None
-        act_v = self.constants.empty_action_vel[:, i] if empty else agent.action.u[:, 0]
-        act_s = self.constants.empty_action_steering[:, i] if empty else agent.action.u[:, 1]
-        # The derived entries are elementwise in the agent: they are computed for ALL agents in one batched op each, when agent 0 asks (VMAS collects the infos of
-        # all agents back to back after the step, tests/vmas_env_shim.py), and sliced per agent -- 16 x ~20 small launches become ~20 (same values: same ops).
-        if i == 0 or getattr(self, "_info_batch", None) is None:
-            state = self.env.buffer(capi.BUF_STATE)
-            two_pi = 2 * math.pi
-            rot = state[..., 2:3] % two_pi
-            rot = torch.where(rot > math.pi, rot - two_pi, rot)  # angle_eliminate_two_pi, helper_scenario.py:1276-1289
-            short = ws.ref_paths_agent_related.short_term
-            dl = ws.distances.left_boundaries.min(dim=-1)[0]
-            dr = ws.distances.right_boundaries.min(dim=-1)[0]
-            self._info_batch = dict(
-                pos_nom=state[..., 0:2] / nz.pos_world, rot=rot, rot_nom=rot / nz.rot, vel_nom=state[..., 5:7] / nz.v,
-                ref_nom=(short / nz.pos_world).reshape(B, self.n_agents, -1), distance_ref_nom=ws.distances.ref_paths / nz.distance_ref,
-                dl=dl, dl_nom=dl / nz.distance_lanelet, dr=dr, dr_nom=dr / nz.distance_lanelet,
-                col_agents=ws.collisions.with_agents.to(torch.bool).any(dim=-1), col_lane=ws.collisions.with_lanelets.to(torch.bool),
-                goal=ws.collisions.with_exit_segments.to(torch.bool), lanelet_ids=self._lanelet_table[self.env.buffer(capi.BUF_PATH)[..., 0].long()])
-        ib = self._info_batch
-        short = ws.ref_paths_agent_related.short_term[:, i]
+    def _info_refresh(self):
+        """The derived entries of info() for ALL agents, written IN PLACE into buffers that live as long as the scenario (same ops, same values as one call per agent:
+        they are elementwise in the agent).  The per-agent dicts of info() hold views of these buffers and of the library's, so they are built once."""
+        ws, nz, B, N = self.world_state, self.normalizers, self.env.B, self.n_agents
+        state = self.env.buffer(capi.BUF_STATE)
+        ib = self._info_buf
+        if ib is None:
+            dev = self.env.device
+            f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)  # noqa: E731
+            ib = self._info_buf = dict(
+                pos_nom=f32(B, N, 2), rot=f32(B, N, 1), rot_nom=f32(B, N, 1), vel_nom=f32(B, N, 2), ref_nom=f32(B, N, ws.ref_paths_agent_related.short_term.shape[2], 2),
+                distance_ref_nom=f32(B, N), dl=f32(B, N), dl_nom=f32(B, N), dr=f32(B, N), dr_nom=f32(B, N), act_v_nom=f32(B, N), act_s_nom=f32(B, N),
+                col_agents=torch.empty((B, N), dtype=torch.bool, device=dev), col_lane=torch.empty((B, N), dtype=torch.bool, device=dev),
+                goal=torch.empty((B, N), dtype=torch.bool, device=dev), col_any=torch.empty((B, N, N), dtype=torch.bool, device=dev),
+                lanelet_ids=torch.empty((B * N, self._lanelet_table.shape[1]), dtype=self._lanelet_table.dtype, device=dev),
+                arg=torch.empty((B, N), dtype=torch.long, device=dev), wrap=torch.empty((B, N, 1), dtype=torch.bool, device=dev), rot_m=f32(B, N, 1))
+        two_pi = 2 * math.pi
+        torch.remainder(state[..., 2:3], two_pi, out=ib["rot"])
+        torch.gt(ib["rot"], math.pi, out=ib["wrap"])
+        torch.sub(ib["rot"], two_pi, out=ib["rot_m"])
+        torch.where(ib["wrap"], ib["rot_m"], ib["rot"], out=ib["rot"])  # angle_eliminate_two_pi, helper_scenario.py:1276-1289
+        torch.div(state[..., 0:2], nz.pos_world, out=ib["pos_nom"])
+        torch.div(ib["rot"], nz.rot, out=ib["rot_nom"])
+        torch.div(state[..., 5:7], nz.v, out=ib["vel_nom"])
+        torch.div(ws.ref_paths_agent_related.short_term, nz.pos_world, out=ib["ref_nom"])
+        torch.div(ws.distances.ref_paths, nz.distance_ref, out=ib["distance_ref_nom"])
+        torch.min(ws.distances.left_boundaries, dim=-1, out=(ib["dl"], ib["arg"]))
+        torch.min(ws.distances.right_boundaries, dim=-1, out=(ib["dr"], ib["arg"]))
+        torch.div(ib["dl"], nz.distance_lanelet, out=ib["dl_nom"])
+        torch.div(ib["dr"], nz.distance_lanelet, out=ib["dr_nom"])
+        torch.ne(ws.collisions.with_agents, 0, out=ib["col_any"])
+        torch.any(ib["col_any"], dim=-1, out=ib["col_agents"])
+        torch.ne(ws.collisions.with_lanelets, 0, out=ib["col_lane"])
+        torch.ne(ws.collisions.with_exit_segments, 0, out=ib["goal"])
+        torch.index_select(self._lanelet_table, 0, self.env.buffer(capi.BUF_PATH)[..., 0].reshape(-1).long(), out=ib["lanelet_ids"])
+        act = self.env.buffer(capi.BUF_ACTION)  # (agent.action.u after a step: the clamped action)
+        torch.div(act[..., 0], nz.v, out=ib["act_v_nom"])
+        torch.div(act[..., 1], nz.steering, out=ib["act_s_nom"])
+        self._info_batch = ib
+
+    def _info_views(self, i: int, empty: bool):
+        ws, ib, B = self.world_state, self._info_buf, self.env.B
+        st = self.world.agents[i].state
+        act = self.env.buffer(capi.BUF_ACTION)
+        act_v = self.constants.empty_action_vel[:, i] if empty else act[:, i, 0]
+        act_s = self.constants.empty_action_steering[:, i] if empty else act[:, i, 1]
         info = {
             "pos": st.pos, "pos_nom": ib["pos_nom"][:, i], "rot": ib["rot"][:, i], "rot_nom": ib["rot_nom"][:, i],
             "vel": st.vel, "vel_nom": ib["vel_nom"][:, i],
-            "act_vel": act_v, "act_vel_nom": act_v if empty else act_v / nz.v,
-            "act_steer": act_s, "act_steer_nom": act_s if empty else act_s / nz.steering,
-            "ref": short.reshape(B, -1), "ref_nom": ib["ref_nom"][:, i],
+            "act_vel": act_v, "act_vel_nom": act_v if empty else ib["act_v_nom"][:, i],
+            "act_steer": act_s, "act_steer_nom": act_s if empty else ib["act_s_nom"][:, i],
+            "ref": ws.ref_paths_agent_related.short_term[:, i].reshape(B, -1), "ref_nom": ib["ref_nom"][:, i].reshape(B, -1),
             "distance_ref": ws.distances.ref_paths[:, i], "distance_ref_nom": ib["distance_ref_nom"][:, i],
             "distance_left_b": ib["dl"][:, i], "distance_left_b_nom": ib["dl_nom"][:, i],
             "distance_right_b": ib["dr"][:, i], "distance_right_b_nom": ib["dr_nom"][:, i],
             "is_collision_with_agents": ib["col_agents"][:, i],
             "is_collision_with_lanelets": ib["col_lane"][:, i],
             "is_reach_goal": ib["goal"][:, i],
-            "ref_lanelet_ids": ib["lanelet_ids"][:, i], "path_id": ws.ref_paths_agent_related.path_id[:, i],
+            "ref_lanelet_ids": ib["lanelet_ids"].view(B, self.n_agents, -1)[:, i], "path_id": ws.ref_paths_agent_related.path_id[:, i],
             "applied_action_vel": ws.applied_action_vel[:, i], "applied_action_steer": ws.applied_action_steer[:, i],
             "nominal_action_vel": ws.nominal_action_vel[:, i], "nominal_action_steer": ws.nominal_action_steer[:, i],
         }
+        rew = {name: getattr(self.reward_info, name)[:, i] for name in capi.REWARD_INFO_FIELDS}
+        return info, rew
+
+    def info(self, agent) -> Dict[str, torch.Tensor]:
+        """The 27 + 12 entries of road_traffic.py:1489-1635 (+ 2 with is_using_prioritized_marl).
+
+        The derived entries are elementwise in the agent: they are computed for ALL agents in one batched op each, when the first agent asks after a step or reset
+        (VMAS collects the infos of all agents back to back, tests/vmas_env_shim.py), IN PLACE into buffers that live as long as the scenario -- so every entry of
+        every agent is a view that is built ONCE (624 view constructions per step cost the host 16 % of a surface step; the values are the same ops on the same
+        inputs).  A consumer that keeps an info tensor across steps must clone it -- vmas' Environment does."""
+        i = self._index(agent)
+        empty = agent.action.u is None
+        if getattr(self, "_info_batch", None) is None:
+            self._info_refresh()
+        cache = self._info_cache_empty if empty else self._info_cache
+        if cache[i] is None:
+            cache[i] = self._info_views(i, empty)
+        info = dict(cache[i][0])
+        cv = self.world._clamped_views
+        if not empty and not (cv is not None and agent.action.u is cv[i]):
+            # agent.action.u is not the clamped block the last step left behind (a caller assigned an action and asks before stepping): report what is there
+            nz = self.normalizers
+            act_v, act_s = agent.action.u[:, 0], agent.action.u[:, 1]
+            info.update(act_vel=act_v, act_vel_nom=act_v / nz.v, act_steer=act_s, act_steer_nom=act_s / nz.steering)
         if getattr(self.parameters, "is_using_prioritized_marl", False):
             # the two extra entries of prioritised MARL (road_traffic.py:1513-1520, :1616-1625): the observation padded with the placeholders of the
             # neighbours' actions for the base policy, and the observation itself for the priority-assignment policy
             obs = self.stored_observations[i] if self.stored_observations[i] is not None else self.env.obs[:, i]
             info["base_observation"] = torch.nn.functional.pad(obs.clone(), (0, self.parameters.n_nearing_agents_observed * 2))
             info["priority_observation"] = obs.clone()
-        for name in capi.REWARD_INFO_FIELDS:
-            info[name] = getattr(self.reward_info, name)[:, i]
+        info.update(cache[i][1])  # (the RewardInfo fields last, as the reference's dict orders them)
         return info
 
 
