@@ -900,6 +900,8 @@ int sigmaenv_oracle_obs_dim_full(int32_t n_agents, int32_t n_nearing, int32_t f)
   if (f & SIGMAENV_OBS_STEERING) wid[nf++] = 1;
   if (!(f & SIGMAENV_OBS_NO_DIST_AGENTS)) wid[nf++] = N;
   if (f & SIGMAENV_OBS_REF_OTHERS) wid[nf++] = 2 * NS;
+  if (N % K != 0) return SIGMAENV_EINVAL;  /* the reference reshapes all nine feature tensors to [B, n_nearing, -1], the width-1 ones (rotation, length, width, steering) included, whether
+                                             * or not they end up in the row (observation_provider_rt.py:790-816) */
   int others = 0;
   for (int q = 0; q < nf; ++q) {
     if ((N * wid[q]) % K != 0) return SIGMAENV_EINVAL;          /* torch.reshape(B, n_nearing_agents, -1) raises */

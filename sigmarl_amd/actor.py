@@ -121,7 +121,7 @@ class Actor:
         self.precision = precision
         self.lib = lib or capi.load_library()
         self._mlp32 = Mlp32(mlp, self.lib, mode=mode)  # the exact network (also kept by the bf16 variant: a caller may ask for either per call)
-        self._scratch4 = None
+        self._scratch_by_env = {}
         lin = [m for m in mlp.modules() if isinstance(m, torch.nn.Linear)]
         if len(lin) != 4 or lin[1].in_features != 256 or lin[2].out_features != 256 or lin[3].out_features != 4:
             raise ValueError("expected Linear(D,256), Linear(256,256), Linear(256,256), Linear(256,4)")
@@ -162,15 +162,29 @@ class Actor:
         except Exception:  # noqa: BLE001
             pass
 
+    # Scratch buffers are keyed PER ENV HANDLE: one Actor may drive several env shards on their own streams (bench.py --policy --streams 2), and a buffer shared by two
+    # shards of equal size would be overwritten by the other shard's launches.  Entries live as long as the Actor (a handful of shards).
+    def _scratch_actions(self, env: SigmaEnv) -> torch.Tensor:
+        t = self._scratch_by_env.get(("a", env.h.value if hasattr(env.h, "value") else id(env)))
+        if t is None or t.shape[0] != env.B or t.device != env.device:
+            t = torch.zeros((env.B, env.N, 2), dtype=torch.float32, device=env.device)
+            self._scratch_by_env[("a", env.h.value if hasattr(env.h, "value") else id(env))] = t
+        return t
+
+    def _scratch_out4(self, env: SigmaEnv) -> torch.Tensor:
+        t = self._scratch_by_env.get(("o", env.h.value if hasattr(env.h, "value") else id(env)))
+        if t is None or t.shape[0] != env.B * env.N or t.device != env.device:
+            t = torch.empty((env.B * env.N, 4), dtype=torch.float32, device=env.device)
+            self._scratch_by_env[("o", env.h.value if hasattr(env.h, "value") else id(env))] = t
+        return t
+
     def forward(self, env: SigmaEnv, actions: torch.Tensor, log_prob: torch.Tensor | None = None, loc_scale: torch.Tensor | None = None,
                 obs: torch.Tensor | None = None, seed: int = 0, counter: int = 0, deterministic: bool = False, precision: str | None = None):
         """actions[B,N,2] := policy(env.obs or ``obs``); enqueued on the env's stream."""
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
         if (precision or self.precision) == "fp32":
-            if self._scratch4 is None or self._scratch4.shape[0] != env.B * env.N or self._scratch4.device != env.device:
-                self._scratch4 = torch.empty((env.B * env.N, 4), dtype=torch.float32, device=env.device)
             lo, hi = self._keep[-2], self._keep[-1]
-            rc = env.lib.actor_forward_f32(env.h, self._mlp32.handle(env.lib), p(obs), p(self._scratch4), lo.ctypes.data_as(C.c_void_p), hi.ctypes.data_as(C.c_void_p),
+            rc = env.lib.actor_forward_f32(env.h, self._mlp32.handle(env.lib), p(obs), p(self._scratch_out4(env)), lo.ctypes.data_as(C.c_void_p), hi.ctypes.data_as(C.c_void_p),
                                             p(actions), p(log_prob), p(loc_scale), int(seed), int(counter), int(bool(deterministic)))
             if rc != 0:
                 raise RuntimeError(f"sigmaenv_actor_forward_f32 failed with code {rc}: {env.lib.last_error(env.h).decode()}")
@@ -189,21 +203,18 @@ class Actor:
         arithmetic (``sigmaenv_rollout_f32``), "bf16" = the fast inference variant (``sigmaenv_rollout``)."""
         if path_first is None:
             path_first, path_count = env.default_paths()
-        if not hasattr(self, "_scratch") or self._scratch.shape[0] != env.B or self._scratch.device != env.device:
-            self._scratch = torch.zeros((env.B, env.N, 2), dtype=torch.float32, device=env.device)
+        scratch = self._scratch_actions(env)
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
         p_slab = C.c_void_p(int(slab_ptr)) if slab_ptr else p(slab)
         if (precision or self.precision) == "fp32":
-            if self._scratch4 is None or self._scratch4.shape[0] != env.B * env.N or self._scratch4.device != env.device:
-                self._scratch4 = torch.empty((env.B * env.N, 4), dtype=torch.float32, device=env.device)
             lo, hi = self._keep[-2], self._keep[-1]
-            rc = env.lib.rollout_f32(env.h, self._mlp32.handle(env.lib), lo.ctypes.data_as(C.c_void_p), hi.ctypes.data_as(C.c_void_p), p(self._scratch4), int(n_steps),
-                                      p(self._scratch), p_slab, p(log_prob), p(actions), int(seed), int(counter0), int(path_first), int(path_count),
+            rc = env.lib.rollout_f32(env.h, self._mlp32.handle(env.lib), lo.ctypes.data_as(C.c_void_p), hi.ctypes.data_as(C.c_void_p), p(self._scratch_out4(env)), int(n_steps),
+                                      p(scratch), p_slab, p(log_prob), p(actions), int(seed), int(counter0), int(path_first), int(path_count),
                                       int(bool(deterministic)))
             if rc != 0:
                 raise RuntimeError(f"sigmaenv_rollout_f32 failed with code {rc}: {env.lib.last_error(env.h).decode()}")
             return
-        rc = env.lib.rollout(env.h, self._bf16_handle(env.lib), int(n_steps), p(self._scratch), p_slab, p(log_prob), p(actions), int(seed), int(counter0), int(path_first),
+        rc = env.lib.rollout(env.h, self._bf16_handle(env.lib), int(n_steps), p(scratch), p_slab, p(log_prob), p(actions), int(seed), int(counter0), int(path_first),
                               int(path_count), int(bool(deterministic)))
         if rc != 0:
             raise RuntimeError(f"sigmaenv_rollout failed with code {rc}: {env.lib.last_error(env.h).decode()}")

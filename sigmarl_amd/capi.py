@@ -128,7 +128,9 @@ def obs_dim(n_nearing: int, obs_flags: int = 0, n_short_term: int = N_SHORT_TERM
         if not obs_flags & OBS_BIRD_VIEW or n_nearing < 1:
             raise ValueError("full observation (is_partial_observation=False) exists in bird view only (is_ego_view=False), with n_nearing_agents_observed >= 1")
         widths = ([2, 1, 1, 1] if obs_flags & OBS_NO_VERTICES else [8]) + [2] + [1] * s + ([] if obs_flags & OBS_NO_DIST_AGENTS else [n_agents]) + [2 * n_short_term] * r
-        if any((n_agents * w) % n_nearing for w in widths):
+        # the reference reshapes ALL nine feature tensors to [B, n_nearing, -1] -- position 2, rotation 1, velocity 2, reference path 2 NS, vertices 8, distance N, length 1,
+        # width 1, steering 1 -- whether or not they end up in the row (observation_provider_rt.py:790-816): the width-1 tensors make N % n_nearing == 0 the condition
+        if n_agents % n_nearing or any((n_agents * w) % n_nearing for w in widths):
             raise ValueError(f"full observation: {n_agents} agents x feature widths {widths} do not split into n_nearing_agents_observed = {n_nearing} chunks "
                              "(the reference's reshape(batch, n_nearing_agents, -1) raises)")
         return own + n_agents * sum(widths) + pad

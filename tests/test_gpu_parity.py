@@ -988,12 +988,14 @@ def test_full_observation_16_agents_hip_vs_oracle_and_refusals():
     assert dist.shape[-1] == 8 * N and (dist >= 0).all() and (dist < cfg.obs_noise_level).all()   # zero + noise in [0, level)
     dev.close()
     ora.close()
-    for kw in (dict(is_ego_view=True), dict(is_ego_view=False, n_agents=5, n_nearing_agents_observed=2), dict(is_ego_view=False, n_agents=6, n_nearing_agents_observed=4, is_obs_steering=True)):
+    for kw in (dict(is_ego_view=True), dict(is_ego_view=False, n_agents=5, n_nearing_agents_observed=2), dict(is_ego_view=False, n_agents=6, n_nearing_agents_observed=4, is_obs_steering=True),
+               dict(is_ego_view=False, n_agents=6, n_nearing_agents_observed=4)):  # (vertices 48, velocities 12, distances 36 all split into 4 chunks -- the reference still raises: it reshapes
+                                                                                   # the six rotations / lengths / widths / steering angles to [B, 4, -1] whether or not the row uses them)
         with pytest.raises(NotImplementedError):
             make_config(Parameters(**dict(dict(n_agents=4, scenario_type="cpm_entire", is_partial_observation=False), **kw)), mp, 4)
     lib = capi.load_library()
     assert lib.obs_dim_full(5, 2, capi.OBS_FULL | capi.OBS_BIRD_VIEW) < 0 and lib.obs_dim_full(4, 2, capi.OBS_FULL) < 0
-    assert lib.obs_dim_full(4, 2, capi.OBS_FULL | capi.OBS_BIRD_VIEW) == 70
+    assert lib.obs_dim_full(4, 2, capi.OBS_FULL | capi.OBS_BIRD_VIEW) == 70 and lib.obs_dim_full(6, 4, capi.OBS_FULL | capi.OBS_BIRD_VIEW) < 0
 
 
 @pytest.mark.parametrize("noise", [False, True])

@@ -67,6 +67,13 @@ def test_config_mirrors_init_params():
     assert m.n_nearing == 2 and m.has_entry_exit == 1 and abs(m.threshold_near_other_agents_high - 0.22) < 1e-7
     assert abs(m.lane_width - 0.15) < 1e-7  # make_world's scenario_type kwarg defaults to cpm_entire (road_traffic.py:116-123)
     assert capi.obs_dim(2) == 32
+    # full observation: the reference reshapes all nine feature tensors of the N agents to [B, n_nearing, -1] (observation_provider_rt.py:790-816): N % n_nearing != 0 raises there
+    # even when every INCLUDED width splits (6 agents, 4 chunks: vertices 48, velocities 12, distances 36)
+    full = capi.OBS_FULL | capi.OBS_BIRD_VIEW
+    assert capi.obs_dim(2, full, 3, 4) == 70
+    for n, k in ((6, 4), (5, 2), (16, 3)):
+        with pytest.raises(ValueError):
+            capi.obs_dim(k, full, 3, n)
 
 
 def test_map_tables():
