@@ -361,21 +361,25 @@ def test_two_env_shards_roll_out_into_one_record_buffer():
         assert torch.equal(whole.buffer(w), torch.cat([e.buffer(w) for e in shards], dim=0))
     # ONE Actor driving both shards on their streams: its scratch buffers are per env handle, so the shards' launches do not overwrite each other's actions
     shared = Actor(mlp, low=[-1.0, -0.6], high=[1.0, 0.6])
-    for e in shards:
-        e.reset_random(seed=3)
-    slab3 = torch.zeros((T, B, W), device="cuda")
-    lp3 = [torch.zeros((T, Bs, whole.N), device="cuda") for _ in range(2)]
-    torch.cuda.synchronize()
-    for rep in range(3):  # (a race shows up as a mismatch in some repetition)
-        for e in shards:
-            e.reset_random(seed=3)
+    for rep in range(3):  # (a race shows up as a mismatch in some repetition; fresh shards: the episode counters key the sensor noise)
+        fresh = []
+        for k in range(2):
+            with torch.cuda.stream(streams[k]):
+                e = SigmaEnv(Parameters(**kw), n_envs=Bs, device="cuda:0", env_index_base=k * Bs)
+                e.reset_random(seed=3)
+                e.set_rollout_slab_stride(B * W)
+                fresh.append(e)
+        slab3 = torch.zeros((T, B, W), device="cuda")
+        lp3 = [torch.zeros((T, Bs, whole.N), device="cuda") for _ in range(2)]
         torch.cuda.synchronize()
-        for k, e in enumerate(shards):
+        for k, e in enumerate(fresh):
             shared.rollout(e, T, slab_ptr=slab3.data_ptr() + k * Bs * W * 4, log_prob=lp3[k], seed=9, counter0=100)
-        for e in shards:
+        for e in fresh:
             e.sync()
         assert torch.equal(slab, slab3), f"repetition {rep}"
         assert torch.equal(lp, torch.cat(lp3, dim=1))
+        for e in fresh:
+            e.close()
     assert len(shared._scratch_by_env) >= 2
     shards[0].set_rollout_slab_stride(0)  # back to the handle's own [T, Bs, W] layout
     own = torch.zeros((2, Bs, W), device="cuda")
