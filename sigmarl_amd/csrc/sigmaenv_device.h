@@ -148,6 +148,14 @@ __device__ __forceinline__ float cr_atan(float x) { return sigma_atanf(x); }
 __device__ __forceinline__ void cr_sincos(float x, float& s, float& c) { sigma_sincosf(x, &s, &c); }
 __device__ __forceinline__ float norm2(float x, float y) { return sqrtf(fmaf(y, y, x * x)); }
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+// fminf WITHOUT the canonicalisation the compiler puts in front of it (v_max_f32 x, x, x: quiets a signalling NaN before llvm.minnum): v_min_f32 in IEEE mode already returns the
+// other operand for a NaN of either kind -- the same value for every input that is not a SIGNALLING NaN, which no arithmetic result ever is.  One instruction instead of two on the
+// running minima of the scan (4 per segment).
+__device__ __forceinline__ float fmin_nc(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ float remainder_pos(float a, float b) {  // torch.remainder, b > 0
   // 0 <= a < b: fmod returns a itself, exactly (the steering-angle wrap of every step lands here); the general routine -- a loop over the exponent
   // difference -- only runs for the lanes that need it
