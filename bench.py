@@ -792,8 +792,18 @@ def main():
             # the per-launch counts of the profile (per step of its launches) at this run's step rate
             vs = float(vj.get("steps_per_launch", 1))
             launches_per_s = S / step_s
+            # the kernel's VALU instruction RATE per SIMD against the rate of a pure all-VGPR v_fma_f32 stream at the same occupancy (profiles/valu_calibration.json: the
+            # calibration VERDICT r4 asked for -- SQ_ACTIVE_INST_VALU turned out to count instructions, so round 4's "valu_issue_frac 0.94" was this rate x 4 nominal cycles)
+            inst_rate = vj["valu_insts_per_launch"] / vs * launches_per_s / vj["n_simd"]
+            try:
+                with open(os.path.join(ROOT, "profiles", "valu_calibration.json")) as f:
+                    cal = json.load(f)
+            except Exception:  # noqa: BLE001
+                cal = {}
             valu = {
-                "valu_issue_frac": vj["valu_busy_cycles_per_launch"] / vs * launches_per_s / (vj["n_simd"] * vj["clock_hz"]),
+                "valu_inst_per_s_per_simd": inst_rate,
+                "valu_rate_vs_vgpr_fma_stream": (inst_rate / cal["vgpr_fma_stream_inst_per_s_per_simd"]) if cal.get("vgpr_fma_stream_inst_per_s_per_simd") else None,
+                "valu_nominal_cycles_per_inst": vj["clock_hz"] / inst_rate if inst_rate > 0 else None,
                 "fp32_flop_frac": vj["fp32_flops_per_launch"] / vs * launches_per_s / (FP32_PEAK_TFLOPS * 1e12),
                 "valu_insts_per_launch": vj["valu_insts_per_launch"] / vs * steps_per_launch, "valu_source": vj.get("source", "profiles/valu_latest.json") + " (not this run)",
             }

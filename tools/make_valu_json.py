@@ -5,7 +5,7 @@
   valu_busy_cycles_per_launch  SQ_ACTIVE_INST_VALU x 4 (the counter ticks in quad-cycles, MI355X guide "cycle constants"), summed over SIMDs
   fp32_flops_per_launch        (ADD_F32 + MUL_F32 + TRANS_F32 + 2 FMA_F32) x mean active lanes per VALU instruction
                                (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU / 4 ... approximated by thread-cycles per instruction, <= 64)
-bench.py scales them by its own launch rate: valu_issue_frac = busy cycles per second / (1024 SIMDs x clock), fp32_flop_frac = flops per
+bench.py scales them by its own launch rate: valu_inst_per_s_per_simd (against the pure-FMA stream of profiles/valu_calibration.json), fp32_flop_frac = flops per
 second / 157.3e12.  Usage: tools/make_valu_json.py <pmc_outdir> <n_agents> <envs_per_launch> <out.json> [scenario] [source-note]
 Environment: KERNEL_SUBSTR (default sigmaenv_step_wave_kernel) selects the kernel, STEPS_PER_LAUNCH (default 1) records how many env steps ONE
 launch of the profiled run held (the in-kernel step loop, sigmaenv_step_autoreset_n): bench.py divides the per-launch counts by it."""
