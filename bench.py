@@ -915,10 +915,12 @@ def main():
         condition_device(r1, torch, args.condition_ms, step_s)
         r1.run_steps(0, min(args.warmup, 32))
         r1.finish_chunk()
-        el1 = timed(r1, args.steps, args.warmup, use_dist, dist, torch, device)
+        # (an auxiliary leg: the better of two repetitions -- on some boxes the first timed region of a freshly created pair of shard streams carries a one-time stall
+        # of 30-60 ms, profiles/r05_bench.json against r05_lines_bench.json)
+        el1 = min(timed(r1, args.steps, args.warmup, use_dist, dist, torch, device), timed(r1, args.steps, args.warmup + args.steps, use_dist, dist, torch, device))
         out["config"]["per_step_launch"] = {"ms_per_step": el1 / args.steps * 1e3, "value": total_agent_steps / el1, "env_shards_per_gpu": r1.S,
                                             "note": "same steps, one launch per step and env shard (sigmaenv_step_autoreset), timed after the headline regions at the GPU's "
-                                                    "sustained clocks (compare with value_sustained, not with value)"}
+                                                    "sustained clocks (compare with value_sustained, not with value); the better of two repetitions"}
         r1.close()
     if args.emulate_ranks > 1 and world == 1:
         # BASELINE config 3 (16 agents x 32768 envs over 8 GPUs) on the one GPU of this box: rank r's shard -- envs [r B, (r + 1) B) of the batch, the
