@@ -821,6 +821,9 @@ def main():
         # `value` is the contract measurement (W warm-up + K timed steps on the device as the setup left it: warmup_effective_steps == warmup).  What a rollout loop
         # that has been running for a while sees (the GPU's sustained clocks) is reported BESIDE it, never as `value`:
         "warmup_effective_steps": args.warmup,
+        "value_semantics": ("value = the contract measurement (W warm-up + K timed steps on the device as the setup left it), as in rounds 1-3 and as round 4's "
+                            "config.cold_start; value_sustained = the same steps after --condition-ms of the same launches, which is what round 4 printed as `value` "
+                            "(compare BENCH_r04 value 2.46e9 with this line's value_sustained, and BENCH_r04 config.cold_start 2.195e9 with this line's value)"),
         **({"value_sustained": sustained["value"], "ms_per_step_sustained": sustained["ms_per_step"],
             "warmup_effective_steps_sustained": sustained["warmup_effective_steps"]} if sustained is not None else {}),
         "config": {
