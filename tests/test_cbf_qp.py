@@ -272,13 +272,14 @@ def test_qp_matches_an_independent_solver_of_the_original_problem(nominal):
 
 # ---- instances found by tools/fuzz_cbf.py on which earlier versions of the projected Newton iteration failed -----------------------------
 REGRESSIONS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "qp_regressions.npz")
-REGRESSION_TAGS = ["cycle", "crawl0", "crawl1", "crawl2", "crawl3", "crawl4", "noisefloor"]
+REGRESSION_TAGS = ["cycle", "crawl0", "crawl1", "crawl2", "crawl3", "crawl4", "noisefloor", "valley"]
 
 
 def regression_case(make_env, tag):
     """One env of a fuzz run on which the solver once (cycle) alternated between two points because a step that raised F by 1e-9 |F| was
     accepted, (crawl*) halved a variable's distance to its bound per iteration until the step underflowed -- and then called it converged --,
-    (noisefloor) never met the step-size stop although it sat on the minimiser.  Returns (env, actions [1, N, 2], nominal controller)."""
+    (noisefloor) never met the step-size stop although it sat on the minimiser, (valley) zig-zagged for 100 iterations between a free variable and one
+    inside the fixed-width epsilon band of a bound it does not end on (the band now shrinks with the step: Bertsekas' rule).  Returns (env, actions [1, N, 2], nominal controller)."""
     z = np.load(REGRESSIONS)
     kw = eval(str(z[tag + "_kw"]))
     mp = load_map(kw["scenario_type"])
