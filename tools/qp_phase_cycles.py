@@ -14,7 +14,7 @@ for _ in range(20):
     env.step_autoreset(act, seed=1)
 u = torch.zeros((B,N,2), dtype=torch.float64, device="cuda"); info = torch.zeros((B,2), dtype=torch.int32, device="cuda")
 env.cbf_qp(act, None, u, info); env.sync()
-d = u.reshape(B,-1)[:, :14].cpu()
+d = u.reshape(B,-1)[:, :15].cpu()
 it = info[:,0].float().cpu()
 print("cycles (x100MHz shader clock?) mean total %.0f eval %.0f chol %.0f ls %.0f ; iters mean %.2f" % (d[:,0].mean(), d[:,1].mean(), d[:,2].mean(), d[:,3].mean(), it.mean()))
 print("per iteration: eval %.0f chol %.0f ls %.0f ; outside loop %.0f" % ((d[:,1]/it).mean(), (d[:,2]/it).mean(), (d[:,3]/it).mean(), (d[:,0]-d[:,1]-d[:,2]-d[:,3]).mean()))
@@ -32,3 +32,8 @@ for k in order.tolist():
     print("  env %4d: duration %.1f us (start %.1f), candidates %d, iterations %d, cycles total %.0f eval %.0f chol %.0f ls %.0f, before the loop %.0f" % (k, float(en[k]-st[k]), float(st[k]), int(d[k,7]), int(it[k]), d[k,0], d[k,1], d[k,2], d[k,3], d[k,4]+d[k,5]+d[k,6]))
 print("iterations histogram:", torch.bincount(it.long()).tolist())
 print("candidates histogram:", torch.bincount(d[:,7].long()).tolist())
+reg = d[:,1] > 0
+for nm, msk in (("without candidates", reg & z), ("with candidates", reg & ~z)):
+    if msk.any():
+        print("register path, envs %s: evaluations %.2f per solve (%.2f per iteration), cycles per evaluation %.0f, per direction %.0f (iterations %.2f); solve %.0f" % (nm, d[msk,14].mean(), (d[msk,14]/it[msk]).mean(), (d[msk,2]/d[msk,14]).mean(), (d[msk,3]/it[msk]).mean(), it[msk].mean(), d[msk,1].mean()))
+k = int(order[0]); print("slowest env: evaluations %d, cycles in evaluations %.0f, in directions %.0f, iterations %d" % (int(d[k,14]), d[k,2], d[k,3], int(it[k])))
