@@ -56,4 +56,14 @@ for rep in range(int(os.environ.get("REPS", 4))):
     for t_ in order.tolist():
         k_ = int(inv[t_]); pos[t_] = seen.get(k_, 0); seen[k_] = pos[t_] + 1
     out["by rank of the tile index among the SIMD's four: mean end us"] = {int(x): round(float(end[pos == x].mean()), 1) for x in range(int(pos.max()) + 1)}
+    # where the spread between SIMDs comes from: the SIMD's last end by XCC / CU / SIMD
+    cu_key = simd_key >> 2
+    lastw = last[inv]
+    import collections
+    def spread(keyarr):
+        ks, iv = np.unique(keyarr, return_inverse=True)
+        m = np.zeros(len(ks)); c = np.zeros(len(ks)); np.add.at(m, iv, lastw); np.add.at(c, iv, 1); m /= c
+        return float(m.std()), float(m.max() - m.min())
+    out["std / range of the mean last-end us by XCC, by CU, by SIMD"] = [[round(x, 1) for x in spread(xcc)], [round(x, 1) for x in spread(cu_key)], [round(x, 1) for x in spread(simd_key)]]
+    out["SIMD index within the CU: mean last-end us"] = {int(x): round(float(last[(keys & 3) == x].mean()), 1) for x in range(4)}
     print(json.dumps(out))

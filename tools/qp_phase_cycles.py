@@ -13,7 +13,8 @@ act = torch.stack([torch.rand(B, N, generator=g, device="cuda") * 1.2 - 0.1, tor
 for _ in range(20):
     env.step_autoreset(act, seed=1)
 u = torch.zeros((B,N,2), dtype=torch.float64, device="cuda"); info = torch.zeros((B,2), dtype=torch.int32, device="cuda")
-env.cbf_qp(act, None, u, info); env.sync()
+for _ in range(int(os.environ.get("QP_CALLS", 1))):  # (QP_CALLS > 1: repeated solves of the same problem)
+    env.cbf_qp(act, None, u, info); env.sync()
 d = u.reshape(B,-1)[:, :15].cpu()
 it = info[:,0].float().cpu()
 print("cycles (x100MHz shader clock?) mean total %.0f eval %.0f chol %.0f ls %.0f ; iters mean %.2f" % (d[:,0].mean(), d[:,1].mean(), d[:,2].mean(), d[:,3].mean(), it.mean()))
