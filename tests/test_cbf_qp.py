@@ -272,14 +272,15 @@ def test_qp_matches_an_independent_solver_of_the_original_problem(nominal):
 
 # ---- instances found by tools/fuzz_cbf.py on which earlier versions of the projected Newton iteration failed -----------------------------
 REGRESSIONS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "qp_regressions.npz")
-REGRESSION_TAGS = ["cycle", "crawl0", "crawl1", "crawl2", "crawl3", "crawl4", "noisefloor", "valley"]
+REGRESSION_TAGS = ["cycle", "crawl0", "crawl1", "crawl2", "crawl3", "crawl4", "noisefloor", "valley", "wall"]
 
 
 def regression_case(make_env, tag):
     """One env of a fuzz run on which the solver once (cycle) alternated between two points because a step that raised F by 1e-9 |F| was
     accepted, (crawl*) halved a variable's distance to its bound per iteration until the step underflowed -- and then called it converged --,
     (noisefloor) never met the step-size stop although it sat on the minimiser, (valley) zig-zagged for 100 iterations between a free variable and one
-    inside the fixed-width epsilon band of a bound it does not end on (the band now shrinks with the step: Bertsekas' rule).  Returns (env, actions [1, N, 2], nominal controller)."""
+    inside the fixed-width epsilon band of a bound it does not end on (the band now shrinks with the step: Bertsekas' rule), (wall) ended 1e-15 beside a
+    minimiser that sits where a 1e9-weighted term switches on, with the one-sided projected gradient 10 % above the stop test.  Returns (env, actions [1, N, 2], nominal controller)."""
     z = np.load(REGRESSIONS)
     kw = eval(str(z[tag + "_kw"]))
     mp = load_map(kw["scenario_type"])
@@ -304,7 +305,9 @@ def test_solver_regressions_converge_to_the_solution_of_the_original_problem(tag
         assert np.abs(x - u[0].reshape(-1)).max() <= 1e-5
     elif kw.get("adaptive_lambda"):  # (the interior-point check needs the lambda penalty: without it the original problem is not strictly convex)
         assert compare_with_original_problem(env, u, con, unom, kw["nom_controller_type"], 1) <= 1e-5
-    check_kkt(env, u, con, unom, kw["nom_controller_type"], tol=1e-8) if not kw.get("is_grouping_agents") else None
+    # ("wall": the minimiser sits where a 1e9-weighted term switches on and is approached from the flat side: the stationarity residual there is the one-sided
+    #  gradient, 1.1e-6, while the point itself is within 1e-9 of the interior-point solution checked above)
+    check_kkt(env, u, con, unom, kw["nom_controller_type"], tol=2e-6 if tag == "wall" else 1e-8) if not kw.get("is_grouping_agents") else None
     env.close()
 
 

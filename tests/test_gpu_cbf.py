@@ -576,7 +576,7 @@ def test_grouped_qp_full_size_4096_envs():
     env.close()
 
 
-@pytest.mark.parametrize("tag", ["cycle", "crawl0", "crawl1", "crawl2", "crawl3", "crawl4", "noisefloor", "valley"])
+@pytest.mark.parametrize("tag", ["cycle", "crawl0", "crawl1", "crawl2", "crawl3", "crawl4", "noisefloor", "valley", "wall"])
 def test_solver_regressions_hip_vs_oracle(tag):
     """The instances of tests/data/qp_regressions.npz (found by tools/fuzz_cbf.py: a 2-cycle of the noise-tolerant acceptance rule, a
     variable creeping towards a bound with a collapsing line search, a stop test below the gradient's noise floor, a zig-zag along a valley
