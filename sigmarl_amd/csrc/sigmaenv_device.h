@@ -482,6 +482,27 @@ __device__ __forceinline__ void row16_min6(float& a, float& b, float& c, float& 
                SIGMA_DPP_ROW6("v_min_f32_dpp", "row_mirror")
                : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
 }
+// three minima at once (the same pattern; three chains leave two instructions between a write and its DPP read: one s_nop per step)
+#define SIGMA_DPP_ROW3(OP, CTRL) \
+  OP " %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\t" OP " %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t" \
+  OP " %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
+__device__ __forceinline__ void row16_min3(float& a, float& b, float& c) {
+  asm volatile("s_nop 1\n\t"
+               SIGMA_DPP_ROW3("v_min_f32_dpp", "quad_perm:[1,0,3,2]")
+               SIGMA_DPP_ROW3("v_min_f32_dpp", "quad_perm:[2,3,0,1]")
+               SIGMA_DPP_ROW3("v_min_f32_dpp", "row_half_mirror")
+               SIGMA_DPP_ROW3("v_min_f32_dpp", "row_mirror")
+               : "+v"(a), "+v"(b), "+v"(c));
+}
+// ONE minimum (a single chain: two wait states between dependent steps)
+__device__ __forceinline__ void row16_min1(float& a) {
+  asm volatile("s_nop 1\n\t"
+               "v_min_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+               "v_min_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+               "v_min_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+               "v_min_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+               : "+v"(a));
+}
 // two row-of-16 minima of non-negative ints (two interleaved chains, one s_nop between dependent steps)
 #define SIGMA_DPP_ROW2(OP, CTRL) \
   OP " %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\t" OP " %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
