@@ -660,3 +660,37 @@ def test_grouped_qp_beyond_32_vehicles():
     assert np.abs(safe_d - safe_o).max() <= 1e-6
     dev.close()
     ora.close()
+
+
+def test_packed_hessian_with_an_odd_vehicle_count():
+    """41 vehicles (tests/data/qp_big_odd_instance.npz, found by tools/fuzz_cbf.py --cpm-agents 48): the packed lower triangle of the <BIG> instantiation has
+    N (2 N + 1) words -- odd for an odd vehicle count -- and its last word (the last unknown's diagonal entry) was not cleared between the evaluations: the solve
+    depended on what the LDS held before (13 ... 100 iterations from run to run, one env not converged).  HIP == oracle, twice, with the oracle's iteration counts."""
+    import torch
+    from sigmarl_amd.maps import load_map
+    from sigmarl_amd.params import make_config
+
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "qp_big_odd_instance.npz"), allow_pickle=True)
+    kw = eval(str(d["kw"]))
+    B, N = d["state"].shape[:2]
+    assert N == 41
+    mp = load_map(kw["scenario_type"])
+    p = Parameters(**kw)
+    outs = []
+    for make in (ob.OracleEnv, _hip_env, _hip_env):
+        env = make(make_config(p, mp, B), mp)
+        seg_l, seg_r = cbf.load_segment_tables(mp)
+        env.cbf_attach(cbf.make_cbf_config(p), seg_l, seg_r)
+        env.reset(np.repeat(np.arange(B), N).astype(np.int32), np.tile(np.arange(N), B).astype(np.int32), d["path"].reshape(-1, 4), d["state"].reshape(-1, 8), 1)
+        if make is ob.OracleEnv:
+            env.get(capi.BUF_SHORT_TERM, copy=False)[:] = d["short"]
+        else:
+            env.env.buffer(capi.BUF_SHORT_TERM)[:] = torch.as_tensor(d["short"]).to(env.env.device)
+        safe, u, info = env.cbf_qp(d["act"].astype(np.float32))[:3]
+        outs.append((u, info))
+        env.close()
+    (u_o, i_o), (u_1, i_1), (u_2, i_2) = outs
+    assert i_o[:, 1].all() and i_1[:, 1].all() and i_2[:, 1].all(), (i_o, i_1, i_2)
+    assert np.array_equal(i_1, i_2) and np.array_equal(u_1, u_2)
+    assert np.array_equal(i_1[:, 0], i_o[:, 0]), (i_1[:, 0], i_o[:, 0])
+    assert np.abs(u_1 - u_o).max() <= 1e-7

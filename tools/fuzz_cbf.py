@@ -22,10 +22,16 @@ from sigmarl_amd.params import Parameters, make_config
 MAPS = ["cpm_entire", "cpm_entire", "intersection_1", "on_ramp_1", "roundabout_1"]
 
 
+UNCONVERGED = [0]  # solves at the iteration limit on both sides (only beyond 16 vehicles)
+CPM_MAX_AGENTS = 16  # (--cpm-agents: up to 64 vehicles on the CPM map -- the two / one lanes per vehicle layouts of the QP kernel's register path and its <BIG> instantiation)
+
+
 def one_case(rng, k):
     scen = MAPS[rng.integers(len(MAPS))]
     mp = load_map(scen)
-    N = int(rng.integers(1, (16 if scen.startswith("cpm") else 5) + 1))
+    N = int(rng.integers(1, (CPM_MAX_AGENTS if scen.startswith("cpm") else 5) + 1))
+    if CPM_MAX_AGENTS > 16 and scen.startswith("cpm"):
+        N = int(rng.integers(17, CPM_MAX_AGENTS + 1))
     B = int(rng.integers(4, 40))
     solve = bool(rng.integers(3) > 0)
     grouping = solve and N >= 3 and bool(rng.integers(3) == 0)
@@ -57,11 +63,17 @@ def one_case(rng, k):
         if solve:
             sd, ud, idv = dev.cbf_qp(act)
             so, uo, io = ora.cbf_qp(act)[:3]
-            if not (idv[:, 1].all() and io[:, 1].all()):
+            if not np.array_equal(idv[:, 1], io[:, 1]) or (CPM_MAX_AGENTS <= 16 and not idv[:, 1].all()):
+                # up to 16 vehicles every solve converges; beyond (--cpm-agents), crammed scenes hit the iteration limit -- on BOTH sides, for the same envs, or it is a finding
                 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
                 np.savez(os.path.join(ROOT, "gpurun_out", "fuzz_cbf_fail.npz"), state=ora.get(capi.BUF_STATE), path=ora.get(capi.BUF_PATH), short=ora.get(capi.BUF_SHORT_TERM),
                          act=act, info_hip=idv, info_ora=io, u_hip=ud, u_ora=uo, kw=np.asarray(repr(kw)))
                 raise AssertionError(tag + f" | not converged at step {t}: hip {np.flatnonzero(idv[:, 1] == 0).tolist()} iters {idv[:, 0].max()}, oracle {np.flatnonzero(io[:, 1] == 0).tolist()} iters {io[:, 0].max()}")
+            UNCONVERGED[0] += int((idv[:, 1] == 0).sum())
+            keep = idv[:, 1] != 0
+            ud, uo = ud[keep], uo[keep]  # (an env at the iteration limit: wherever the iteration happened to stand -- the safe action compared below is the nominal one on both sides)
+            if len(ud) == 0:
+                ud, uo = np.zeros((1, 1, 2)), np.zeros((1, 1, 2))
             if grouping:
                 assert np.array_equal(dev.cbf_groups(), ora.cbf_groups()), tag + " | groups"
             du = float(np.abs(ud - uo).max())
@@ -101,7 +113,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=240.0)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--cpm-agents", type=int, default=16, help="largest vehicle count on the CPM map (17 .. 64: only such cases are drawn there)")
     args = ap.parse_args()
+    global CPM_MAX_AGENTS
+    CPM_MAX_AGENTS = args.cpm_agents
     rng = np.random.default_rng(args.seed)
     t0 = time.time()
     k = n_qp = n_grp = n_margin = 0
@@ -111,7 +126,8 @@ def main():
         k += 1
         n_qp += int(solve and not grouping); n_grp += int(grouping); n_margin += int(not solve)
         wu, wm = max(wu, du), max(wm, dm)
-    print(f"fuzz_cbf: {k} configurations ({n_qp} centralized QP, {n_grp} grouped QP, {n_margin} margin reward): all converged, max |u_hip - u_oracle| {wu:.2e}, "
+    conv = "all converged" if UNCONVERGED[0] == 0 else str(UNCONVERGED[0]) + " solves at the iteration limit on both sides alike"
+    print(f"fuzz_cbf: {k} configurations ({n_qp} centralized QP, {n_grp} grouped QP, {n_margin} margin reward): {conv}, max |u_hip - u_oracle| {wu:.2e}, "
           f"max relative margin difference {wm:.2e}, env buffers identical")
 
 
