@@ -341,9 +341,9 @@ def test_cbf_qp_rollout_reward_vs_oracle(apply, nominal):
     ora.close()
 
 
-@pytest.mark.parametrize("N", [24, 40])
+@pytest.mark.parametrize("N", [24, 40, 41])
 def test_cbf_qp_dense_cluster_uses_the_full_system(N):
-    """24 (40: the packed-Hessian variant) vehicles piled within half a metre: (almost) every vehicle is coupled to others through active pair rows, more than
+    """24 (40, 41: the packed-Hessian variant, with an even and an odd number of words) vehicles piled within half a metre: (almost) every vehicle is coupled to others through active pair rows, more than
     the 16 the compacted register factorisation takes -- the full-system LDS path; same minimiser as the oracle, KKT conditions hold."""
     from test_cbf_qp import check_kkt
 
