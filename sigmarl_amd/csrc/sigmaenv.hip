@@ -1761,6 +1761,7 @@ struct sigmaenv {
   unsigned long long* lanelet_neigh = nullptr;  // [n_lanelets] neighbour bit masks
   int n_lanelets = 0, lanelet_pts = 0;
   int DL = 0;                     // floats per agent slot of the kernels' LDS staging of the observation rows (= D unless SIGMAENV_OBS_FULL, see ObsLayout)
+  void* cbf_defer = nullptr;      // [B] u8: envs the CBF-QP's lean launch left to the full-layout launch (up to 32 vehicles; allocated by the first sigmaenv_cbf_qp)
   void* cbf_cand_big = nullptr;   // [B][N (N - 1) C^2] u32: the CBF-QP's candidate pair rows for 33 .. 64 vehicles (allocated by the first such sigmaenv_cbf_qp)
   int32_t* cbf_groups = nullptr;  // [B,N] group index of every vehicle (grouped CBF-QPs), formed by the first sigmaenv_cbf_qp call
   bool cbf_groups_valid = false;
