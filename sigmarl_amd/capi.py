@@ -166,6 +166,7 @@ _SIGS = {
     "cbf_get_groups": (C.c_int, [C.c_void_p, C.c_void_p]),
 }
 _PRODUCT_ONLY = {
+    "build_id": (C.c_char_p, []),
     "step_time_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "kernel_time_ms": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "set_slab": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -225,6 +226,36 @@ def variant_path(n_short_term: int = N_SHORT_TERM) -> str:
     return DEFAULT_LIB if n_short_term == N_SHORT_TERM else os.path.join(_PKG_DIR, "csrc", f"libsigmaenv_ns{int(n_short_term)}.so")
 
 
+def source_build_id() -> str:
+    """What ``sigmaenv_build_id()`` of a library built from THIS tree returns: the first 16 hex digits of the SHA-256 over the files of the Makefile's SRC list, in
+    that order (the Makefile is one of them)."""
+    import hashlib
+    import re
+
+    csrc = os.path.join(_PKG_DIR, "csrc")
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    files = re.search(r"^SRC = (.*)$", mk, re.M).group(1).split()
+    h = hashlib.sha256()
+    for f in files:
+        h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def check_build_id(lib: "Library") -> None:
+    """A library built from other sources than the tree's is refused (the .so files are not rebuilt on the GPU box).  SIGMAENV_ALLOW_STALE=1 turns the error into a
+    warning (A/B runs against a kept older build)."""
+    have, want = (lib.build_id().decode() if hasattr(lib, "build_id") else "none (an older build)"), source_build_id()
+    if have != want:
+        msg = (f"{lib.path} was built from other sources than this tree (build id {have}, tree {want}): run `python -c 'import __graft_entry__ as g; g.build()'` "
+               f"or `make -C sigmarl_amd/csrc`")
+        if os.environ.get("SIGMAENV_ALLOW_STALE") == "1":
+            import warnings
+
+            warnings.warn(msg)
+        else:
+            raise RuntimeError(msg)
+
+
 def load_library(path: str | None = None, n_short_term: int = N_SHORT_TERM) -> Library:
     """Loads ``libsigmaenv.so`` (or the build for another ``n_points_short_term``).  torch is imported first on purpose: PyTorch-ROCm ships its own
     ``libamdhip64``; loading ours before torch's would put two HIP runtimes in the process (observed: hipGetDeviceCount fails in the second one)."""
@@ -242,6 +273,7 @@ def load_library(path: str | None = None, n_short_term: int = N_SHORT_TERM) -> L
             lib = Library(p, "sigmaenv_", _PRODUCT_ONLY)
             if lib.n_short_term() != n_short_term:
                 raise RuntimeError(f"{p} is built for n_points_short_term={lib.n_short_term()}, not {n_short_term}")
+            check_build_id(lib)
             _product_libs[n_short_term] = lib
         return lib
     return Library(path, "sigmaenv_", _PRODUCT_ONLY)

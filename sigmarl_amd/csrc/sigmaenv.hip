@@ -1225,6 +1225,7 @@ __device__ inline void load_tile_for_observation(const Smem& s, const DevBufs& g
 }
 
 __global__ void __launch_bounds__(256) sigmaenv_observe_kernel(sigmaenv_config_t c, DevBufs g, int G) {
+  sigma_poison_lds();
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const Tile t(c, G);
   Smem s(smem_raw, G * t.N, t.N, t.K, t.DL);
@@ -1237,6 +1238,7 @@ __global__ void __launch_bounds__(256) sigmaenv_observe_kernel(sigmaenv_config_t
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void sigmaenv_reset_scatter_kernel(DevBufs g, int N, int n, const int32_t* env_idx, const int32_t* agent_idx, const int32_t* path_ids,
                                               const float* state8, int full_env) {
+  sigma_poison_lds();
   int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   int b = env_idx[k], i = agent_idx[k];
@@ -1391,6 +1393,7 @@ __device__ inline void reset_finish_body(const sigmaenv_config_t& c, const DevBu
 
 // host-driven resets: only tiles with marked agents do work
 __global__ void __launch_bounds__(512) sigmaenv_reset_derive_kernel(sigmaenv_config_t c, DevMap m, DevBufs g, int with_obs, int G) {
+  sigma_poison_lds();
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const Tile t(c, G);
   const int N = t.N;
@@ -1424,6 +1427,7 @@ __global__ void __launch_bounds__(512) sigmaenv_reset_derive_kernel(sigmaenv_con
 // Start table (DevMap::start_table): one workgroup derives 64 consecutive (path, point) rows with the same code the resets use
 // (rect_vertices, scan_mask_task, pair_scan, short_term_path), so that copying a row is bit-identical to deriving it in place.
 __global__ void __launch_bounds__(256) sigmaenv_start_table_kernel(sigmaenv_config_t c, DevMap m, float* table) {
+  sigma_poison_lds();
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int S = 64;
   Smem s(smem_raw, S, 1, 0, 1);
@@ -1676,6 +1680,7 @@ __device__ __forceinline__ void auto_reset_tile(const sigmaenv_config_t& c, cons
 // stand-alone launch: one workgroup per tile; tiles without a finished env / a reset request exit at once
 __global__ void __launch_bounds__(512) sigmaenv_auto_reset_kernel(sigmaenv_config_t c, DevMap m, DevBufs g, uint64_t seed, uint64_t counter,
                                                                   int path_first, int path_count, int G) {
+  sigma_poison_lds();
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const Tile t(c, G);
   const int N = t.N;
@@ -1777,12 +1782,19 @@ struct sigmaenv {
     }                                                                                                \
   } while (0)
 
-static int dev_alloc(sigmaenv* h, void** p, size_t bytes) {
+// Device memory of the handle, zero-filled (state buffers rely on that).  scratch: a buffer every consumer of which is preceded by its producer in the same call
+// (intermediates between kernels, staging areas) -- zero in the product build too, 0xFF bytes in the poison build (sigmaenv_device.h: sigma_poison_lds).
+static int dev_alloc(sigmaenv* h, void** p, size_t bytes, bool scratch = false) {
   if (bytes == 0) bytes = 16;
   hipError_t e = hipMalloc(p, bytes);
   if (e != hipSuccess) { h->err = std::string("hipMalloc: ") + hipGetErrorString(e); return SIGMAENV_ENOMEM; }
   h->allocs.push_back(*p);
+#ifdef SIGMAENV_POISON
+  e = hipMemsetAsync(*p, scratch ? 0xFF : 0, bytes, h->stream);
+#else
+  (void)scratch;
   e = hipMemsetAsync(*p, 0, bytes, h->stream);
+#endif
   if (e != hipSuccess) { h->err = std::string("hipMemsetAsync: ") + hipGetErrorString(e); return SIGMAENV_EHIP; }
   return SIGMAENV_OK;
 }
@@ -1795,6 +1807,10 @@ static void dev_free(sigmaenv* h, void* p) {
 }
 
 extern "C" int sigmaenv_n_short_term(void) { return NS; }
+#ifndef SIGMAENV_BUILD_ID
+#define SIGMAENV_BUILD_ID "unknown"
+#endif
+extern "C" const char* sigmaenv_build_id(void) { return SIGMAENV_BUILD_ID; }
 extern "C" int sigmaenv_obs_dim(int32_t n_nearing) { return 1 + 2 * NS + 3 + n_nearing * 11; }
 extern "C" int sigmaenv_obs_dim_ex(int32_t n_nearing, int32_t f) {  // observation_provider_rt.py:803-925
   const int s = (f & SIGMAENV_OBS_STEERING) ? 1 : 0, r = (f & SIGMAENV_OBS_REF_OTHERS) ? 1 : 0;
@@ -1845,6 +1861,38 @@ static int pick_envs_per_group(int N, int B, int n_cu) {
   return G;
 }
 
+#ifdef SIGMAENV_POISON
+// poison build: how many bytes one unit of LDS_ALLOC.LDS_SIZE stands for, measured once per process with a launch of known size (the fill of sigma_poison_lds must
+// cover the allocation and nothing beyond it)
+__global__ void sigma_poison_probe_kernel(unsigned* out) {
+  extern __shared__ char probe_smem[];
+  if (threadIdx.x == 0) { probe_smem[0] = 1; out[0] = sigma_lds_alloc_units() + (probe_smem[0] ? 0u : 1u); }
+}
+static int poison_probe(hipStream_t stream) {
+  static bool done = false;
+  if (done) return SIGMAENV_OK;
+  unsigned* d = nullptr;
+  unsigned units[2] = {0u, 0u};
+  if (hipMalloc((void**)&d, 8) != hipSuccess) return SIGMAENV_ENOMEM;
+  hipLaunchKernelGGL(sigma_poison_probe_kernel, dim3(1), dim3(64), 32768, stream, d);
+  hipLaunchKernelGGL(sigma_poison_probe_kernel, dim3(1), dim3(64), 16384, stream, d + 1);
+  if (hipMemcpyAsync(units, d, 8, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) { (void)hipFree(d); return SIGMAENV_EHIP; }
+  (void)hipFree(d);
+  // (gfx950 answers 130 / 65: units of 256 bytes, allocations rounded up to 1280 bytes -- 160 KB / 128; the rounding belongs to the workgroup too)
+  unsigned granule = 0u;
+  for (unsigned g : {64u, 128u, 256u, 512u})
+    if (units[0] * g >= 32768u && units[0] * g < 32768u + 2048u && units[1] * g >= 16384u && units[1] * g < 16384u + 2048u) granule = g;
+  if (granule == 0u) {
+    fprintf(stderr, "sigmaenv (poison build): unexpected LDS_ALLOC.LDS_SIZE readings %u / %u for 32768 / 16384 bytes\n", units[0], units[1]);
+    return SIGMAENV_EHIP;
+  }
+  if (hipMemcpyToSymbol(HIP_SYMBOL(sigmadev::sigma_lds_granule), &granule, sizeof(unsigned)) != hipSuccess) return SIGMAENV_EHIP;
+  fprintf(stderr, "sigmaenv (poison build): LDS and scratch buffers are poisoned (LDS_SIZE unit = %u bytes)\n", granule);
+  done = true;
+  return SIGMAENV_OK;
+}
+#endif
+
 extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_t* map, int device_id, void* hip_stream, sigmaenv_t** out) {
   if (!cfg || !map || !out) return SIGMAENV_EINVAL;
   *out = nullptr;
@@ -1862,6 +1910,9 @@ extern "C" int sigmaenv_create(const sigmaenv_config_t* cfg, const sigmaenv_map_
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1 || device_id < 0 || device_id >= n_dev) return SIGMAENV_ENODEV;
   if (hipSetDevice(device_id) != hipSuccess) return SIGMAENV_ENODEV;
+#ifdef SIGMAENV_POISON
+  { const int rcp = poison_probe(reinterpret_cast<hipStream_t>(hip_stream)); if (rcp != SIGMAENV_OK) return rcp; }
+#endif
   sigmaenv* h = new sigmaenv();
   h->cfg = *cfg;
   h->device = device_id;
@@ -2256,13 +2307,13 @@ extern "C" int sigmaenv_reset(sigmaenv_t* h, int32_t n, const int32_t* env_idx, 
     size_t cap = (size_t)n * 2;
     void* p;
     int rc;
-    if ((rc = dev_alloc(h, &p, cap * 4)) != 0) return rc;
+    if ((rc = dev_alloc(h, &p, cap * 4, true)) != 0) return rc;
     h->d_env_idx = (int32_t*)p;
-    if ((rc = dev_alloc(h, &p, cap * 4)) != 0) return rc;
+    if ((rc = dev_alloc(h, &p, cap * 4, true)) != 0) return rc;
     h->d_agent_idx = (int32_t*)p;
-    if ((rc = dev_alloc(h, &p, cap * 16)) != 0) return rc;
+    if ((rc = dev_alloc(h, &p, cap * 16, true)) != 0) return rc;
     h->d_path_ids = (int32_t*)p;
-    if ((rc = dev_alloc(h, &p, cap * 32)) != 0) return rc;
+    if ((rc = dev_alloc(h, &p, cap * 32, true)) != 0) return rc;
     h->d_state8 = (float*)p;
     h->staging_cap = cap;
   }
@@ -2491,6 +2542,7 @@ extern "C" int sigmaenv_kernel_time_ms(sigmaenv_t* h, int32_t kernel_id, double*
 extern "C" int sigmaenv_step_time_ms(sigmaenv_t* h, double* avg_ms, int32_t* n_launches) { return sigmaenv_kernel_time_ms(h, SIGMAENV_KERNEL_STEP, avg_ms, n_launches); }
 
 __global__ void sigmaenv_trig_selftest_kernel(int kind, int n, const float* __restrict__ in, float* __restrict__ out) {
+  sigma_poison_lds();
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   const float x = in[k];

@@ -21,6 +21,24 @@
 
 namespace sigmadev {
 
+// `make poison` (libsigmaenv_poison.so, -DSIGMAENV_POISON; never loaded by the package unless SIGMAENV_LIB points at it): every kernel starts by filling its whole LDS
+// allocation -- static + dynamic, read from the wavefront's LDS_ALLOC hardware register -- with 0xFF bytes (NaN as float / double, huge as an index), and every SCRATCH
+// buffer in HBM is allocated as 0xFF instead of zero (dev_alloc).  A kernel that reads what "the previous workgroup left" then fails deterministically instead of
+// from run to run (the packed Hessian's last word of round 4: profiles/r06_poison_suite.txt).  The product build compiles this to nothing.
+#ifdef SIGMAENV_POISON
+__device__ unsigned sigma_lds_granule = 0u;  // bytes per unit of LDS_ALLOC.LDS_SIZE, measured by sigmaenv_create's probe launch (sigma_poison_probe_kernel)
+__device__ __forceinline__ unsigned sigma_lds_alloc_units() { return (unsigned)__builtin_amdgcn_s_getreg(6 | (12 << 6) | ((9 - 1) << 11)); }  // HW_REG_LDS_ALLOC, LDS_SIZE = bits [20:12]
+__device__ __forceinline__ void sigma_poison_lds() {
+  const unsigned words = sigma_lds_alloc_units() * sigma_lds_granule / 4u;
+  auto* lds = (__attribute__((address_space(3))) unsigned*)0;
+  const unsigned tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z), nt = blockDim.x * blockDim.y * blockDim.z;
+  for (unsigned k = tid; k < words; k += nt) lds[k] = 0xFFFFFFFFu;
+  __syncthreads();
+}
+#else
+__device__ __forceinline__ void sigma_poison_lds() {}
+#endif
+
 struct DevMap {
   const float* center;  // [n_paths][P][2] padded (world_state_rt.py:313-420)
   const float* left;

@@ -53,6 +53,7 @@ def load_oracle(n_short_term: int = capi.N_SHORT_TERM) -> capi.Library:
             "fn_trig": (None, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
             "fn_pseudo_distance": (None, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
             "cbf_qp_ex": (C.c_int, [C.c_void_p] * 7),
+            "fn_qp_vanish_tol": (C.c_double, [C.c_double]),
             "env0_reset_side_effect": (C.c_int, [C.c_void_p, C.c_int32]),
             "path_table": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(_f32p), C.POINTER(_f32p), C.POINTER(_f32p)]),
         }

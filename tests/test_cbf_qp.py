@@ -350,3 +350,16 @@ def test_fuzz_instance_oracle_equals_the_interior_point_solution():
     print("oracle vs interior point per env:", " ".join(f"{e:.1e}" for e in err))
     assert err.max() <= FUZZ_IP_TOL
     env.close()
+
+
+def test_vanishing_step_stop_test_is_capped_by_an_absolute_term():
+    """after a vanishing step (<= 1e-10) the projected gradient may exceed the strict tolerance 1e-6 (1 + |F|) -- the "wall" regression's one-sided
+    1.1e-6 -- but by an ABSOLUTE allowance (1e-4), not by a factor of |F|: with the round-5 rule (100 x the strict tolerance) an env whose 1e9-weighted rows are
+    active (F ~ 1e6 ... 1e9) got a bound of 1e2 ... 1e5, the order of the stalls (3e4) that the crawl regressions exist to reject.  A stalled point with large F
+    must be reported as not converged: the bound at F = 1e9 stays far below 3e4, and it is never stricter than the strict test."""
+    f = ob.load_oracle().fn_qp_vanish_tol
+    assert f(0.0) == 1e-4 and f(10.0) == 1e-4            # small F: the absolute allowance (round 5: 1e-4 and 1.1e-3)
+    for F in (1e3, 1e6, 1e9, -1e9):
+        strict = 1e-6 * (1.0 + abs(F))
+        assert f(F) == max(strict, 1e-4)                   # large F: no loosening at all
+    assert f(1e9) < 3e4 / 10 and f(1e6) < 3e4 / 1e3        # the crawl stalls (projected gradient 3e4) are rejected whatever F is

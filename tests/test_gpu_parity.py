@@ -33,8 +33,12 @@ def _hip_env(cfg, mp):
 
 def test_extension_is_loaded_and_exports_abi():
     lib = capi.load_library()
-    assert lib.path.endswith("sigmarl_amd/csrc/libsigmaenv.so")
+    # (SIGMAENV_LIB: an explicitly chosen other build of the same HIP library from the same directory -- the poison build of tools/poison_suite.sh)
+    chosen = os.environ.get("SIGMAENV_LIB")
+    assert lib.path.endswith("sigmarl_amd/csrc/libsigmaenv.so") or (chosen and lib.path == chosen and os.path.basename(chosen).startswith("libsigmaenv"))
     assert lib.obs_dim(2) == 32
+    # the library was built from the sources of this tree (the .so files are not rebuilt on the GPU box: a stale one must not be tested silently)
+    assert lib.build_id().decode() == capi.source_build_id()
 
 
 @pytest.mark.parametrize("name", tr.TRAJ_NAMES)

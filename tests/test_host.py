@@ -112,6 +112,11 @@ def test_hip_library_exports_the_declared_abi():
             assert v.sigmaenv_n_short_term() == ns
     lib.sigmaenv_obs_dim.restype = ctypes.c_int
     assert lib.sigmaenv_obs_dim(2) == 32
+    # every built library carries the id of the sources of this tree (the GPU box uses the prebuilt files: a stale one must fail loudly, capi.check_build_id)
+    for path in [so] + [capi.variant_path(ns) for ns in (2, 5) if os.path.exists(capi.variant_path(ns))]:
+        v = ctypes.CDLL(path)
+        v.sigmaenv_build_id.restype = ctypes.c_char_p
+        assert v.sigmaenv_build_id().decode() == capi.source_build_id(), f"{path} is stale: rebuild it (make -C sigmarl_amd/csrc [NS=k])"
     # create() without a device must fail cleanly, not crash
     cfg = make_config(Parameters(n_agents=2, scenario_type="cpm_entire", is_apply_mask=False), load_map("cpm_entire"), 1)
     m = load_map("cpm_entire").as_struct()

@@ -3,6 +3,7 @@
 # turn, REPS rounds interleaved, through SIGMAENV_LIB (capi.py: an alternative build of the same HIP library, never a fallback).
 # Usage: tools/ab_libs.sh <tag> <lib.so> [<lib.so> ...]   (paths relative to sigmarl_amd/csrc; REPS=3, STEPS=256 by default)
 tag=$1; shift
+export SIGMAENV_ALLOW_STALE=1 SIGMAENV_LIB_OLD_ABI=1  # (kept older builds are the point of an A/B)
 R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/$tag; mkdir -p $out
 REPS=${REPS:-3}; STEPS=${STEPS:-256}
 for r in $(seq 1 $REPS); do

@@ -22,6 +22,9 @@ from sigmarl_amd.params import Parameters, make_config
 MAPS = ["cpm_entire", "cpm_entire", "intersection_1", "on_ramp_1", "roundabout_1"]
 
 
+STATS = {"iter_mismatch": 0, "solves": 0, "repeat_checked": 0}  # iteration counts HIP vs oracle; bitwise repeats of the HIP solve (CHECK_REPEAT)
+CHECK_REPEAT = [False]  # tests/test_gpu_fuzz.py: every QP is solved twice on the device and the two results must be the same bits (minimiser, safe action, iteration counts)
+FORCE_N = [0]           # tests/test_gpu_fuzz.py: the vehicle count of the next CPM case (odd counts beyond 32: the packed Hessian's last word)
 UNCONVERGED = [0]  # solves at the iteration limit on both sides (only beyond 16 vehicles)
 CPM_MAX_AGENTS = 16  # (--cpm-agents: up to 64 vehicles on the CPM map -- the two / one lanes per vehicle layouts of the QP kernel's register path and its <BIG> instantiation)
 
@@ -32,6 +35,8 @@ def one_case(rng, k):
     N = int(rng.integers(1, (CPM_MAX_AGENTS if scen.startswith("cpm") else 5) + 1))
     if CPM_MAX_AGENTS > 16 and scen.startswith("cpm"):
         N = int(rng.integers(17, CPM_MAX_AGENTS + 1))
+        if FORCE_N[0]:
+            N = FORCE_N[0]
     B = int(rng.integers(4, 40))
     solve = bool(rng.integers(3) > 0)
     grouping = solve and N >= 3 and bool(rng.integers(3) == 0)
@@ -62,7 +67,14 @@ def one_case(rng, k):
         act = np.stack([rng.uniform(-0.3, 1.2, (B, N)), rng.uniform(-0.5, 0.5, (B, N))], axis=-1).astype(np.float32)
         if solve:
             sd, ud, idv = dev.cbf_qp(act)
+            if CHECK_REPEAT[0]:
+                sd2, ud2, idv2 = dev.cbf_qp(act)
+                assert np.array_equal(idv, idv2) and np.array_equal(ud.view(np.uint64), ud2.view(np.uint64)) and np.array_equal(sd.view(np.uint32), sd2.view(np.uint32)), \
+                    tag + f" | a second solve of the same problem differs at step {t}: iterations {idv[:, 0].tolist()} vs {idv2[:, 0].tolist()}"
+                STATS["repeat_checked"] += B
             so, uo, io = ora.cbf_qp(act)[:3]
+            STATS["solves"] += B
+            STATS["iter_mismatch"] += int((idv[:, 0] != io[:, 0]).sum())
             if not np.array_equal(idv[:, 1], io[:, 1]) or (CPM_MAX_AGENTS <= 16 and not idv[:, 1].all()):
                 # up to 16 vehicles every solve converges; beyond (--cpm-agents), crammed scenes hit the iteration limit -- on BOTH sides, for the same envs, or it is a finding
                 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
