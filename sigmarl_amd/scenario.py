@@ -42,6 +42,16 @@ try:  # pragma: no cover - vmas is not installed in the build image
     from vmas.simulator.scenario import BaseScenario as _VmasBaseScenario
 except Exception:  # noqa: BLE001
     _VmasBaseScenario = None
+# The reference's WorldCustom / Vehicle / VehicleState ARE vmas classes (helper_training.py:791, helper_common.py:382, :290): with vmas importable the classes below derive
+# from the same bases, so that an ``isinstance(world, vmas.simulator.core.World)`` in VMAS / TorchRL / user code holds.  The bases' allocating ``__init__`` is NOT called
+# (the state stays a view of the library's buffers); every attribute the mirror keeps on its instances is declared at class level below, which takes the bases'
+# read-only properties of the same names (Entity.name, Agent.u_range, World.x_semidim, TorchVectorizedObject.batch_dim ...) out of the way
+# (tests/test_host.py::test_mirror_classes_derive_from_the_vmas_bases, with a stand-in vmas package of the published attribute names).
+try:  # pragma: no cover
+    from vmas.simulator.core import Agent as _VmasAgent, AgentState as _VmasAgentState, World as _VmasWorld
+except Exception:  # noqa: BLE001
+    _VmasAgent = _VmasAgentState = _VmasWorld = None
+_WorldBase, _AgentBase, _AgentStateBase = (_VmasWorld or object), (_VmasAgent or object), (_VmasAgentState or object)
 
 
 class _BaseScenarioStandIn:
@@ -118,11 +128,17 @@ class _Action:
             setattr(self, k, getattr(self, k).to(device))
 
 
-class VehicleState:
+class VehicleState(_AgentStateBase):
     """pos/rot/vel + speed/steering/sideslip_angle (helper_common.py:290-379) as views of ``SIGMAENV_BUF_STATE[:, i]``."""
+
+    batch_dim = device = None  # (instance attributes here; properties with a set-once rule on vmas' TorchVectorizedObject)
 
     def __init__(self, state_row: torch.Tensor):
         self._s = state_row  # [B, 8] strided view: x, y, psi, speed, steering, vx, vy, sideslip
+        self.batch_dim, self.device = state_row.shape[0], state_row.device
+        # what the bases' own accessors read (EntityState / AgentState: no angular velocity, communication, force or torque here)
+        self._batch_dim, self._device = self.batch_dim, self.device
+        self._ang_vel = self._c = self._force = self._torque = None
 
     pos = property(lambda self: self._s[:, 0:2])
     rot = property(lambda self: self._s[:, 2:3])
@@ -132,9 +148,13 @@ class VehicleState:
     sideslip_angle = property(lambda self: self._s[:, 7:8])
 
 
-class Vehicle:
+class Vehicle(_AgentBase):
     """``Vehicle(Agent)`` of helper_common.py:382-430.  Direct state writes do NOT refresh the derived tensors; go through
     ``ScenarioRoadTraffic.reset_world_at`` / ``SigmaEnv.reset`` for that."""
+
+    # instance attributes of the mirror (read-only properties on vmas' Entity / Agent: see the note at the imports)
+    name = shape = color = collide = render_action = u_range = u_multiplier = max_speed = dynamics = batch_dim = device = None
+    action_size = silent = movable = rotatable = action_script = is_scripted_ai = obs_range = obs_noise = discrete_action_nvec = None
 
     def __init__(self, name, state_row, shape, u_range, max_speed, dynamics, color=None):
         self.name = name
@@ -147,8 +167,8 @@ class Vehicle:
         self.max_speed = max_speed
         self.dynamics = dynamics
         self._state = VehicleState(state_row)
-        self.batch_dim = state_row.shape[0]
-        self.device = state_row.device
+        self.batch_dim = self._batch_dim = state_row.shape[0]
+        self.device = self._device = state_row.device
         self._action = _Action(u_range, self.u_multiplier, self.device)
         # what vmas' Environment reads on an agent while it sets actions and collects results (Agent(..., dynamics=...) derives action_size from
         # dynamics.needed_action_size; road_traffic.py:788-813 passes collide=False, render_action=False, no action script, silent by default)
@@ -193,13 +213,15 @@ class Vehicle:
         self._set(self.state.sideslip_angle, sideslip_angle, batch_index)
 
 
-class WorldCustom:
+class WorldCustom(_WorldBase):
     """``WorldCustom(World)`` of helper_training.py:791-861: ``step()`` is ONE fused HIP launch over agents x envs."""
+
+    batch_dim = device = dt = x_semidim = y_semidim = parameters = dim_c = dim_p = None  # instance attributes of the mirror (properties on vmas' World)
 
     def __init__(self, env: SigmaEnv, dt: float, x_semidim, y_semidim):
         self._env = env
-        self.batch_dim = env.B
-        self.device = env.device
+        self.batch_dim = self._batch_dim = env.B
+        self.device = self._device = env.device
         self.dt = dt
         self.x_semidim, self.y_semidim = x_semidim, y_semidim
         self._agents = []

@@ -360,15 +360,40 @@ def test_seeded_initial_reset_reproduces_the_reference(name, kw):
     env.close()
 
 
-def test_mirror_under_an_environment_shaped_driver():
-    """The plugin surface driven the way vmas' Environment drives a scenario (tests/vmas_env_shim.py: __init__ -> env_make_world + reset, step ->
+@pytest.mark.parametrize("vmas_bases", [False, True])
+def test_mirror_under_an_environment_shaped_driver(vmas_bases):
+    """(vmas_bases: the same run with the mirror's classes DERIVED from vmas' World / Agent / AgentState / BaseScenario -- tests/fake_vmas.py, the published class
+    skeleton whose constructors and tensor-touching methods raise when reached -- as they are wherever vmas is installed: isinstance holds and nothing changes.)
+    The plugin surface driven the way vmas' Environment drives a scenario (tests/vmas_env_shim.py: __init__ -> env_make_world + reset, step ->
     _set_action / env_process_action / pre_step / world.step / post_step / get_from_scenario, reset_at for finished envs as TorchRL's VmasEnv
     issues it): every attribute that driver touches exists on WorldCustom / Vehicle / Action, out-of-range actions trip its assertion unless
     clamp_actions is set, and the results equal the same episode driven through the callbacks by hand."""
+    import contextlib
+    import importlib
+    import sys
+
     import torch
-    from sigmarl_amd.scenario import make_scenario
+
+    import fake_vmas
+    import sigmarl_amd.scenario as scmod
     from vmas_env_shim import EnvironmentShim
 
+    with (fake_vmas.installed() if vmas_bases else contextlib.nullcontext()):
+        try:
+            scmod = importlib.reload(scmod)
+            _environment_shaped_driver(scmod, EnvironmentShim, torch)
+            if vmas_bases:
+                core = sys.modules["vmas.simulator.core"]
+                assert issubclass(scmod.WorldCustom, core.World) and issubclass(scmod.Vehicle, core.Agent) and issubclass(scmod.VehicleState, core.AgentState)
+        finally:
+            if vmas_bases:
+                for n in [k for k in sys.modules if k == "vmas" or k.startswith("vmas.")]:
+                    sys.modules.pop(n)
+            importlib.reload(scmod)
+
+
+def _environment_shaped_driver(scmod, EnvironmentShim, torch):
+    make_scenario = scmod.make_scenario
     B, N, T = 24, 4, 14  # (4 agents: the reference's rejection sampler, restated on the host, does not terminate for more on this small map)
     kw = dict(n_agents=N, scenario_type="intersection_1", is_use_mtv_distance=False, is_apply_mask=False, is_obs_noise=False, num_vmas_envs=B, max_steps=9, dt=0.1)
     sc_a, sc_b = make_scenario(Parameters(**kw)), make_scenario(Parameters(**kw))

@@ -475,3 +475,104 @@ def test_observation_noise_specification_matches_the_reference_scaling():
     assert np.array_equal(noisy, run(True)) and not np.array_equal(noisy, run(True, seed=7))
     # the draws follow the env's index in the WHOLE batch: a shard sees what the unsharded batch sees
     assert np.array_equal(run(True, lo=32, hi=64), noisy[:, 32:64])
+
+
+def test_mirror_classes_derive_from_the_vmas_bases():
+    """the reference's WorldCustom / Vehicle / VehicleState are vmas subclasses (helper_training.py:791, helper_common.py:382, :290); with vmas importable the
+    mirror's classes derive from the same bases -- ``isinstance`` holds --, the bases' allocating constructors are never called, no read-only base property (name,
+    u_range, x_semidim, batch_dim ...) keeps the mirror from holding its own value, and the state accessors are still views of the library's buffer.  vmas itself is
+    absent from the image: tests/fake_vmas.py provides the published class skeleton (its constructors and tensor-touching methods raise when reached)."""
+    import importlib
+    from types import SimpleNamespace
+
+    import torch
+
+    import fake_vmas
+    import sigmarl_amd.scenario as sc
+
+    try:
+        with fake_vmas.installed():
+            sc = importlib.reload(sc)
+            core = sys.modules["vmas.simulator.core"]
+            assert sc.BaseScenario is sys.modules["vmas.simulator.scenario"].BaseScenario
+            B, N = 5, 3
+            state = torch.arange(B * N * 8, dtype=torch.float32).reshape(B, N, 8)  # stands for SIGMAENV_BUF_STATE
+            env = SimpleNamespace(B=B, N=N, device=torch.device("cpu"))
+            world = sc.WorldCustom(env, 0.05, torch.tensor(4.5), torch.tensor(4.0))
+            for i in range(N):
+                world.add_agent(sc.Vehicle(name=f"agent_{i}", state_row=state[:, i], shape=sc.Box(0.16, 0.08), u_range=[1.0, 0.5], max_speed=1.0,
+                                           dynamics=sc.KinematicBicycleModel(device="cpu")))
+            assert isinstance(world, core.World) and isinstance(world, core.TorchVectorizedObject)
+            a = world.agents[1]
+            assert isinstance(a, core.Agent) and isinstance(a, core.Entity) and isinstance(a.state, core.AgentState) and isinstance(a.state, core.EntityState)
+            # nothing of the bases shadows what the mirror keeps: names, ranges, dims, and the views themselves
+            assert a.name == "agent_1" and a.u_range == [1.0, 0.5] and a.max_speed == 1.0 and a.silent is True and a.action_size == 2 and a.action_script is None
+            assert a.batch_dim == B and a.state.batch_dim == B and world.batch_dim == B and world.dim_c == 0 and world.dim_p == 2 and float(world.x_semidim) == 4.5
+            assert world.agents is world.policy_agents and world.entities == world.agents and world.scripted_agents == []
+            assert a.state.pos.data_ptr() == state[:, 1, 0:2].data_ptr() and a.state.rot.shape == (B, 1) and a.state.vel.shape == (B, 2)
+            a.set_pos(torch.tensor([7.0, 8.0]), batch_index=2)  # the mirror's setter (a write into the buffer), not Entity.set_pos
+            assert state[2, 1, 0] == 7.0 and state[2, 1, 1] == 8.0
+            a.set_rot(torch.full((B, 1), 0.25))
+            assert torch.all(state[:, 1, 2] == 0.25)
+            assert a.state.c is None and a.state.force is None  # the bases' own accessors find their (empty) backing fields
+            world.reset(None); world.zero_grad(); world.to(torch.device("cpu"))  # the mirror's no-ops, not World's
+            assert a.action.u is None and a.action.u_range_tensor.shape == (2,)
+    finally:
+        sc = importlib.reload(sc)  # back to the image's state (no vmas)
+    assert sc.WorldCustom.__mro__[1] is object
+
+
+_PARTIAL_CHUNK_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch
+import torch.distributed as dist
+from sigmarl_amd.shard import RolloutExchange, slab_width
+
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+B, N, D, T = 3, 2, 5, 7            # 7 steps over 3 / 8 ranks: uneven (and, for 8 ranks, EMPTY) time slices
+W = slab_width(N, D)
+def cell(r, t, b):                 # what rank r records for step t of its env b: a value that names all three (and the chunk it belongs to, below)
+    return float(1000 * r + 10 * t + b)
+ex = RolloutExchange(B, N, D, T, "cpu", mode="alltoall")
+assert ex.slices == [(r * T) // world for r in range(world + 1)]
+for chunk_no, n_steps in enumerate([T, 4]):   # a full chunk through chunk() / commit(), then a LAST chunk of which only 4 rows are new: commit(4)
+    buf = ex.chunk()
+    buf.fill_(-1.0)                           # (rows beyond n_steps are stale by contract: they still travel, valid_steps says so)
+    for t in range(n_steps):
+        for b in range(B):
+            buf[t, b, :] = cell(rank, t, b) + 100000.0 * chunk_no
+    ex.commit(n_steps)
+ex.wait_all()
+assert ex.completed == [(0, T), (1, 4)] and ex.valid_steps == [T, 4], (ex.completed, ex.valid_steps)
+lo, hi = ex.slices[rank], ex.slices[rank + 1]
+for k, n_steps in ex.completed:
+    mine = ex.time_slice(k)                   # [my steps, world * B, W]: steps [lo, hi) of the chunk for the envs of ALL ranks, in rank order
+    assert tuple(mine.shape) == (hi - lo, world * B, W), mine.shape
+    for t in range(lo, hi):
+        for r in range(world):
+            for b in range(B):
+                want = cell(r, t, b) + 100000.0 * k if t < n_steps else -1.0    # (a stale row arrives as it was left; the consumer reads valid_steps)
+                got = mine[t - lo, r * B + b]
+                assert torch.all(got == want), (k, t, r, b, float(got[0]), want)
+# what a learner rank may read of the last chunk: its slice cut at valid_steps
+new_rows = max(0, min(hi, ex.valid_steps[1]) - lo)
+assert new_rows == len([t for t in range(lo, hi) if t < 4])
+dist.barrier()
+if rank == 0: print("PARTIAL_OK", world)
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("world,port", [(3, 29531), (8, 29533)])
+def test_last_partial_chunk_ships_valid_steps_under_alltoall_with_uneven_slices(tmp_path, world, port):
+    """``commit(n_steps < T)`` on the last chunk under the all-to-all exchange with uneven time slices, for world sizes 3 and 8 (gloo; 7 steps over
+    8 ranks leaves one rank an EMPTY slice): ``completed`` / ``valid_steps`` carry the number of new rows, every rank receives exactly its slice of every rank's chunk,
+    stale rows arrive as they were left."""
+    script = tmp_path / "worker.py"
+    script.write_text(_PARTIAL_CHUNK_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), str(script), ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and f"PARTIAL_OK {world}" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
