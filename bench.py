@@ -489,6 +489,101 @@ class SurfaceRun:
     close = GpuRun.close
 
 
+def cbf_valu_roofline(kernel_name, N, Bs, kernel_ms, hbm_roofline):
+    """The CBF kernels (centralized QP, margin rewards) are bound by VALU ISSUE, not by HBM or a matrix pipe ("frac 0.0018 of HBM is not a bound for a
+    projected-Newton kernel"): roofline = the kernel's VALU wavefront-instructions per second and SIMD against what a SIMD-32 can issue -- one wave64 instruction per
+    2 cycles (MI355X guide) at the shader clock the kernel ran at in its PMC pass.  Instruction counts, clock, fp64 share and wait fractions come from the committed
+    pass of this workload (profiles/valu_dominant_latest.json / valu_cbf_margin_latest.json, tools/make_valu_json.py), the duration from THIS run's HIP events (one
+    bracket around the launches of a call: for the QP the lean launch and the launch for the envs it left over)."""
+    src = "valu_dominant_latest.json" if "qp" in kernel_name else "valu_cbf_margin_latest.json"
+    try:
+        with open(os.path.join(ROOT, "profiles", src)) as f:
+            vj = json.load(f)
+        if not (vj.get("kernel", "") in kernel_name and vj.get("n_agents") == N and vj.get("envs_per_launch") == Bs):
+            return {}
+    except Exception:  # noqa: BLE001
+        return {}
+    clk = vj.get("shader_clock_hz_measured") or vj["clock_hz"]
+    rate = vj["valu_insts_per_launch"] / (kernel_ms * 1e-3) / vj["n_simd"]  # wavefront instructions per second and SIMD
+    peak = clk / 2.0
+    f64 = vj.get("f64_insts_per_launch") or 0.0
+    return {
+        "bound": "valu", "achieved": rate / 1e9, "peak": peak / 1e9, "unit": "G wave64-inst/s/SIMD", "frac": rate / peak,
+        "frac_nominal_clock": rate / (vj["clock_hz"] / 2.0), "shader_clock_hz_measured": vj.get("shader_clock_hz_measured"),
+        "valu_insts_per_launch": vj["valu_insts_per_launch"], "f64_inst_share": f64 / vj["valu_insts_per_launch"], "f64_flops_per_launch": vj.get("f64_flops_per_launch"),
+        "f64_flop_frac": (vj.get("f64_flops_per_launch") or 0.0) / (kernel_ms * 1e-3) / 78.6e12,
+        "mean_active_lanes_per_valu_inst": vj.get("mean_active_lanes_per_valu_inst"), "wait_any_frac": vj.get("wait_any_frac"), "wait_inst_any_frac": vj.get("wait_inst_any_frac"),
+        "hbm_frac": hbm_roofline.get("frac"), "hbm_achieved_gbps": hbm_roofline.get("achieved"),
+        "valu_source": vj.get("source"),
+        "achieved_basis": "the DOMINANT kernel of this workload (largest share of GPU time by HIP events) is bound by VALU issue: its VALU wavefront-instructions per launch "
+                          "(rocprofv3 --pmc SQ_INSTS_VALU of this workload, committed pass, not this run) / its average duration in THIS run / 1024 SIMDs, against one wave64 "
+                          "instruction per 2 cycles at the shader clock of the pass (SQ_BUSY_CYCLES / 32 / dispatch duration).  What keeps it below that is latency, not "
+                          "issue: wait_any_frac of the wave-cycles wait on memory / LDS counters (profiles/r06_qp_lds.txt); hbm_frac restates the old HBM figure",
+    }
+
+
+def baseline_lines(args, device, torch, dist, head_step_s):
+    """config.lines: the other single-GPU configurations of BASELINE.json in the driver's own line (every line of BASELINE.md section 5 but the headline
+    was the builder's own run) -- config 4 (on_ramp_1, 32 agents x 8192 envs), config 5 (the centralized CBF-QP before every step), the mtv distance, the reference's
+    own defaults (mtv + mask + noise).  Each: a fresh run object, ~60 ms of its own launches (sustained clocks), W warm-up + K timed steps between synchronisations,
+    HIP-event kernel averages, the dominant kernel's roofline with the bound that kernel has.  Timed AFTER the headline's regions: `value` is untouched."""
+    import copy
+
+    from sigmarl_amd import capi as _capi
+
+    specs = [
+        ("config4_on_ramp_32x8192", dict(scenario="on_ramp_1", agents=32, envs_per_gpu=8192), 64, 32,
+         "BASELINE config 4: on_ramp_1, 32 agents x 8192 envs (injected start: every env restarts every step -- a reset benchmark by construction; its shape on CPM runs at ~1.6e9)"),
+        ("config5_cbf_qp", dict(cbf_qp=True), 48, 16, "BASELINE config 5: CPM, 16 agents x 4096 envs, centralized CBF-QP safety filter solved before every step (two env shards on two streams)"),
+        ("distance_mtv", dict(distance="mtv"), 128, 32, "config 2 with the mtv distance (Parameters.is_use_mtv_distance)"),
+        ("reference_defaults", dict(defaults=True), 128, 32, "config 2 with the reference's own defaults for this path (helper_common.py:66-79): mtv distance, is_apply_mask, is_obs_noise"),
+    ]
+    lines = []
+    for name, over, K, W, what in specs:
+        t_line = time.perf_counter()
+        try:
+            a = copy.copy(args)
+            for k, v in over.items():
+                setattr(a, k, v)
+            plain = not (a.policy or a.cbf or a.cbf_qp)
+            T = pick_chunk(K) if plain else 1
+            os.environ["SIGMAENV_TIMING_STRIDE"] = str(max(1, min(32, (K // T) // 8)))  # (read when a handle is created: the HIP-event brackets of every stride-th launch)
+            run = GpuRun(a, device, a.envs_per_gpu, 1, 0, with_exchange=True, T=T)
+            run.arm_timing()
+            run.run_steps(0, W)
+            run.finish_chunk()
+            torch.cuda.synchronize()
+            el0 = timed(run, K, W, False, dist, torch, device)
+            condition_device(run, torch, 60.0, el0 / K, T)
+            run.run_steps(0, W)
+            run.finish_chunk()
+            torch.cuda.synchronize()
+            run.kernel_timing()
+            el = timed(run, K, W, False, dist, torch, device)
+            kt = run.kernel_timing()
+            N, B, D, Bs, S = a.agents, a.envs_per_gpu, run.D, run.Bs, run.S
+            dom = max(kt, key=lambda k: kt[k][0] * kt[k][1]) if kt else _capi.KERNEL_STEP
+            dms, dn = kt.get(dom, (0.0, 0))
+            value = N * B * K / el
+            bytes_per = algorithmic_bytes_per_agent_step(N, D)
+            hbm = {"bound": "hbm", "achieved": bytes_per * value / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": bytes_per * value / 1e9 / HBM_PEAK_GBPS,
+                   "algorithmic_bytes_per_agent_env_step": bytes_per}
+            roof = dict(hbm)
+            if dom in (_capi.KERNEL_CBF_QP, _capi.KERNEL_CBF_MARGIN):
+                roof.update(cbf_valu_roofline(_capi.KERNEL_NAMES[dom], N, Bs, dms, hbm))
+            roof.update({"kernel": _capi.KERNEL_NAMES[dom], "kernel_avg_ms": dms, "kernel_launches": dn, "steps_per_launch": T,
+                         "kernel_time_share": {_capi.KERNEL_NAMES[k]: {"avg_ms": v[0], "launches_bracketed": v[1]} for k, v in kt.items()}})
+            lines.append({"name": name, "workload": what, "value": value, "value_contract_style": N * B * K / el0, "unit": "agent-env-steps/s", "ms_per_step": el / K * 1e3, "steps": K, "warmup": W,
+                          "n_agents": N, "envs_per_gpu": B, "env_shards_per_gpu": S, "steps_per_launch": T, "obs_dim": D, "dominant_kernel": _capi.KERNEL_NAMES[dom], "roofline": roof,
+                          "clocks": "sustained (60 ms of the line's own launches before its warm-up; value_contract_style = the first W + K steps of the fresh run object)",
+                          "wall_s": None})
+            run.close()
+        except Exception as exc:  # noqa: BLE001 -- a side line must never take the headline down
+            lines.append({"name": name, "workload": what, "error": f"{type(exc).__name__}: {exc}"})
+        lines[-1]["wall_s"] = time.perf_counter() - t_line
+    return lines
+
+
 def condition_device(run, torch, ms, step_s, per=1):
     """Device conditioning (--condition-ms): `ms` milliseconds of the run's own step launches, as a STEP COUNT derived from `step_s` (a MAX-reduced time: the same
     count on every rank, so the ranks issue the same number of chunk exchanges).  Returns the steps run."""
@@ -654,6 +749,8 @@ def main():
                     help="skip the additional per-step-launch measurement reported in config.per_step_launch")
     ap.add_argument("--emulate-ranks", type=int, default=0, help="after the headline: BASELINE config 3's workload on this ONE GPU -- R shards of --envs-per-gpu envs "
                     "(rank r = envs [r B, (r + 1) B) of the batch), each timed like the headline with its own rollout exchange; reported in config.emulated_ranks")
+    ap.add_argument("--no-lines", dest="lines", action="store_false", help="skip config.lines: the other single-GPU BASELINE configurations (config 4, config 5, mtv, the "
+                    "reference's defaults), each timed for a few seconds AFTER the headline's regions and appended to the headline's JSON line")
     ap.add_argument("--no-reset", action="store_true", help="diagnostic: leave finished envs un-reset")
     ap.add_argument("--separate-reset", action="store_true", help="two launches per step (sigmaenv_step; sigmaenv_auto_reset) instead of the fused one")
     ap.add_argument("--no-gather", action="store_true", help="diagnostic: no rollout record (and no exchange for N > 1)")
@@ -800,7 +897,14 @@ def main():
                     cal = json.load(f)
             except Exception:  # noqa: BLE001
                 cal = {}
+            # against the MACHINE: a wave64 VALU instruction issues in 2 cycles on a SIMD-32 (MI355X guide: v_fma_f32 2 cyc), so a SIMD takes clock / 2
+            # of them per second; the clock is the one the kernel ran at in the PMC pass (SQ_BUSY_CYCLES / 32 shader engines / the dispatch's duration), not the
+            # nominal 2.4 GHz.  x mean active lanes / 64 = the share of lane-cycles that carry work.
+            clk = vj.get("shader_clock_hz_measured") or vj["clock_hz"]
             valu = {
+                "valu_issue_frac_arch": inst_rate * 2.0 / clk, "valu_issue_frac_arch_nominal_clock": inst_rate * 2.0 / vj["clock_hz"],
+                "valu_lane_cycle_frac_arch": inst_rate * 2.0 / clk * vj.get("mean_active_lanes_per_valu_inst", 64.0) / 64.0,
+                "shader_clock_hz_measured": vj.get("shader_clock_hz_measured"), "valu_cycles_per_inst_at_measured_clock": clk / inst_rate if inst_rate > 0 else None,
                 "valu_inst_per_s_per_simd": inst_rate,
                 "valu_rate_vs_vgpr_fma_stream": (inst_rate / cal["vgpr_fma_stream_inst_per_s_per_simd"]) if cal.get("vgpr_fma_stream_inst_per_s_per_simd") else None,
                 "valu_nominal_cycles_per_inst": vj["clock_hz"] / inst_rate if inst_rate > 0 else None,
@@ -903,14 +1007,7 @@ def main():
                 "achieved_basis": "the DOMINANT kernel of this workload is the actor network: matrix-pipe FLOP issued per launch (2 x MACs of 32-256-256-256-4 per row; x 3 in split "
                                   "mode: hi hi + hi lo + lo hi) / its average launch duration by HIP events, against the dense peak of the pipe it issues on "
                                   "(fp16 / bf16 2.5 PFLOP/s, fp32 157.3 TFLOP/s); fp32_equivalent_tflops counts every fp32 product once"})
-        try:  # fp64 / MFMA issue figures of that kernel from its committed PMC pass (tools/make_valu_json.py --kernel)
-            with open(os.path.join(ROOT, "profiles", "valu_dominant_latest.json")) as f:
-                vj = json.load(f)
-            if vj.get("kernel") in _capi.KERNEL_NAMES[dom] and vj.get("n_agents") == N and vj.get("envs_per_launch") == Bs:
-                out["roofline"].update({"f64_flops_per_launch": vj.get("f64_flops_per_launch"), "f64_flop_frac": vj.get("f64_flops_per_launch", 0) / (dms * 1e-3) / 78.6e12,
-                                        "valu_insts_per_launch": vj.get("valu_insts_per_launch"), "valu_source": vj.get("source")})
-        except Exception:  # noqa: BLE001
-            pass
+        out["roofline"].update(cbf_valu_roofline(_capi.KERNEL_NAMES[dom], N, Bs, dms, out["roofline"]))
     run.close()
     if T > 1 and not args.no_compare and world == 1 and not use_dist:
         # the same workload with ONE launch per step (two env shards on two streams, the round-2 form): what the step loop inside the kernel buys
@@ -924,7 +1021,13 @@ def main():
         out["config"]["per_step_launch"] = {"ms_per_step": el1 / args.steps * 1e3, "value": total_agent_steps / el1, "env_shards_per_gpu": r1.S,
                                             "note": "same steps, one launch per step and env shard (sigmaenv_step_autoreset), timed after the headline regions at the GPU's "
                                                     "sustained clocks (compare with value_sustained, not with value); the better of two repetitions"}
+        # the form that writes ALL of SURVEY 8(d)'s outputs every step (a T-step launch writes the per-step outputs of its last step only: traffic_over_algorithmic < 1)
+        out["roofline"]["frac_full_outputs"] = bytes_per * out["config"]["per_step_launch"]["value"] / world / 1e9 / HBM_PEAK_GBPS
+        out["roofline"]["frac_full_outputs_note"] = ("algorithmic bytes x config.per_step_launch.value / 8 TB/s: one launch per step materialises every per-step output; "
+                                                     "`frac` credits the T-step launch with stores it elides (see traffic_over_algorithmic / frac_measured)")
         r1.close()
+    if args.lines and world == 1 and not use_dist and plain and args.scenario == "cpm_entire" and N == 16 and not args.param and not args.defaults and args.distance == "c2c":
+        out["config"]["lines"] = baseline_lines(args, device, torch, dist, step_s)
     if args.emulate_ranks > 1 and world == 1:
         # BASELINE config 3 (16 agents x 32768 envs over 8 GPUs) on the one GPU of this box: rank r's shard -- envs [r B, (r + 1) B) of the batch, the
         # same seed, its own rollout exchange (RCCL with world size 1 under --force-dist) -- timed like the headline, one rank after the other

@@ -52,11 +52,33 @@ def test_default_line_follows_the_contract():
     assert c["sustained"]["value"] == d["value_sustained"] and "cold_start" not in c
     assert abs(r["frac_sustained"] - 375 * d["value_sustained"] / 1e9 / 8000.0) <= 1e-12
     assert r["frac_measured"] is None or abs(r["frac_measured"] - r["achieved_measured"] / 8000.0) <= 1e-12
+    # the form that materialises every per-step output (one launch per step) next to the T-step launch's figure
+    assert abs(r["frac_full_outputs"] - 375 * c["per_step_launch"]["value"] / 1e9 / 8000.0) <= 1e-12 and r["frac_full_outputs"] < r["frac_sustained"]
+    # the issue-side picture against the MACHINE: VALU wave64 instructions x 2 cycles / (SIMDs x shader clock x time); between 0 and 1, and below the rate relative
+    # to the measured FMA stream (which itself does not reach the 2-cycle limit)
+    if "valu_issue_frac_arch" in r:
+        assert 0.0 < r["valu_lane_cycle_frac_arch"] <= r["valu_issue_frac_arch"] < 1.0
+        assert abs(r["valu_issue_frac_arch"] - r["valu_inst_per_s_per_simd"] * 2.0 / (r["shader_clock_hz_measured"] or 2.4e9)) <= 1e-9
+    # every other single-GPU BASELINE configuration rides in the same line (timed after the headline's regions)
+    lines = {l["name"]: l for l in c["lines"]}
+    assert list(lines) == ["config4_on_ramp_32x8192", "config5_cbf_qp", "distance_mtv", "reference_defaults"]
+    for name, l in lines.items():
+        assert "error" not in l, l
+        assert l["value"] > 0 and abs(l["value"] - l["n_agents"] * l["envs_per_gpu"] / (l["ms_per_step"] * 1e-3)) <= 1e-6 * l["value"] and l["wall_s"] < 8.0
+        lr = l["roofline"]
+        assert lr["bound"] in ("hbm", "valu") and 0.0 < lr["frac"] < 1.0 and lr["kernel"] == l["dominant_kernel"] and lr["kernel_avg_ms"] > 0
+    assert lines["config4_on_ramp_32x8192"]["n_agents"] == 32 and lines["config4_on_ramp_32x8192"]["envs_per_gpu"] == 8192
+    assert lines["config4_on_ramp_32x8192"]["roofline"]["algorithmic_bytes_per_agent_env_step"] == 44 + 251 + 5 * 32
+    assert "cbf_qp" in lines["config5_cbf_qp"]["dominant_kernel"] and lines["config5_cbf_qp"]["env_shards_per_gpu"] == 2
+    q = lines["config5_cbf_qp"]["roofline"]
+    if q["bound"] == "valu":  # (the committed PMC pass matches this workload) issue rate against one wave64 instruction per 2 cycles at the measured clock
+        assert q["unit"] == "G wave64-inst/s/SIMD" and abs(q["frac"] - q["achieved"] / q["peak"]) <= 1e-12 and 0.0 < q["f64_inst_share"] < 1.0 and q["hbm_frac"] < 0.05
+    assert lines["distance_mtv"]["value"] < d["value_sustained"] and lines["reference_defaults"]["value"] < lines["distance_mtv"]["value"] * 1.05
 
 
 def test_without_conditioning_there_is_no_sustained_figure():
-    d = _run("--cpu-seconds", "0", "--no-compare", "--condition-ms", "0")
-    assert "value_sustained" not in d and "sustained" not in d["config"] and d["warmup_effective_steps"] == 4
+    d = _run("--cpu-seconds", "0", "--no-compare", "--condition-ms", "0", "--no-lines")
+    assert "value_sustained" not in d and "sustained" not in d["config"] and d["warmup_effective_steps"] == 4 and "lines" not in d["config"]
 
 
 def test_config4_and_qp_lines_name_their_workload():
