@@ -7,7 +7,7 @@
  *
  * Parity status: PINNED.  tests/test_oracle_golden.py checks every function below
  * against golden vectors produced by running the reference itself in the build
- * container (tests/golden/*.npz, generator tests/golden/gen/gen_golden.py).
+ * container (tests/golden/ npz files, generator tests/golden/gen/gen_golden.py).
  * Third-party pieces the reference pulls from packages absent from
  * /root/reference are restated from their published behaviour and are "unpinned":
  *   torchdiffeq==0.2.5 odeint(method="euler")  -> one explicit Euler step
