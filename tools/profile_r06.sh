@@ -73,3 +73,5 @@ cd /tmp
 trace mtv --steps 256 --warmup 32 --cpu-seconds 0 --no-compare --distance mtv
 trace obs_bird --steps 256 --warmup 32 --cpu-seconds 0 --no-compare --param is_ego_view=false
 ls $out | head -100
+# the raw traces / counter dumps stay on the box (gpurun copies at most 64 MiB back): only the summaries above travel
+cd $R; find $out -maxdepth 1 -type d \( -name "trace_*" -o -name "pmc_*" \) -exec rm -rf {} +; find $out -name "*.err" -size +64k -delete; du -sh $out
