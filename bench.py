@@ -749,7 +749,7 @@ def main():
                     help="skip the additional per-step-launch measurement reported in config.per_step_launch")
     ap.add_argument("--emulate-ranks", type=int, default=0, help="after the headline: BASELINE config 3's workload on this ONE GPU -- R shards of --envs-per-gpu envs "
                     "(rank r = envs [r B, (r + 1) B) of the batch), each timed like the headline with its own rollout exchange; reported in config.emulated_ranks")
-    ap.add_argument("--no-lines", dest="lines", action="store_false", help="skip config.lines: the other single-GPU BASELINE configurations (config 4, config 5, mtv, the "
+    ap.add_argument("--no-lines", dest="lines", action="store_false", help="skip config.lines (--no-compare skips them too: profile runs must hold the headline's launches only): the other single-GPU BASELINE configurations (config 4, config 5, mtv, the "
                     "reference's defaults), each timed for a few seconds AFTER the headline's regions and appended to the headline's JSON line")
     ap.add_argument("--no-reset", action="store_true", help="diagnostic: leave finished envs un-reset")
     ap.add_argument("--separate-reset", action="store_true", help="two launches per step (sigmaenv_step; sigmaenv_auto_reset) instead of the fused one")
@@ -1026,7 +1026,7 @@ def main():
         out["roofline"]["frac_full_outputs_note"] = ("algorithmic bytes x config.per_step_launch.value / 8 TB/s: one launch per step materialises every per-step output; "
                                                      "`frac` credits the T-step launch with stores it elides (see traffic_over_algorithmic / frac_measured)")
         r1.close()
-    if args.lines and world == 1 and not use_dist and plain and args.scenario == "cpm_entire" and N == 16 and not args.param and not args.defaults and args.distance == "c2c":
+    if args.lines and not args.no_compare and world == 1 and not use_dist and plain and args.scenario == "cpm_entire" and N == 16 and not args.param and not args.defaults and args.distance == "c2c":
         out["config"]["lines"] = baseline_lines(args, device, torch, dist, step_s)
     if args.emulate_ranks > 1 and world == 1:
         # BASELINE config 3 (16 agents x 32768 envs over 8 GPUs) on the one GPU of this box: rank r's shard -- envs [r B, (r + 1) B) of the batch, the
