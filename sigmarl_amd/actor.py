@@ -121,7 +121,9 @@ class Actor:
         self.precision = precision
         self.lib = lib or capi.load_library()
         self._mlp32 = Mlp32(mlp, self.lib, mode=mode)  # the exact network (also kept by the bf16 variant: a caller may ask for either per call)
-        self._scratch_by_env = {}
+        import weakref
+
+        self._scratch_by_env = weakref.WeakKeyDictionary()  # SigmaEnv -> {kind: tensor}
         lin = [m for m in mlp.modules() if isinstance(m, torch.nn.Linear)]
         if len(lin) != 4 or lin[1].in_features != 256 or lin[2].out_features != 256 or lin[3].out_features != 4:
             raise ValueError("expected Linear(D,256), Linear(256,256), Linear(256,256), Linear(256,4)")
@@ -162,21 +164,23 @@ class Actor:
         except Exception:  # noqa: BLE001
             pass
 
-    # Scratch buffers are keyed PER ENV HANDLE: one Actor may drive several env shards on their own streams (bench.py --policy --streams 2), and a buffer shared by two
-    # shards of equal size would be overwritten by the other shard's launches.  Entries live as long as the Actor (a handful of shards).
-    def _scratch_actions(self, env: SigmaEnv) -> torch.Tensor:
-        t = self._scratch_by_env.get(("a", env.h.value if hasattr(env.h, "value") else id(env)))
-        if t is None or t.shape[0] != env.B or t.device != env.device:
-            t = torch.zeros((env.B, env.N, 2), dtype=torch.float32, device=env.device)
-            self._scratch_by_env[("a", env.h.value if hasattr(env.h, "value") else id(env))] = t
+    # Scratch buffers are keyed PER ENV OBJECT: one Actor may drive several env shards on their own streams (bench.py --policy --streams 2), and a buffer shared by two
+    # shards of equal size would be overwritten by the other shard's launches.  The key is the SigmaEnv itself, held weakly (the raw handle
+    # address can be handed to a NEW env after close() -- same B, larger N: an undersized buffer, written past its end -- and the entries of closed envs never went
+    # away); the FULL shape is compared as well.
+    def _scratch(self, kind: str, env: SigmaEnv, shape, zero: bool) -> torch.Tensor:
+        per_env = self._scratch_by_env.setdefault(env, {})
+        t = per_env.get(kind)
+        if t is None or tuple(t.shape) != tuple(shape) or t.device != env.device:
+            t = (torch.zeros if zero else torch.empty)(tuple(shape), dtype=torch.float32, device=env.device)
+            per_env[kind] = t
         return t
 
+    def _scratch_actions(self, env: SigmaEnv) -> torch.Tensor:
+        return self._scratch("a", env, (env.B, env.N, 2), True)
+
     def _scratch_out4(self, env: SigmaEnv) -> torch.Tensor:
-        t = self._scratch_by_env.get(("o", env.h.value if hasattr(env.h, "value") else id(env)))
-        if t is None or t.shape[0] != env.B * env.N or t.device != env.device:
-            t = torch.empty((env.B * env.N, 4), dtype=torch.float32, device=env.device)
-            self._scratch_by_env[("o", env.h.value if hasattr(env.h, "value") else id(env))] = t
-        return t
+        return self._scratch("o", env, (env.B * env.N, 4), False)
 
     def forward(self, env: SigmaEnv, actions: torch.Tensor, log_prob: torch.Tensor | None = None, loc_scale: torch.Tensor | None = None,
                 obs: torch.Tensor | None = None, seed: int = 0, counter: int = 0, deterministic: bool = False, precision: str | None = None):
