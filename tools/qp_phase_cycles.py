@@ -15,13 +15,14 @@ for _ in range(20):
 u = torch.zeros((B,N,2), dtype=torch.float64, device="cuda"); info = torch.zeros((B,2), dtype=torch.int32, device="cuda")
 for _ in range(int(os.environ.get("QP_CALLS", 1))):  # (QP_CALLS > 1: repeated solves of the same problem)
     env.cbf_qp(act, None, u, info); env.sync()
-d = u.reshape(B,-1)[:, :21].cpu()
+d = u.reshape(B,-1)[:, :22].cpu()
 it = info[:,0].float().cpu()
 print("cycles (x100MHz shader clock?) mean total %.0f eval %.0f chol %.0f ls %.0f ; iters mean %.2f" % (d[:,0].mean(), d[:,1].mean(), d[:,2].mean(), d[:,3].mean(), it.mean()))
 print("per iteration: eval %.0f chol %.0f ls %.0f ; outside loop %.0f" % ((d[:,1]/it).mean(), (d[:,2]/it).mean(), (d[:,3]/it).mean(), (d[:,0]-d[:,1]-d[:,2]-d[:,3]).mean()))
 print("before the Newton loop: load %.0f stencil phase %.0f lane + candidate rows %.0f" % (d[:,4].mean(), d[:,5].mean(), d[:,6].mean()))
 print("candidate pair rows per env: mean %.1f p50 %.0f p90 %.0f max %.0f (of %d pair rows); lane rows %d" % (d[:,7].mean(), d[:,7].median(), d[:,7].quantile(0.9), d[:,7].max(), N*(N-1)//2*9, N*3*2))
 z = d[:,7] == 0
+print("pairs whose rows were evaluated (of %d): mean %.1f p50 %.0f p90 %.0f max %.0f" % (N*(N-1)//2, d[:,21].mean(), d[:,21].median(), d[:,21].quantile(0.9), d[:,21].max()))
 print("stencil phase of the Newton wavefront: set-up %.0f, stage 1 %.0f, stage 2 %.0f, bound %.0f, later passes %.0f, conversion + barrier %.0f" % tuple(d[:,k].mean() for k in range(15, 21)))
 print("between the stencil phase and the Newton phase: lane rows %.0f, candidate flags %.0f, compaction %.0f; register path %.0f (without / with candidates %.0f / %.0f), output phase %.0f" % (d[:,10].mean(), d[:,11].mean(), d[:,12].mean(), d[:,1].mean(), d[z,1].mean(), d[~z,1].mean(), d[:,13].mean()))
 print("envs without candidate pair rows: %.1f %%; Newton phase cycles (loop + outputs): those %.0f, the rest %.0f; iterations %.2f / %.2f" % (100*z.float().mean(), d[z,0].mean(), d[~z,0].mean(), it[z].mean(), it[~z].mean()))
