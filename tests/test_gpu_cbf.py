@@ -390,6 +390,52 @@ def test_cbf_qp_dense_cluster_uses_the_full_system(N):
     ora.close()
 
 
+def test_cbf_qp_mixed_batch_of_lean_and_deferred_envs():
+    """Round 6: up to 32 vehicles the LEAN instantiation solves an env unless its register path cannot take it (more than 8 vehicles in candidate pair rows); such an env
+    is flagged and solved by the full-layout launch that follows, one workgroup per span of 16 envs.  A batch over three spans in which every other env is a dense pile
+    (deferred) and the rest are spread out (solved by the lean launch): both kinds equal the oracle, and the flags are cleared -- a second call on the same handle with
+    every env spread out, and a third with the piles back, are right as well."""
+    z, meta = _cbf_fixture()
+    B, N = 40, 24
+    mp = load_map("cpm_entire")
+    p = Parameters(n_agents=N, scenario_type="cpm_entire", dt=0.05, rew_method="cbf", is_solve_qp=True, is_using_cbf_training=True, is_obs_noise=False, is_apply_mask=False)
+    cfg = make_config(p, mp, B)
+    dev, ora = _hip_env(cfg, mp), ob.OracleEnv(cfg, mp)
+    seg_l, seg_r = cbf.load_segment_tables(mp)
+    rng = np.random.default_rng(17)
+    ids = np.zeros((B, N, 4), np.int32)
+
+    def states(dense_mask):
+        st8 = np.zeros((B, N, 8), np.float32)
+        for b in range(B):
+            src = b % z["p2_state"].shape[0]
+            st8[b, :, :5] = z["p2_state"][src, 0]
+            spread = 0.25 if dense_mask[b] else 2.0  # a pile within half a metre, or vehicles metres apart
+            st8[b, :, 0:2] += rng.uniform(-spread, spread, (N, 2)).astype(np.float32)
+            st8[b, :, 2] += rng.uniform(-0.5, 0.5, N).astype(np.float32)
+            st8[b, :, 3] = rng.uniform(0.0, 1.0, N).astype(np.float32)
+            ids[b, :, 0] = z["p2_path"][src, 0]
+        ids[..., 2] = ids[..., 0]
+        return st8
+
+    for e in (dev, ora):
+        e.cbf_attach(cbf.make_cbf_config(p), seg_l, seg_r)
+    n_iter_dense = []
+    for dense in (np.arange(B) % 2 == 0, np.zeros(B, bool), np.arange(B) % 3 == 0):
+        st8 = states(dense)
+        for e in (dev, ora):
+            e.reset(np.repeat(np.arange(B), N), np.tile(np.arange(N), B), ids.reshape(-1, 4), st8.reshape(-1, 8), 1)
+        act = rng.uniform(-0.3, 1.0, (B, N, 2)).astype(np.float32)
+        safe_d, u_d, info_d = dev.cbf_qp(act)
+        safe_o, u_o, info_o = ora.cbf_qp(act)[:3]
+        assert np.array_equal(info_d[:, 1], info_o[:, 1]) and info_o[:, 1].all(), (info_d[:, 1], info_o[:, 1])
+        assert np.abs(u_d - u_o).max() <= 1e-6 and np.abs(safe_d - safe_o).max() <= 1e-6, (np.abs(u_d - u_o).max(), np.flatnonzero(np.abs(u_d - u_o).max(axis=(1, 2)) > 1e-6))
+        n_iter_dense.append(int(info_d[dense, 0].sum()) if dense.any() else 0)
+    assert n_iter_dense[0] > 0 and n_iter_dense[2] > 0
+    dev.close()
+    ora.close()
+
+
 def test_cbf_qp_is_bitwise_repeatable():
     """The candidate list is compacted in row order and the Newton phase runs on one wavefront (its LDS atomics execute in program / lane
     order): repeated launches on the same state return the same bits."""
